@@ -1,0 +1,151 @@
+/*
+ * sonar_mi355.h -- C ABI of the MI355X-native SONAR inference hot path.
+ *
+ * The reference (facebookresearch/SONAR v0.4.0) has no native code and no FFI:
+ * its hot path is `model(batch)` inside the Python pipelines.  The entry points
+ * below are what a binding for that path attaches to; each one cites the
+ * reference interface it stands in for (paths relative to the reference repo).
+ * INTEGRATION.md shows the ctypes stub a SONAR maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *  - every call returns SMI_OK (0) or a negative smi_status; smi_last_error()
+ *    returns a thread-local human readable message for the last failure;
+ *  - device buffers passed in are borrowed for the duration of the call (it is
+ *    stream-ordered: the call enqueues work on `stream` and returns);
+ *  - the engine owns its packed weights and workspace; the caller may free its
+ *    own weight buffers as soon as *_create returns;
+ *  - a handle is not re-entrant: use one handle per device and per thread;
+ *  - nothing here falls back to the CPU: without a HIP device every compute
+ *    entry point fails with SMI_ERR_NO_DEVICE.
+ */
+#ifndef SONAR_MI355_H
+#define SONAR_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum smi_status {
+  SMI_OK = 0,
+  SMI_ERR_INVALID_ARG = -1,
+  SMI_ERR_UNSUPPORTED = -2, /* shape/config outside what the kernels cover */
+  SMI_ERR_NO_DEVICE = -3,
+  SMI_ERR_OOM = -4,
+  SMI_ERR_HIP = -5 /* a HIP runtime call failed; see smi_last_error() */
+} smi_status;
+
+typedef enum smi_dtype { SMI_F32 = 0, SMI_F16 = 1 } smi_dtype;
+typedef enum smi_pooling { SMI_POOL_MEAN = 0, SMI_POOL_MAX = 1, SMI_POOL_LAST = 2 } smi_pooling;
+
+/* A dense tensor handed to the engine at create time.  `data` may live in host
+ * or device memory (`on_device`); fp32 or fp16. */
+typedef struct smi_tensor {
+  const void* data;
+  int32_t dtype;     /* smi_dtype */
+  int32_t on_device; /* 0 host, 1 device (current HIP device) */
+  int64_t numel;
+} smi_tensor;
+
+/* Mirrors SonarTextEncoderConfig (sonar/models/sonar_text/config.py:14-85) for
+ * the fields that affect the forward pass of the `basic`/`small` archs. */
+typedef struct smi_text_encoder_config {
+  int32_t model_dim;     /* 1024; must be num_heads*64 and a multiple of 256 */
+  int32_t num_layers;    /* 24 */
+  int32_t num_heads;     /* 16 */
+  int32_t ffn_inner_dim; /* 8192; multiple of 128 */
+  int64_t vocab_size;    /* 256206 */
+  int32_t max_seq_len;   /* 514 = 512 + pad_idx + 1 (factory.py:56-59) */
+  int32_t pos_offset;    /* 2 = pad_idx + 1 (_legacy_pad_idx, factory.py:88-92) */
+  float embed_scale;     /* sqrt(model_dim), or 1 if no_scale_embedding */
+  float ln_eps;          /* 1e-5 */
+  int32_t pooling;       /* smi_pooling (config.py: pooling="mean") */
+  int32_t reserved;
+} smi_text_encoder_config;
+
+/* Per-layer parameters, names as produced by the reference's checkpoint
+ * conversion (sonar/models/sonar_text/handler.py:71-82).  Linear weights are
+ * [out, in] row-major as in torch.nn.Linear. */
+typedef struct smi_text_encoder_layer {
+  smi_tensor self_attn_layer_norm_w, self_attn_layer_norm_b;
+  smi_tensor q_w, q_b, k_w, k_b, v_w, v_b, out_w, out_b;
+  smi_tensor ffn_layer_norm_w, ffn_layer_norm_b;
+  smi_tensor ffn_inner_w, ffn_inner_b, ffn_out_w, ffn_out_b;
+} smi_text_encoder_layer;
+
+typedef struct smi_text_encoder_weights {
+  smi_tensor embed;     /* encoder_frontend.embed.weight [vocab, model_dim] */
+  smi_tensor pos_table; /* sinusoidal table [max_seq_len + pos_offset, model_dim] fp32 */
+  smi_tensor final_layer_norm_w, final_layer_norm_b; /* model-level layer_norm (factory.py:117) */
+  const smi_text_encoder_layer* layers;              /* num_layers entries */
+} smi_text_encoder_weights;
+
+typedef struct smi_text_encoder smi_text_encoder; /* opaque */
+
+/* Library / device ------------------------------------------------------- */
+const char* smi_version(void);
+const char* smi_last_error(void);
+/* Selects the HIP device for this thread (hipSetDevice). */
+int smi_init(int device_id);
+int smi_device_count(void);
+
+/* Text encoder ------------------------------------------------------------
+ * Stands in for: SonarTextEncoderFactory.create_model + checkpoint load
+ * (sonar/models/sonar_text/factory.py:72-120, handler.py:52-94) and
+ * SonarTextTransformerEncoderModel.forward (sonar/models/sonar_text/model.py:130-143)
+ * as invoked by `.map(self.model)` in
+ * TextToEmbeddingModelPipeline.predict (sonar/inference_pipelines/text.py:244). */
+int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_encoder_weights* w,
+                            int64_t max_tokens_hint, smi_text_encoder** out);
+void smi_text_encoder_destroy(smi_text_encoder* enc);
+
+/* ids:      device int64 [n, s] right-padded token ids (SequenceBatch.seqs)
+ * seq_lens: HOST int32 [n] valid lengths, or NULL when the batch is not ragged
+ *           (PaddingMask is None, sonar/inference_pipelines/utils.py:18-21)
+ * out_emb:  device [n, model_dim] sentence_embeddings, out_dtype
+ * out_encoded: optional device [n, s, model_dim] encoded_seqs (out_dtype), pads zeroed; may be NULL
+ * stream:   hipStream_t (NULL = default stream) */
+int smi_text_encoder_forward(smi_text_encoder* enc, const int64_t* ids, const int32_t* seq_lens,
+                             int32_t n, int32_t s, void* out_emb, void* out_encoded,
+                             int32_t out_dtype, void* stream);
+
+/* Bytes of device memory currently held by the handle (weights + workspace). */
+int64_t smi_text_encoder_device_bytes(const smi_text_encoder* enc);
+
+/* xsim mining ---------------------------------------------------------------
+ * Stands in for the similarity search the reference performs as
+ * F.normalize(x) @ F.normalize(y).T (tests/integration_tests/test_text_sonar.py:42-53)
+ * and that xsim (README.md:5) evaluates: for each of the nx rows of X return the
+ * k (<= 8) most cosine-similar rows of Y, best first.
+ *
+ * smi_xsim_normalize: dst = f16 row-normalised copy of src, padded with zero
+ *   rows to a multiple of 128 rows (dst must hold smi_xsim_padded_rows(rows)*d f16).
+ * smi_xsim_topk: Xn/Yn are such normalised, padded matrices.  idx [nx,k] int32
+ *   (row index in Y plus y_index_offset; -1 if fewer than k candidates),
+ *   score [nx,k] fp32.  workspace: smi_xsim_workspace_bytes() bytes of device memory. */
+int64_t smi_xsim_padded_rows(int64_t rows);
+int smi_xsim_normalize(const void* src, int32_t src_dtype, int64_t rows, int32_t d, void* dst_f16,
+                       void* stream);
+int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k);
+int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny, int32_t d,
+                  int32_t k, int64_t y_index_offset, int32_t* idx, float* score, void* workspace,
+                  void* stream);
+
+/* Building blocks (exported for the parity tests and microbenchmarks) ------ */
+/* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi: 0 f16 out, 1 f16 ReLU out,
+ * 2 fp32 residual accumulate (out += ...).  m%128==0, n%128==0, k%64==0. */
+int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
+                int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);
+int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out_f16,
+                  int32_t rows, int32_t d, void* stream);
+/* qkv: f16 [t, 3*d] packed rows; cu_seqlens: device int32 [n+1]; ctx: f16 [t, d] */
+int smi_attention(const void* qkv_f16, const int32_t* cu_seqlens, void* ctx_f16, int32_t n,
+                  int32_t max_len, int32_t d, int32_t heads, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SONAR_MI355_H */

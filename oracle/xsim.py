@@ -1,0 +1,53 @@
+"""ORACLE -- test infrastructure only.  Never imported by the product package.
+
+xsim cosine mining on the CPU in fp32.  The reference does not implement xsim
+(it is only named, README.md:5); the nearest in-tree code is
+`F.normalize(x) @ F.normalize(y).T` at tests/integration_tests/test_text_sonar.py:42-53.
+The external definition restated here is LASER's xsim: nearest
+neighbour by cosine, or by ratio margin with k = 4.  PARITY IS UNPINNED for
+xsim: the reference holds no golden vector or fixture for it.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def cosine_topk(x: torch.Tensor, y: torch.Tensor, k: int, block: int = 4096):
+    """Top-k cosine neighbours in y for every row of x. Returns (scores [nx,k], idx [nx,k]).
+    Ties are broken towards the lower index (same total order as the kernel)."""
+    xn = F.normalize(x.float(), dim=-1)
+    yn = F.normalize(y.float(), dim=-1)
+    scores, idxs = [], []
+    for i in range(0, xn.shape[0], block):
+        s = xn[i:i + block] @ yn.T
+        # stable sort descending == (score desc, index asc)
+        order = torch.sort(s, dim=1, descending=True, stable=True)
+        scores.append(order.values[:, :k])
+        idxs.append(order.indices[:, :k])
+    return torch.cat(scores), torch.cat(idxs)
+
+
+def xsim_error_rate(x: torch.Tensor, y: torch.Tensor, margin: str = "cosine", k: int = 4) -> float:
+    """Fraction of rows i whose best match in y is not row i (x[i] <-> y[i] aligned)."""
+    xn = F.normalize(x.float(), dim=-1)
+    yn = F.normalize(y.float(), dim=-1)
+    s = xn @ yn.T
+    if margin == "ratio":
+        kx = s.topk(min(k, s.shape[1]), dim=1).values.mean(dim=1)  # x -> y neighbourhood
+        ky = s.topk(min(k, s.shape[0]), dim=0).values.mean(dim=0)  # y -> x neighbourhood
+        s = s / (0.5 * (kx.unsqueeze(1) + ky.unsqueeze(0)))
+    elif margin != "cosine":
+        raise ValueError(margin)
+    pred = s.argmax(dim=1)
+    return float((pred != torch.arange(s.shape[0])).float().mean())
+
+
+def synthetic_pairs(n: int, d: int = 1024, noise: float = 0.3, seed: int = 2):
+    """Y unit-normalised N(0,1); X = normalise(Y[perm] + noise*N(0,1))."""
+    g = torch.Generator().manual_seed(seed)
+    y = F.normalize(torch.randn(n, d, generator=g), dim=-1)
+    g2 = torch.Generator().manual_seed(seed + 1)
+    perm = torch.randperm(n, generator=g2)
+    x = F.normalize(y[perm] + noise * torch.randn(n, d, generator=g2) / (d ** 0.5), dim=-1)
+    return x, y, perm

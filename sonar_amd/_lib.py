@@ -1,0 +1,135 @@
+"""ctypes binding of the C ABI declared in include/sonar_mi355.h.
+
+The shared library is the product path.  There is no CPU fallback: if the
+library has not been built, `load()` raises, and every compute entry point of
+the library itself fails with SMI_ERR_NO_DEVICE when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
+
+SMI_OK = 0
+SMI_F32, SMI_F16 = 0, 1
+SMI_POOL = {"mean": 0, "max": 1, "last": 2}
+STATUS_NAMES = {
+    0: "SMI_OK",
+    -1: "SMI_ERR_INVALID_ARG",
+    -2: "SMI_ERR_UNSUPPORTED",
+    -3: "SMI_ERR_NO_DEVICE",
+    -4: "SMI_ERR_OOM",
+    -5: "SMI_ERR_HIP",
+}
+
+
+class SmiError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class smi_tensor(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("on_device", C.c_int32),
+        ("numel", C.c_int64),
+    ]
+
+
+class smi_text_encoder_config(C.Structure):
+    _fields_ = [
+        ("model_dim", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("ffn_inner_dim", C.c_int32),
+        ("vocab_size", C.c_int64),
+        ("max_seq_len", C.c_int32),
+        ("pos_offset", C.c_int32),
+        ("embed_scale", C.c_float),
+        ("ln_eps", C.c_float),
+        ("pooling", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+_LAYER_FIELDS = [
+    "self_attn_layer_norm_w", "self_attn_layer_norm_b",
+    "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "out_w", "out_b",
+    "ffn_layer_norm_w", "ffn_layer_norm_b",
+    "ffn_inner_w", "ffn_inner_b", "ffn_out_w", "ffn_out_b",
+]
+
+
+class smi_text_encoder_layer(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in _LAYER_FIELDS]
+
+
+class smi_text_encoder_weights(C.Structure):
+    _fields_ = [
+        ("embed", smi_tensor),
+        ("pos_table", smi_tensor),
+        ("final_layer_norm_w", smi_tensor),
+        ("final_layer_norm_b", smi_tensor),
+        ("layers", C.POINTER(smi_text_encoder_layer)),
+    ]
+
+
+# every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SYMBOLS = {
+    "smi_version": (C.c_char_p, []),
+    "smi_last_error": (C.c_char_p, []),
+    "smi_init": (C.c_int, [C.c_int]),
+    "smi_device_count": (C.c_int, []),
+    "smi_text_encoder_create": (C.c_int, [C.POINTER(smi_text_encoder_config),
+                                          C.POINTER(smi_text_encoder_weights), _i64,
+                                          C.POINTER(_vp)]),
+    "smi_text_encoder_destroy": (None, [_vp]),
+    "smi_text_encoder_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "smi_text_encoder_device_bytes": (_i64, [_vp]),
+    "smi_xsim_padded_rows": (_i64, [_i64]),
+    "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp]),
+    "smi_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libsonar_mi355.so (torch is imported first so both share one HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m sonar_amd.build` "
+            "(needs hipcc, gfx950). There is no CPU fallback for the SONAR hot path."
+        )
+    import torch  # noqa: F401  (loads libamdhip64 the way torch wants it)
+
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != SMI_OK:
+        raise SmiError(status, load().smi_last_error().decode("utf-8", "replace"))
+
+
+def current_stream_ptr() -> int:
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)

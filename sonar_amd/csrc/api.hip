@@ -1,0 +1,421 @@
+// C-ABI implementation (see include/sonar_mi355.h).  Host-side runtime of the
+// engine: weight packing into the fp16/fp32 HBM layout the kernels want,
+// stream-ordered workspace, and the per-layer launch schedule of the text
+// encoder forward pass (reference op order: sonar/models/sonar_text/model.py:130-143
+// + factory.py:102-153, pre-LN layers, model-level final LayerNorm, pooling).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sonar_mi355.h"
+#include "kernels.hpp"
+
+using namespace smi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return fail(_e == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "%s failed: %s",  \
+                  #expr, hipGetErrorString(_e));                                           \
+  } while (0)
+
+bool have_device() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <typename T>
+  T* as() const {
+    return (T*)p;
+  }
+};
+
+// Copy a caller tensor into a freshly allocated device buffer as fp16 or fp32.
+int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst, const char* name) {
+  if (!t.data) return fail(SMI_ERR_INVALID_ARG, "weight %s: null data", name);
+  if (t.numel != expect_numel)
+    return fail(SMI_ERR_INVALID_ARG, "weight %s: numel %lld, expected %lld", name,
+                (long long)t.numel, (long long)expect_numel);
+  if (t.dtype != SMI_F32 && t.dtype != SMI_F16)
+    return fail(SMI_ERR_INVALID_ARG, "weight %s: bad dtype %d", name, t.dtype);
+  const size_t n = (size_t)t.numel;
+  const size_t src_es = t.dtype == SMI_F32 ? 4 : 2;
+  const size_t dst_es = want_f16 ? 2 : 4;
+  HIP_TRY(dst.alloc(n * dst_es));
+  const bool same = (t.dtype == SMI_F16) == want_f16;
+  const hipMemcpyKind kind = t.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (same) {
+    HIP_TRY(hipMemcpy(dst.p, t.data, n * src_es, kind));
+    return SMI_OK;
+  }
+  // convert through a bounded staging buffer (the embedding table is ~1 GB fp32)
+  const size_t chunk = (size_t)32 << 20;  // elements
+  DevBuf stage;
+  if (!t.on_device) HIP_TRY(stage.alloc(std::min(n, chunk) * src_es));
+  for (size_t off = 0; off < n; off += chunk) {
+    const size_t m = std::min(chunk, n - off);
+    const void* src = (const char*)t.data + off * src_es;
+    if (!t.on_device) {
+      HIP_TRY(hipMemcpy(stage.p, src, m * src_es, hipMemcpyHostToDevice));
+      src = stage.p;
+    }
+    if (want_f16)
+      HIP_TRY(launch_f32_to_f16((const float*)src, dst.as<f16>() + off, m, nullptr));
+    else
+      HIP_TRY(launch_f16_to_f32((const f16*)src, dst.as<float>() + off, m, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
+  return SMI_OK;
+}
+
+struct Layer {
+  DevBuf ln1_w, ln1_b, w_qkv, b_qkv, w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2;
+};
+
+constexpr int kCuRing = 8;
+
+}  // namespace
+
+struct smi_text_encoder {
+  smi_text_encoder_config cfg;
+  DevBuf embed, pos, lnf_w, lnf_b;
+  std::vector<Layer> layers;
+  // workspace (capacity in packed+padded token rows)
+  int64_t cap_rows = 0;
+  DevBuf x, h, qkv, ctx, ffn;
+  // cu_seqlens staging ring: pinned host + device copies
+  int32_t* h_cu[kCuRing] = {};
+  DevBuf d_cu[kCuRing];
+  hipEvent_t cu_ev[kCuRing] = {};
+  int64_t cu_cap = 0;
+  int cu_next = 0;
+  int64_t weight_bytes = 0;
+
+  ~smi_text_encoder() {
+    for (int i = 0; i < kCuRing; ++i) {
+      if (h_cu[i]) (void)hipHostFree(h_cu[i]);
+      if (cu_ev[i]) (void)hipEventDestroy(cu_ev[i]);
+    }
+  }
+};
+
+namespace {
+
+int ensure_cu(smi_text_encoder* e, int64_t n) {
+  if (n + 1 <= e->cu_cap) return SMI_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t cap = std::max<int64_t>(n + 1, 4096);
+  for (int i = 0; i < kCuRing; ++i) {
+    if (e->h_cu[i]) (void)hipHostFree(e->h_cu[i]);
+    e->h_cu[i] = nullptr;
+    HIP_TRY(hipHostMalloc((void**)&e->h_cu[i], cap * sizeof(int32_t), hipHostMallocDefault));
+    HIP_TRY(e->d_cu[i].alloc(cap * sizeof(int32_t)));
+    if (!e->cu_ev[i]) HIP_TRY(hipEventCreateWithFlags(&e->cu_ev[i], hipEventDisableTiming));
+  }
+  e->cu_cap = cap;
+  return SMI_OK;
+}
+
+int ensure_workspace(smi_text_encoder* e, int64_t rows) {
+  if (rows <= e->cap_rows) return SMI_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  const int64_t d = e->cfg.model_dim, f = e->cfg.ffn_inner_dim;
+  e->cap_rows = 0;
+  HIP_TRY(e->x.alloc((size_t)rows * d * 4));
+  HIP_TRY(e->h.alloc((size_t)rows * d * 2));
+  HIP_TRY(e->qkv.alloc((size_t)rows * 3 * d * 2));
+  HIP_TRY(e->ctx.alloc((size_t)rows * d * 2));
+  HIP_TRY(e->ffn.alloc((size_t)rows * f * 2));
+  // rows that no kernel writes (tile padding) must hold finite values
+  HIP_TRY(hipMemset(e->x.p, 0, e->x.bytes));
+  HIP_TRY(hipMemset(e->h.p, 0, e->h.bytes));
+  HIP_TRY(hipMemset(e->qkv.p, 0, e->qkv.bytes));
+  HIP_TRY(hipMemset(e->ctx.p, 0, e->ctx.bytes));
+  HIP_TRY(hipMemset(e->ffn.p, 0, e->ffn.bytes));
+  e->cap_rows = rows;
+  return SMI_OK;
+}
+
+int check_cfg(const smi_text_encoder_config& c) {
+  if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
+    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must equal num_heads %d * 64", c.model_dim,
+                c.num_heads);
+  if (c.model_dim % 256 || (c.model_dim / 256 > 4 && c.model_dim != 2048))
+    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must be 256/512/768/1024/2048", c.model_dim);
+  if (c.ffn_inner_dim <= 0 || c.ffn_inner_dim % 128)
+    return fail(SMI_ERR_UNSUPPORTED, "ffn_inner_dim %d must be a multiple of 128", c.ffn_inner_dim);
+  if (c.num_layers < 0 || c.vocab_size <= 0 || c.max_seq_len <= 0 || c.pos_offset < 0)
+    return fail(SMI_ERR_INVALID_ARG, "bad num_layers/vocab_size/max_seq_len/pos_offset");
+  if (c.pooling < SMI_POOL_MEAN || c.pooling > SMI_POOL_LAST)
+    return fail(SMI_ERR_INVALID_ARG, "bad pooling %d", c.pooling);
+  return SMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* smi_version(void) { return "sonar_mi355 0.1.0 (gfx950)"; }
+const char* smi_last_error(void) { return g_err.c_str(); }
+
+int smi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int smi_init(int device_id) {
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(hipSetDevice(device_id));
+  return SMI_OK;
+}
+
+int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_encoder_weights* w,
+                            int64_t max_tokens_hint, smi_text_encoder** out) {
+  if (!cfg || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (int rc = check_cfg(*cfg)) return rc;
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->num_layers > 0 && !w->layers) return fail(SMI_ERR_INVALID_ARG, "null layers");
+
+  smi_text_encoder* e = new smi_text_encoder();
+  e->cfg = *cfg;
+  const int64_t d = cfg->model_dim, f = cfg->ffn_inner_dim;
+  int rc = SMI_OK;
+  auto up = [&](const smi_tensor& t, int64_t numel, bool f16, DevBuf& dst, const char* name) {
+    if (rc == SMI_OK) rc = upload(t, numel, f16, dst, name);
+  };
+  up(w->embed, cfg->vocab_size * d, true, e->embed, "embed");
+  up(w->pos_table, (int64_t)(cfg->max_seq_len + cfg->pos_offset) * d, false, e->pos, "pos_table");
+  up(w->final_layer_norm_w, d, false, e->lnf_w, "layer_norm.weight");
+  up(w->final_layer_norm_b, d, false, e->lnf_b, "layer_norm.bias");
+  e->layers.resize(cfg->num_layers);
+  for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
+    const smi_text_encoder_layer& s = w->layers[l];
+    Layer& L = e->layers[l];
+    up(s.self_attn_layer_norm_w, d, false, L.ln1_w, "self_attn_layer_norm.weight");
+    up(s.self_attn_layer_norm_b, d, false, L.ln1_b, "self_attn_layer_norm.bias");
+    up(s.ffn_layer_norm_w, d, false, L.ln2_w, "ffn_layer_norm.weight");
+    up(s.ffn_layer_norm_b, d, false, L.ln2_b, "ffn_layer_norm.bias");
+    up(s.out_w, d * d, true, L.w_o, "output_proj.weight");
+    up(s.out_b, d, false, L.b_o, "output_proj.bias");
+    up(s.ffn_inner_w, f * d, true, L.w_1, "ffn.inner_proj.weight");
+    up(s.ffn_inner_b, f, false, L.b_1, "ffn.inner_proj.bias");
+    up(s.ffn_out_w, d * f, true, L.w_2, "ffn.output_proj.weight");
+    up(s.ffn_out_b, d, false, L.b_2, "ffn.output_proj.bias");
+    // fused [q; k; v] projection: one [3d, d] weight, one [3d] bias
+    if (rc == SMI_OK) {
+      DevBuf tq, tk, tv, bq, bk, bv;
+      up(s.q_w, d * d, true, tq, "q_proj.weight");
+      up(s.k_w, d * d, true, tk, "k_proj.weight");
+      up(s.v_w, d * d, true, tv, "v_proj.weight");
+      up(s.q_b, d, false, bq, "q_proj.bias");
+      up(s.k_b, d, false, bk, "k_proj.bias");
+      up(s.v_b, d, false, bv, "v_proj.bias");
+      if (rc == SMI_OK) {
+        hipError_t he = L.w_qkv.alloc((size_t)3 * d * d * 2);
+        if (he == hipSuccess) he = L.b_qkv.alloc((size_t)3 * d * 4);
+        const size_t wb = (size_t)d * d * 2, bb = (size_t)d * 4;
+        if (he == hipSuccess) he = hipMemcpy(L.w_qkv.p, tq.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + wb, tk.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + 2 * wb, tv.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy(L.b_qkv.p, bq.p, bb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.b_qkv.p + bb, bk.p, bb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.b_qkv.p + 2 * bb, bv.p, bb, hipMemcpyDeviceToDevice);
+        if (he != hipSuccess)
+          rc = fail(he == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "packing qkv: %s",
+                    hipGetErrorString(he));
+      }
+    }
+  }
+  if (rc == SMI_OK && max_tokens_hint > 0) rc = ensure_workspace(e, (max_tokens_hint + 127) / 128 * 128);
+  if (rc != SMI_OK) {
+    delete e;
+    return rc;
+  }
+  e->weight_bytes = (int64_t)(e->embed.bytes + e->pos.bytes + 2 * e->lnf_w.bytes);
+  for (auto& L : e->layers)
+    e->weight_bytes += (int64_t)(L.w_qkv.bytes + L.b_qkv.bytes + L.w_o.bytes + L.b_o.bytes +
+                                 L.w_1.bytes + L.b_1.bytes + L.w_2.bytes + L.b_2.bytes +
+                                 4 * L.ln1_w.bytes);
+  *out = e;
+  return SMI_OK;
+}
+
+void smi_text_encoder_destroy(smi_text_encoder* enc) {
+  if (!enc) return;
+  (void)hipDeviceSynchronize();
+  delete enc;
+}
+
+int64_t smi_text_encoder_device_bytes(const smi_text_encoder* e) {
+  if (!e) return 0;
+  return e->weight_bytes + (int64_t)(e->x.bytes + e->h.bytes + e->qkv.bytes + e->ctx.bytes + e->ffn.bytes);
+}
+
+int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int32_t* seq_lens,
+                             int32_t n, int32_t s, void* out_emb, void* out_encoded,
+                             int32_t out_dtype, void* stream_v) {
+  if (!e || !ids || !out_emb) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || s <= 0) return fail(SMI_ERR_INVALID_ARG, "empty batch (n=%d, s=%d)", n, s);
+  if (out_dtype != SMI_F32 && out_dtype != SMI_F16)
+    return fail(SMI_ERR_INVALID_ARG, "bad out_dtype %d", out_dtype);
+  const smi_text_encoder_config& c = e->cfg;
+  if (s > c.max_seq_len)
+    return fail(SMI_ERR_INVALID_ARG, "seq_len %d exceeds max_seq_len %d of the encoder", s,
+                c.max_seq_len);
+  hipStream_t stream = (hipStream_t)stream_v;
+
+  if (int rc = ensure_cu(e, n)) return rc;
+  const int slot = e->cu_next;
+  e->cu_next = (slot + 1) % kCuRing;
+  HIP_TRY(hipEventSynchronize(e->cu_ev[slot]));  // previous use of this slot has been copied
+  int32_t* cu = e->h_cu[slot];
+  int64_t total = 0;
+  int max_len = 0;
+  cu[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    const int len = seq_lens ? seq_lens[i] : s;
+    if (len < 0 || len > s) return fail(SMI_ERR_INVALID_ARG, "seq_lens[%d]=%d outside [0,%d]", i, len, s);
+    total += len;
+    if (total > 0x7fffff00LL) return fail(SMI_ERR_UNSUPPORTED, "too many tokens in one batch");
+    cu[i + 1] = (int32_t)total;
+    max_len = std::max(max_len, len);
+  }
+  const int32_t* d_cu = e->d_cu[slot].as<int32_t>();
+  HIP_TRY(hipMemcpyAsync((void*)d_cu, cu, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipEventRecord(e->cu_ev[slot], stream));
+
+  const int d = c.model_dim, f = c.ffn_inner_dim;
+  if (total == 0) {  // nothing but empty sentences: pooled vectors are zero
+    HIP_TRY(hipMemsetAsync(out_emb, 0, (size_t)n * d * (out_dtype == SMI_F32 ? 4 : 2), stream));
+    if (out_encoded)
+      HIP_TRY(hipMemsetAsync(out_encoded, 0, (size_t)n * s * d * (out_dtype == SMI_F32 ? 4 : 2), stream));
+    return SMI_OK;
+  }
+  const int64_t rows = (total + 127) / 128 * 128;
+  if (int rc = ensure_workspace(e, rows)) return rc;
+  const int M = (int)rows;
+
+  float* x = e->x.as<float>();
+  f16* h = e->h.as<f16>();
+  f16* qkv = e->qkv.as<f16>();
+  f16* ctx = e->ctx.as<f16>();
+  f16* ffn = e->ffn.as<f16>();
+
+  if (rows > total)
+    HIP_TRY(hipMemsetAsync(x + (size_t)total * d, 0, (size_t)(rows - total) * d * 4, stream));
+  HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
+                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream));
+  for (int l = 0; l < c.num_layers; ++l) {
+    Layer& L = e->layers[l];
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d,
+                           3 * d, stream));
+    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d, stream));
+    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d, stream));
+  }
+  HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
+                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream));
+  return SMI_OK;
+}
+
+// ------------------------------------------------------------------- xsim
+int64_t smi_xsim_padded_rows(int64_t rows) { return (rows + 127) / 128 * 128; }
+
+int smi_xsim_normalize(const void* src, int32_t src_dtype, int64_t rows, int32_t d, void* dst,
+                       void* stream) {
+  if (!src || !dst || rows <= 0 || d <= 0) return fail(SMI_ERR_INVALID_ARG, "bad argument");
+  if (src_dtype != SMI_F32 && src_dtype != SMI_F16) return fail(SMI_ERR_INVALID_ARG, "bad dtype");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_l2_normalize(src, src_dtype == SMI_F32, (f16*)dst, rows, d, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k) {
+  if (nx <= 0 || ny <= 0 || k < 1 || k > 8) return 0;
+  return (int64_t)xsim_workspace_bytes(smi_xsim_padded_rows(nx), smi_xsim_padded_rows(ny), k);
+}
+
+int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_t d, int32_t k,
+                  int64_t y_off, int32_t* idx, float* score, void* ws, void* stream) {
+  if (!xn || !yn || !idx || !score || !ws) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (k < 1 || k > 8) return fail(SMI_ERR_UNSUPPORTED, "k=%d outside [1,8]", k);
+  if (d <= 0 || d % 64) return fail(SMI_ERR_UNSUPPORTED, "d=%d must be a multiple of 64", d);
+  if (nx <= 0 || ny <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_xsim_topk((const f16*)xn, nx, smi_xsim_padded_rows(nx), (const f16*)yn, ny,
+                           smi_xsim_padded_rows(ny), d, k, y_off, idx, score, ws, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+// -------------------------------------------------------- building blocks
+int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, void* out, int32_t m,
+                int32_t n, int32_t k, int32_t ldo, void* stream) {
+  if (!x || !w || !bias || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || epi < 0 || epi > 2 || ldo < n)
+    return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out, int32_t rows,
+                  int32_t d, void* stream) {
+  if (!x || !w || !b || !out || rows <= 0) return fail(SMI_ERR_INVALID_ARG, "bad argument");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  hipError_t e = launch_layernorm(x, w, b, eps, (f16*)out, rows, d, (hipStream_t)stream);
+  if (e == hipErrorInvalidValue) return fail(SMI_ERR_UNSUPPORTED, "layernorm d=%d unsupported", d);
+  HIP_TRY(e);
+  return SMI_OK;
+}
+
+int smi_attention(const void* qkv, const int32_t* cu, void* ctx, int32_t n, int32_t max_len,
+                  int32_t d, int32_t heads, void* stream) {
+  if (!qkv || !cu || !ctx) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (heads <= 0 || d != heads * 64) return fail(SMI_ERR_UNSUPPORTED, "head_dim must be 64");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_attention((const f16*)qkv, cu, (f16*)ctx, n, max_len, d, heads, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Shared device/host helpers for the gfx950 (MI355X / CDNA4) SONAR hot path.
+// Wavefront = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smi {
+
+typedef _Float16 f16;
+typedef f16 half8 __attribute__((ext_vector_type(8)));
+typedef f16 half4 __attribute__((ext_vector_type(4)));
+typedef f16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define SMI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define SMI_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// Direct global->LDS DMA of 16 B per lane. LDS destination = wave-uniform
+// base + lane*16 (hardware rule), global source is per-lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware block id remap (bijective for any grid size): hardware deals
+// block b to XCD b%8; give every XCD one contiguous range of logical ids so
+// neighbouring tiles share that XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+  const int q = nb >> 3, r = nb & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace smi

@@ -1,0 +1,145 @@
+// 128x128x64 fp16 MFMA tile engine shared by the dense GEMMs and the xsim
+// mining kernel.  C[m][n] = sum_k X[m][k] * W[n][k]  (both operands K-major,
+// i.e. the nn.Linear layout the reference's checkpoints use:
+// sonar/models/sonar_text/factory.py:130-153 builds Linear(weight[out,in])).
+//
+// Mapping to CDNA4:
+//  * 256 threads = 4 waves in a 2(m) x 2(n) grid, each wave owns 64x64 of C as
+//    2x2 v_mfma_f32_32x32x16_f16 blocks (64 accumulator VGPRs).
+//  * The MFMA "A" operand is the W tile and the "B" operand the X tile, so the
+//    accumulator of a lane holds ONE output row m = lane&31 and 4-element
+//    contiguous runs along n: epilogues store 8/16 B per lane along the
+//    contiguous dimension instead of 2 B.
+//  * Operand tiles go HBM -> LDS with 16-byte global_load_lds DMA (no VGPR
+//    round trip).  The DMA writes LDS lane-linearly, so the bank swizzle is
+//    applied to the per-lane SOURCE address and undone by the ds_read_b128
+//    address: 16-B chunk c of tile row r lives at slot c ^ ((r>>1)&7).  With
+//    128-B rows this makes every 16-lane ds_read_b128 group hit 16 distinct
+//    16-B slots of the 256-B bank row (conflict free).
+//  * 2 LDS stages (64 KiB) -> 2 workgroups per CU; one barrier per K tile, the
+//    DMA for tile t+1 is in flight while tile t is multiplied.
+#pragma once
+#include "common.hpp"
+
+namespace smi {
+
+constexpr int GT_BM = 128;
+constexpr int GT_BN = 128;
+constexpr int GT_BK = 64;
+constexpr int GT_THREADS = 256;
+constexpr int GT_STAGE_BYTES = (GT_BM + GT_BN) * GT_BK * 2;  // 32 KiB
+constexpr int GT_LDS_BYTES = 2 * GT_STAGE_BYTES;             // 64 KiB
+
+struct GemmTileAcc {
+  f32x16 v[2][2];  // [ni][mi]
+};
+
+// Issue the DMA for one K tile.  xg/wg: per-lane source pointers for the four
+// 1-KiB wave chunks this wave owns in each operand tile (already swizzled).
+__device__ __forceinline__ void gt_issue(const f16* const (&xg)[4], const f16* const (&wg)[4],
+                                         int koff, char* stage, int wave) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    glds16(xg[q] + koff, stage + (wave * 4 + q) * 1024);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    glds16(wg[q] + koff, stage + GT_BM * GT_BK * 2 + (wave * 4 + q) * 1024);
+  }
+}
+
+// Multiply one resident K tile.
+__device__ __forceinline__ void gt_compute(GemmTileAcc& acc, const char* stage, int xrow_off,
+                                           int wrow_off, int t_sw) {
+  const char* xs = stage + xrow_off;
+  const char* ws = stage + GT_BM * GT_BK * 2 + wrow_off;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int coff = (t_sw ^ (ks << 5));  // ((ks*2+hi) ^ swz) << 4
+    half8 fw0 = *(const half8*)(ws + coff);
+    half8 fw1 = *(const half8*)(ws + 32 * 128 + coff);
+    half8 fx0 = *(const half8*)(xs + coff);
+    half8 fx1 = *(const half8*)(xs + 32 * 128 + coff);
+    acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fx0, acc.v[0][0], 0, 0, 0);
+    acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw0, fx1, acc.v[0][1], 0, 0, 0);
+    acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fx0, acc.v[1][0], 0, 0, 0);
+    acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1, fx1, acc.v[1][1], 0, 0, 0);
+  }
+}
+
+// Full K loop for the 128x128 tile at (m0, n0).  X: [*, K] row-major, W: [*, K].
+// Rows m0..m0+127 of X and n0..n0+127 of W must be readable.  K % 64 == 0.
+__device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restrict__ X,
+                                            const f16* __restrict__ W, int K, int m0, int n0,
+                                            char* smem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // DMA source pointers: chunk c = wave*4+q covers tile rows c*8..c*8+7;
+  // lane -> row c*8 + (lane>>3), LDS slot lane&7 holds global chunk slot^f(row).
+  const f16* xg[4];
+  const f16* wg[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = wave * 4 + q;
+    const int row = c * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    xg[q] = X + (size_t)(m0 + row) * K + chunk * 8;
+    wg[q] = W + (size_t)(n0 + row) * K + chunk * 8;
+  }
+
+  // Fragment read offsets: row = w*64 + blk*32 + (lane&31); f(row) = ((lane&31)>>1)&7.
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int t_sw = (hi ^ ((l31 >> 1) & 7)) << 4;
+  const int xrow_off = (wm * 64 + l31) * 128;
+  const int wrow_off = (wn * 64 + l31) * 128;
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+
+  const int nt = K / GT_BK;
+  gt_issue(xg, wg, 0, smem, wave);
+  for (int t = 0; t < nt; ++t) {
+    // The compiler drains the outstanding LDS DMA (vmcnt(0)) ahead of this
+    // barrier; after it tile t is visible to every wave and every wave has
+    // finished reading the other stage.
+    __syncthreads();
+    if (t + 1 < nt) gt_issue(xg, wg, (t + 1) * GT_BK, smem + ((t + 1) & 1) * GT_STAGE_BYTES, wave);
+    gt_compute(acc, smem + (t & 1) * GT_STAGE_BYTES, xrow_off, wrow_off, t_sw);
+  }
+}
+
+// Accumulator coordinates: acc.v[ni][mi][r] is C[m][n] with
+//   m = m0 + wm*64 + mi*32 + (lane&31)
+//   n = n0 + wn*64 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+__device__ __forceinline__ int gt_row(int m0, int mi) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  return m0 + (wave >> 1) * 64 + mi * 32 + (lane & 31);
+}
+__device__ __forceinline__ int gt_col(int n0, int ni, int quad) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  return n0 + (wave & 1) * 64 + ni * 32 + 8 * quad + 4 * (lane >> 5);
+}
+
+// Grouped, XCD-aware raster: logical id -> (tile_m, tile_n).  8 tile rows are
+// walked column-major so the ~64 workgroups resident on one XCD cover an
+// 8x8 super-tile whose operand panels fit that XCD's 4 MiB L2.
+__device__ __forceinline__ void gt_tile_coords(int ntm, int ntn, int& tile_m, int& tile_n) {
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int group = id / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, ntm - first_m);
+  const int in_group = id - group * per_group;
+  tile_m = first_m + in_group % gsz;
+  tile_n = in_group / gsz;
+}
+
+}  // namespace smi

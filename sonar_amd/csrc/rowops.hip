@@ -1,0 +1,269 @@
+// HBM-bound row kernels of the text encoder: embedding gather + sinusoidal
+// positions, LayerNorm, final LayerNorm fused with sentence pooling, dtype
+// conversion.  One 64-lane wave owns one 1024-wide row (16 B per lane per
+// access, fully coalesced), statistics are reduced with DPP/shuffle only.
+//
+// Reference semantics:
+//  * frontend  : TransformerEmbeddingFrontend wired at
+//                sonar/models/sonar_text/factory.py:73-100  (E[tok]*sqrt(d) + PE, fp32 add)
+//  * LayerNorm : StandardLayerNorm(d, bias=True), eps 1e-5 (factory.py:117)
+//  * pooling   : SonarTextTransformerEncoderModel.static_pooling,
+//                sonar/models/sonar_text/model.py:86-128
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace smi {
+
+// ---------------------------------------------------------------- embed+pack
+// grid (N, ceil(max_len/4)), 256 threads: wave w handles position blockIdx.y*4+w
+// of sentence blockIdx.x; rows beyond the sentence length do nothing.
+__global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restrict__ ids,
+                                                         const int32_t* __restrict__ cu,
+                                                         const f16* __restrict__ table,
+                                                         const float* __restrict__ pos_table,
+                                                         float scale, int pos_offset,
+                                                         float* __restrict__ x, int S, int d,
+                                                         int64_t vocab) {
+  const int n = blockIdx.x;
+  const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int start = cu[n];
+  const int len = cu[n + 1] - start;
+  if (p >= len) return;
+  int64_t tok = ids[(size_t)n * S + p];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // never read out of the table
+  const f16* e = table + (size_t)tok * d;
+  const float* pe = pos_table + (size_t)(p + pos_offset) * d;
+  float* o = x + (size_t)(start + p) * d;
+  for (int c = lane * 8; c < d; c += 512) {
+    const half8 ev = *(const half8*)(e + c);
+    const f32x4 p0 = *(const f32x4*)(pe + c);
+    const f32x4 p1 = *(const f32x4*)(pe + c + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // reference: (embed(seqs) * scale) in model dtype, then fp32 add of PE
+      o0[i] = (float)(f16)((float)ev[i] * scale) + p0[i];
+      o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
+    }
+    *(f32x4*)(o + c) = o0;
+    *(f32x4*)(o + c + 4) = o1;
+  }
+}
+
+hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* table,
+                             const float* pos_table, float scale, int pos_offset, float* x, int N,
+                             int S, int max_len, int d, int64_t vocab, hipStream_t stream) {
+  if (d % 8 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
+  dim3 grid(N, (max_len + 3) / 4);
+  hipLaunchKernelGGL(embed_pack_kernel, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
+                     pos_offset, x, S, d, vocab);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// NV = d / 256 float4 vectors per lane; lane l owns columns 256*k + 4*l .. +3.
+template <int NV>
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ w,
+                                       const float* __restrict__ b, float eps, int lane,
+                                       f32x4 (&y)[NV]) {
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  constexpr float inv_d = 1.0f / (NV * 256);
+  const float mean = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float c = v[k][i] - mean;
+      v[k][i] = c;
+      q += c * c;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const f32x4 wv = *(const f32x4*)(w + k * 256 + lane * 4);
+    const f32x4 bv = *(const f32x4*)(b + k * 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[k][i] = v[k][i] * rstd * wv[i] + bv[i];
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps,
+                                                        f16* __restrict__ h, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  constexpr int D = NV * 256;
+  for (int r = blockIdx.x * 4 + wv; r < rows; r += gridDim.x * 4) {
+    f32x4 y[NV];
+    ln_row<NV>(x + (size_t)r * D, w, b, eps, lane, y);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      half4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (f16)y[k][i];
+      *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+    }
+  }
+}
+
+hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
+                            int rows, int d, hipStream_t stream) {
+  if (rows <= 0) return hipErrorInvalidValue;
+  const int blocks = min((rows + 3) / 4, 256 * 32);
+#define SMI_LN_CASE(NV)                                                                         \
+  case NV * 256:                                                                                \
+    hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, \
+                       h, rows);                                                                \
+    break;
+  switch (d) {
+    SMI_LN_CASE(1)
+    SMI_LN_CASE(2)
+    SMI_LN_CASE(3)
+    SMI_LN_CASE(4)
+    SMI_LN_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef SMI_LN_CASE
+  return hipGetLastError();
+}
+
+// ------------------------------------------------- final LayerNorm + pooling
+// One workgroup per sentence; wave w walks rows w, w+4, ...; the pooled vector
+// is combined across the 4 waves through LDS.  pooling: 0 mean, 1 max, 2 last.
+template <int NV, typename OutT>
+__global__ __launch_bounds__(256) void ln_pool_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ b, float eps,
+                                                      const int32_t* __restrict__ cu,
+                                                      OutT* __restrict__ out,
+                                                      OutT* __restrict__ encoded, int S,
+                                                      int pooling) {
+  constexpr int D = NV * 256;
+  __shared__ __attribute__((aligned(16))) float red[4][D];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int start = cu[n];
+  const int len = cu[n + 1] - start;
+
+  f32x4 accv[NV];
+  const float init = pooling == 1 ? -INFINITY : 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) accv[k] = f32x4{init, init, init, init};
+
+  for (int p = wv; p < len; p += 4) {
+    f32x4 y[NV];
+    ln_row<NV>(x + (size_t)(start + p) * D, w, b, eps, lane, y);
+    if (encoded) {
+      OutT* e = encoded + ((size_t)n * S + p) * D;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[k * 256 + lane * 4 + i] = (OutT)y[k][i];
+    }
+    if (pooling == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) accv[k] += y[k];
+    } else if (pooling == 1) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accv[k][i] = fmaxf(accv[k][i], y[k][i]);
+    } else if (p == len - 1) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) accv[k] = y[k];
+    }
+  }
+  if (encoded) {  // zero the padded tail so the padded view is deterministic
+    for (int p = len + wv; p < S; p += 4) {
+      OutT* e = encoded + ((size_t)n * S + p) * D;
+      for (int c = lane; c < D; c += 64) e[c] = (OutT)0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) *(f32x4*)(&red[wv][k * 256 + lane * 4]) = accv[k];
+  __syncthreads();
+  // reference (model.py:115-124): weights = 1/(seq_len + 1e-7), in fp32 here
+  const float wgt = 1.0f / ((float)len + 1e-7f);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float v;
+    if (pooling == 1)
+      v = fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c]));
+    else
+      v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (pooling == 0) v *= wgt;
+    if (len <= 0) v = 0.f;
+    out[(size_t)n * D + c] = (OutT)v;
+  }
+}
+
+hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float eps,
+                          const int32_t* cu, void* out, int out_is_f32, void* encoded, int N, int S,
+                          int d, int pooling, hipStream_t stream) {
+  if (N <= 0 || pooling < 0 || pooling > 2) return hipErrorInvalidValue;
+#define SMI_LP_CASE(NV)                                                                            \
+  case NV * 256:                                                                                   \
+    if (out_is_f32)                                                                                \
+      hipLaunchKernelGGL((ln_pool_kernel<NV, float>), dim3(N), dim3(256), 0, stream, x, w, b, eps, \
+                         cu, (float*)out, (float*)encoded, S, pooling);                            \
+    else                                                                                           \
+      hipLaunchKernelGGL((ln_pool_kernel<NV, f16>), dim3(N), dim3(256), 0, stream, x, w, b, eps,   \
+                         cu, (f16*)out, (f16*)encoded, S, pooling);                                \
+    break;
+  switch (d) {
+    SMI_LP_CASE(1)
+    SMI_LP_CASE(2)
+    SMI_LP_CASE(3)
+    SMI_LP_CASE(4)
+    SMI_LP_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef SMI_LP_CASE
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------- conversions
+__global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ s,
+                                                         f16* __restrict__ d, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t nv = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+    const f32x4 v = ((const f32x4*)s)[i];
+    half4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (f16)v[k];
+    ((half4*)d)[i] = o;
+  }
+  for (size_t i = nv * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    d[i] = (f16)s[i];
+}
+__global__ __launch_bounds__(256) void f16_to_f32_kernel(const f16* __restrict__ s,
+                                                         float* __restrict__ d, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = (float)s[i];
+}
+
+hipError_t launch_f32_to_f16(const float* src, f16* dst, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)min((size_t)8192, (n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
+  return hipGetLastError();
+}
+hipError_t launch_f16_to_f32(const f16* src, float* dst, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)min((size_t)8192, (n + 255) / 256);
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(blocks), dim3(256), 0, stream, src, dst, n);
+  return hipGetLastError();
+}
+
+}  // namespace smi

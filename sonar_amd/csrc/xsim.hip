@@ -1,0 +1,238 @@
+// xsim cosine-similarity mining: for every row of X find the k most similar
+// rows of Y (cosine = dot product of L2-normalised rows).  The reference only
+// names xsim (README.md:5); its in-tree form is F.normalize(x) @ F.normalize(y).T
+// (tests/integration_tests/test_text_sonar.py:42-53).  Here the Nx x Ny score
+// matrix is never materialised: each 128x128 score tile comes out of the
+// shared MFMA tile engine straight into a per-lane running top-k kept in
+// VGPRs, so HBM traffic stays ~(Nx+Ny)*d*2 B and the kernel is MFMA-bound
+// (2*d flop per pair).
+//
+// Work split: grid = (x tiles) x (y chunks); a workgroup walks the y tiles of
+// its chunk.  The grouped XCD raster makes the ~64 workgroups resident on one
+// XCD an 8(x) x 8(chunk) block: its 8 X panels stay L2-resident for the whole
+// walk and every streamed Y tile is shared by 8 workgroups.
+#include "gemm_tile.hpp"
+#include "kernels.hpp"
+
+namespace smi {
+
+// total order: higher score first, ties -> lower index first (deterministic
+// regardless of the order candidates are met).
+__device__ __forceinline__ bool better(float s, int i, float s2, int i2) {
+  return s > s2 || (s == s2 && i < i2);
+}
+
+template <int K>
+struct TopK {
+  float s[K];
+  int i[K];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      s[j] = -INFINITY;
+      i[j] = 0x7fffffff;
+    }
+  }
+  __device__ __forceinline__ void push(float v, int idx) {
+    if (better(v, idx, s[K - 1], i[K - 1])) {
+      s[K - 1] = v;
+      i[K - 1] = idx;
+#pragma unroll
+      for (int j = K - 1; j > 0; --j) {
+        if (better(s[j], i[j], s[j - 1], i[j - 1])) {
+          const float ts = s[j];
+          s[j] = s[j - 1];
+          s[j - 1] = ts;
+          const int ti = i[j];
+          i[j] = i[j - 1];
+          i[j - 1] = ti;
+        }
+      }
+    }
+  }
+};
+
+// partial results: ps/pi [nchunks][nx_pad][K]
+template <int K>
+__global__ __launch_bounds__(GT_THREADS, 2) void xsim_tile_kernel(const f16* __restrict__ Xn,
+                                                                  const f16* __restrict__ Yn,
+                                                                  int d, int ntx, int nty,
+                                                                  int nchunks, int tiles_per_chunk,
+                                                                  int ny, int nx_pad,
+                                                                  float* __restrict__ ps,
+                                                                  int* __restrict__ pi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, chunk;
+  gt_tile_coords(ntx, nchunks, tile_m, chunk);
+  const int m0 = tile_m * GT_BM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+
+  TopK<K> best[2];
+  best[0].init();
+  best[1].init();
+
+  const int t_begin = chunk * tiles_per_chunk;
+  const int t_end = min(nty, t_begin + tiles_per_chunk);
+  for (int ty = t_begin; ty < t_end; ++ty) {
+    const int n0 = ty * GT_BN;
+    GemmTileAcc acc;
+    gt_mainloop(acc, Xn, Yn, d, m0, n0, smem);
+    __syncthreads();  // all waves done with LDS before the next tile's DMA
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        float vmax = acc.v[ni][mi][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
+        if (vmax >= best[mi].s[K - 1]) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (n < ny) best[mi].push(acc.v[ni][mi][r], n);
+          }
+        }
+      }
+    }
+  }
+
+  // merge the 4 lists of every x row (2 lane halves x 2 n-waves) through LDS
+  float* ls = (float*)smem;                        // [128 rows][4][K]
+  int* li = (int*)(smem + 128 * 4 * K * 4);
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int row = wm * 64 + mi * 32 + l31;
+    const int slot = wn * 2 + hi;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ls[(row * 4 + slot) * K + j] = best[mi].s[j];
+      li[(row * 4 + slot) * K + j] = best[mi].i[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int row = threadIdx.x;
+    TopK<K> t;
+    t.init();
+    for (int c = 0; c < 4 * K; ++c) t.push(ls[row * 4 * K + c], li[row * 4 * K + c]);
+    const size_t o = ((size_t)chunk * nx_pad + m0 + row) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ps[o + j] = t.s[j];
+      pi[o + j] = t.i[j];
+    }
+  }
+}
+
+// final merge over chunks; one thread per x row.  k_out <= K.
+template <int K>
+__global__ __launch_bounds__(256) void xsim_merge_kernel(const float* __restrict__ ps,
+                                                         const int* __restrict__ pi, int nchunks,
+                                                         int64_t nx, int nx_pad, int k_out,
+                                                         int64_t y_off, int32_t* __restrict__ idx,
+                                                         float* __restrict__ score) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= nx) return;
+  TopK<K> t;
+  t.init();
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t o = ((size_t)c * nx_pad + row) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) t.push(ps[o + j], pi[o + j]);
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < k_out) {
+      const bool valid = t.i[j] != 0x7fffffff;
+      idx[row * k_out + j] = valid ? (int32_t)(t.i[j] + y_off) : -1;
+      score[row * k_out + j] = t.s[j];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- normalise
+// dst[r,:] = f16(src[r,:] / max(||src[r,:]||, 1e-12)), rows >= n_valid zeroed.
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ src, f16* __restrict__ dst,
+                                                     int64_t rows, int64_t rows_pad, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows_pad) return;
+  f16* o = dst + r * d;
+  if (r >= rows) {
+    for (int c = lane; c < d; c += 64) o[c] = (f16)0.f;
+    return;
+  }
+  const T* s = src + r * d;
+  float q = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = (float)s[c];
+    q += v * v;
+  }
+  const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+  for (int c = lane; c < d; c += 64) o[c] = (f16)((float)s[c] * inv);
+}
+
+hipError_t launch_l2_normalize(const void* src, int src_is_f32, f16* dst, int64_t rows, int d,
+                               hipStream_t stream) {
+  const int64_t rows_pad = (rows + GT_BM - 1) / GT_BM * GT_BM;
+  if (rows_pad == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((rows_pad + 3) / 4);
+  if (src_is_f32)
+    hipLaunchKernelGGL(l2norm_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)src,
+                       dst, rows, rows_pad, d);
+  else
+    hipLaunchKernelGGL(l2norm_kernel<f16>, dim3(blocks), dim3(256), 0, stream, (const f16*)src, dst,
+                       rows, rows_pad, d);
+  return hipGetLastError();
+}
+
+static int xsim_chunks(int64_t nty) { return (int)(nty < 8 ? nty : 8); }
+static int round_k(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8)); }
+
+size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k) {
+  const int K = round_k(k);
+  return (size_t)xsim_chunks(ny_pad / GT_BN) * nx_pad * K * 8;
+}
+
+template <int K>
+static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
+                           int64_t ny_pad, int d, int k, int64_t y_off, int32_t* idx, float* score,
+                           void* ws, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)xsim_tile_kernel<K>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
+  const int nchunks = xsim_chunks(nty);
+  const int tpc = (nty + nchunks - 1) / nchunks;
+  float* ps = (float*)ws;
+  int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
+  hipLaunchKernelGGL(xsim_tile_kernel<K>, dim3(ntx * nchunks), dim3(GT_THREADS), GT_LDS_BYTES,
+                     stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(xsim_merge_kernel<K>, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream,
+                     ps, pi, nchunks, nx, (int)nx_pad, k, y_off, idx, score);
+  return hipGetLastError();
+}
+
+hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
+                            int64_t ny_pad, int d, int k, int64_t y_off, int32_t* idx, float* score,
+                            void* ws, hipStream_t stream) {
+  if (nx <= 0 || ny <= 0 || k < 1 || k > 8 || d % GT_BK || nx_pad % GT_BM || ny_pad % GT_BN ||
+      ny_pad > 0x7fffff00LL || nx_pad > 0x7fffff00LL)
+    return hipErrorInvalidValue;
+  switch (round_k(k)) {
+    case 1: return xsim_run<1>(Xn, nx, nx_pad, Yn, ny, ny_pad, d, k, y_off, idx, score, ws, stream);
+    case 2: return xsim_run<2>(Xn, nx, nx_pad, Yn, ny, ny_pad, d, k, y_off, idx, score, ws, stream);
+    case 4: return xsim_run<4>(Xn, nx, nx_pad, Yn, ny, ny_pad, d, k, y_off, idx, score, ws, stream);
+    default: return xsim_run<8>(Xn, nx, nx_pad, Yn, ny, ny_pad, d, k, y_off, idx, score, ws, stream);
+  }
+}
+
+}  // namespace smi

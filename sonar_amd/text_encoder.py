@@ -1,0 +1,358 @@
+"""Host-side mirror of the reference's SONAR text encoder model objects, backed
+by the HIP engine (libsonar_mi355.so) instead of fairseq2 modules.
+
+Reference interfaces mirrored (paths relative to facebookresearch/SONAR):
+  * SonarTextEncoderConfig + archs `basic` / `small`  sonar/models/sonar_text/config.py:14-127
+  * SonarEncoderOutput / SonarEncoderModel           sonar/models/encoder_model.py:17-67
+  * SonarTextTransformerEncoderModel.forward         sonar/models/sonar_text/model.py:130-143
+  * checkpoint key conversion                        sonar/models/sonar_text/handler.py:52-94
+
+PyTorch is used only for device memory, streams and tensors at the boundary;
+all arithmetic runs in the hand-written gfx950 kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Mapping, Optional, Sequence, Union
+
+import torch
+
+from . import _lib
+
+
+# --------------------------------------------------------------------- config
+@dataclass
+class VocabularyInfo:
+    size: int
+    unk_idx: Optional[int] = 1
+    bos_idx: Optional[int] = 2
+    eos_idx: Optional[int] = 3
+    pad_idx: Optional[int] = 1
+
+
+@dataclass
+class SonarTextEncoderConfig:
+    """Same fields as the reference dataclass (config.py:14-85)."""
+
+    model_dim: int = 1024
+    max_seq_len: int = 512
+    vocab_info: VocabularyInfo = field(default_factory=lambda: VocabularyInfo(size=256206))
+    num_encoder_layers: int = 24
+    num_decoder_layers: int = 24
+    num_encoder_attn_heads: int = 16
+    num_decoder_attn_heads: int = 16
+    ffn_inner_dim: int = 1024 * 8
+    pooling: str = "mean"
+    embedding_dim: Optional[int] = None
+    decoder_ffn_inner_dim: Optional[int] = None
+    activation_fn: str = "ReLU"
+    layernorm_embedding: bool = False
+    no_scale_embedding: bool = False
+    no_token_positional_embeddings: bool = False
+    learned_pos: bool = False
+    emb_dropout_p: float = 0.1
+    attention_dropout_p: float = 0.1
+    activation_dropout_p: float = 0.1
+    normalize_before: bool = False
+    _from_fairseq: bool = False
+
+    @property
+    def pos_offset(self) -> int:
+        # SinusoidalPositionEncoder(_legacy_pad_idx=pad_idx), factory.py:88-92
+        return (self.vocab_info.pad_idx or 0) + 1
+
+    @property
+    def model_max_seq_len(self) -> int:
+        # factory.py:56-59: max_seq_len += pad_idx + 1 for fairseq-trained models
+        return self.max_seq_len + (self.pos_offset if self._from_fairseq else 0)
+
+
+def _basic() -> SonarTextEncoderConfig:
+    return SonarTextEncoderConfig(_from_fairseq=True)
+
+
+def _small(vocab_size: int = 32005, depth: int = 6, hidden_dim: int = 1024 * 4) -> SonarTextEncoderConfig:
+    c = _basic()
+    c.vocab_info = VocabularyInfo(size=vocab_size)
+    c.num_encoder_layers = depth
+    c.num_decoder_layers = depth
+    c.ffn_inner_dim = hidden_dim
+    return c
+
+
+TEXT_ENCODER_ARCHS = {"basic": _basic, "small": _small}
+
+
+def get_text_encoder_config(arch: str) -> SonarTextEncoderConfig:
+    try:
+        return TEXT_ENCODER_ARCHS[arch]()
+    except KeyError:
+        raise ValueError(f"unknown sonar text encoder arch {arch!r}; known: {sorted(TEXT_ENCODER_ARCHS)}")
+
+
+def check_supported(cfg: SonarTextEncoderConfig) -> None:
+    """The engine covers the configuration space the released SONAR text encoders use."""
+    bad = []
+    if cfg.embedding_dim not in (None, cfg.model_dim) or cfg.pooling == "attention":
+        bad.append("attention pooling / embedding_dim != model_dim")
+    if cfg.activation_fn != "ReLU":
+        bad.append(f"activation_fn={cfg.activation_fn}")
+    if cfg.layernorm_embedding:
+        bad.append("layernorm_embedding")
+    if cfg.learned_pos or cfg.no_token_positional_embeddings:
+        bad.append("non-sinusoidal positions")
+    if cfg.pooling not in ("mean", "max", "last"):
+        bad.append(f"pooling={cfg.pooling}")
+    if bad:
+        raise NotImplementedError("not covered by the MI355X engine: " + ", ".join(bad))
+
+
+# ------------------------------------------------------------------ positions
+def sinusoidal_table(num_positions: int, dim: int) -> torch.Tensor:
+    """fp32 [num_positions, dim]; row p encodes absolute position p in the fairseq
+    half-split layout [sin | cos] (SinusoidalPositionEncoder)."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
+    ang = torch.arange(num_positions, dtype=torch.float32).unsqueeze(1) * freq.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    if dim % 2 == 1:
+        tab = torch.cat([tab, torch.zeros(num_positions, 1)], dim=1)
+    return tab.contiguous()
+
+
+# ----------------------------------------------------------------- checkpoints
+_FAIRSEQ1_KEY_MAP = [
+    (r"^layers\.([0-9]+)\.self_attn\.q_proj\.", r"encoder.layers.\1.self_attn.q_proj."),
+    (r"^layers\.([0-9]+)\.self_attn\.v_proj\.", r"encoder.layers.\1.self_attn.v_proj."),
+    (r"^layers\.([0-9]+)\.self_attn\.k_proj\.", r"encoder.layers.\1.self_attn.k_proj."),
+    (r"^layers\.([0-9]+)\.self_attn\.out_proj\.", r"encoder.layers.\1.self_attn.output_proj."),
+    (r"^layers\.([0-9]+)\.self_attn_layer_norm\.", r"encoder.layers.\1.self_attn_layer_norm."),
+    (r"^layers\.([0-9]+)\.fc1\.", r"encoder.layers.\1.ffn.inner_proj."),
+    (r"^layers\.([0-9]+)\.fc2\.", r"encoder.layers.\1.ffn.output_proj."),
+    (r"^layers\.([0-9]+)\.final_layer_norm\.", r"encoder.layers.\1.ffn_layer_norm."),
+    (r"^embed_tokens\.", r"encoder_frontend.embed."),
+]
+
+
+def convert_sonar_text_encoder_checkpoint(checkpoint: Mapping) -> Dict[str, torch.Tensor]:
+    """Return a flat fairseq2-style state dict from either checkpoint layout the
+    reference accepts (handler.py:52-94): a fairseq2 `{"model": {...}}` dict is
+    passed through; a fairseq1 `{"state_dict": {...}}` dict gets its keys renamed
+    and the four control-token embedding rows permuted
+    (BOS, PAD, EOS, UNK) -> (PAD, UNK, BOS, EOS)  (handler.py:86-92)."""
+    if "model" in checkpoint and "encoder_frontend.embed.weight" in checkpoint["model"]:
+        return dict(checkpoint["model"])
+    if "state_dict" not in checkpoint:
+        # already a flat fairseq2-style dict
+        if "encoder_frontend.embed.weight" in checkpoint:
+            return dict(checkpoint)
+        raise ValueError("unrecognised SONAR text encoder checkpoint layout")
+    out: Dict[str, torch.Tensor] = {}
+    for key, val in checkpoint["state_dict"].items():
+        if key in ("version", "embed_positions._float_tensor"):
+            continue
+        new = key
+        for pat, rep in _FAIRSEQ1_KEY_MAP:
+            new, n = re.subn(pat, rep, new)
+            if n:
+                break
+        out[new] = val
+    emb = out["encoder_frontend.embed.weight"].clone()
+    emb[[0, 1, 2, 3]] = emb[[1, 3, 0, 2]]
+    out["encoder_frontend.embed.weight"] = emb
+    return out
+
+
+# --------------------------------------------------------------------- engine
+def _tensor_view(t: torch.Tensor, keep: List[torch.Tensor]) -> _lib.smi_tensor:
+    if t.dtype not in (torch.float32, torch.float16):
+        t = t.float()
+    t = t.detach().contiguous()
+    keep.append(t)
+    return _lib.smi_tensor(
+        data=t.data_ptr(),
+        dtype=_lib.SMI_F32 if t.dtype == torch.float32 else _lib.SMI_F16,
+        on_device=1 if t.is_cuda else 0,
+        numel=t.numel(),
+    )
+
+
+class TextEncoderEngine:
+    """Owns one `smi_text_encoder` handle (packed fp16 weights + workspace in HBM)."""
+
+    def __init__(self, cfg: SonarTextEncoderConfig, state_dict: Mapping[str, torch.Tensor],
+                 device: Union[str, torch.device] = "cuda:0", max_tokens_hint: int = 0):
+        check_supported(cfg)
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the SONAR MI355X engine runs on a HIP device only (no CPU path)")
+        self.lib = _lib.load()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        _lib.check(self.lib.smi_init(idx))
+        d = cfg.model_dim
+        ccfg = _lib.smi_text_encoder_config(
+            model_dim=d, num_layers=cfg.num_encoder_layers, num_heads=cfg.num_encoder_attn_heads,
+            ffn_inner_dim=cfg.ffn_inner_dim, vocab_size=cfg.vocab_info.size,
+            max_seq_len=cfg.model_max_seq_len, pos_offset=cfg.pos_offset,
+            embed_scale=1.0 if cfg.no_scale_embedding else math.sqrt(d), ln_eps=1e-5,
+            pooling=_lib.SMI_POOL[cfg.pooling], reserved=0)
+        keep: List[torch.Tensor] = []
+        sd = state_dict
+
+        def tv(name: str) -> _lib.smi_tensor:
+            if name not in sd:
+                raise KeyError(f"checkpoint is missing {name}")
+            return _tensor_view(sd[name], keep)
+
+        layers = (_lib.smi_text_encoder_layer * max(cfg.num_encoder_layers, 1))()
+        for i in range(cfg.num_encoder_layers):
+            p = f"encoder.layers.{i}."
+            L = layers[i]
+            L.self_attn_layer_norm_w = tv(p + "self_attn_layer_norm.weight")
+            L.self_attn_layer_norm_b = tv(p + "self_attn_layer_norm.bias")
+            L.q_w, L.q_b = tv(p + "self_attn.q_proj.weight"), tv(p + "self_attn.q_proj.bias")
+            L.k_w, L.k_b = tv(p + "self_attn.k_proj.weight"), tv(p + "self_attn.k_proj.bias")
+            L.v_w, L.v_b = tv(p + "self_attn.v_proj.weight"), tv(p + "self_attn.v_proj.bias")
+            L.out_w, L.out_b = tv(p + "self_attn.output_proj.weight"), tv(p + "self_attn.output_proj.bias")
+            L.ffn_layer_norm_w = tv(p + "ffn_layer_norm.weight")
+            L.ffn_layer_norm_b = tv(p + "ffn_layer_norm.bias")
+            L.ffn_inner_w, L.ffn_inner_b = tv(p + "ffn.inner_proj.weight"), tv(p + "ffn.inner_proj.bias")
+            L.ffn_out_w, L.ffn_out_b = tv(p + "ffn.output_proj.weight"), tv(p + "ffn.output_proj.bias")
+        w = _lib.smi_text_encoder_weights()
+        w.embed = tv("encoder_frontend.embed.weight")
+        pos = sinusoidal_table(cfg.model_max_seq_len + cfg.pos_offset, d)
+        w.pos_table = _tensor_view(pos, keep)
+        w.final_layer_norm_w = tv("layer_norm.weight")
+        w.final_layer_norm_b = tv("layer_norm.bias")
+        w.layers = C.cast(layers, C.POINTER(_lib.smi_text_encoder_layer))
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_encoder_create(C.byref(ccfg), C.byref(w), max_tokens_hint,
+                                                        C.byref(handle)))
+        self._handle = handle
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                self.lib.smi_text_encoder_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.smi_text_encoder_device_bytes(self._handle))
+
+    def forward(self, ids: torch.Tensor, seq_lens: Optional[Union[torch.Tensor, Sequence[int]]],
+                out_dtype: torch.dtype = torch.float16, return_encoded: bool = False):
+        """ids: int64 [N,S] on the engine's device; seq_lens: host ints [N] or None."""
+        if ids.dim() != 2:
+            raise ValueError("ids must be [N, S]")
+        if ids.device != self.device:
+            ids = ids.to(self.device)
+        ids = ids.to(torch.int64).contiguous()
+        n, s = ids.shape
+        lens_arr = None
+        if seq_lens is not None:
+            if isinstance(seq_lens, torch.Tensor):
+                seq_lens = seq_lens.detach().to("cpu", torch.int32).tolist()
+            if len(seq_lens) != n:
+                raise ValueError("seq_lens must have one entry per sequence")
+            lens_arr = (C.c_int32 * n)(*[int(v) for v in seq_lens])
+        if out_dtype not in (torch.float16, torch.float32):
+            raise ValueError("out_dtype must be float16 or float32")
+        emb = torch.empty((n, self.cfg.model_dim), dtype=out_dtype, device=self.device)
+        enc = torch.empty((n, s, self.cfg.model_dim), dtype=out_dtype, device=self.device) if return_encoded else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_encoder_forward(
+                self._handle, ids.data_ptr(), C.cast(lens_arr, C.c_void_p) if lens_arr is not None else None,
+                n, s, emb.data_ptr(), enc.data_ptr() if enc is not None else None,
+                _lib.SMI_F32 if out_dtype == torch.float32 else _lib.SMI_F16,
+                _lib.current_stream_ptr()))
+        return emb, enc
+
+
+# ------------------------------------------------ reference-shaped model objects
+@dataclass
+class SonarEncoderOutput:
+    """sonar/models/encoder_model.py:17-38."""
+
+    encoded_seqs: Optional[torch.Tensor]
+    sentence_embeddings: torch.Tensor
+    padding_mask: Optional["PaddingMask"]
+
+
+@dataclass
+class PaddingMask:
+    """Stand-in for fairseq2.nn.padding.PaddingMask: lengths + padded length."""
+
+    seq_lens: torch.Tensor  # int [N] (host or device)
+    batch_seq_len: int
+
+
+@dataclass
+class SequenceBatch:
+    """Stand-in for fairseq2.models.sequence.SequenceBatch (seqs + optional mask)."""
+
+    seqs: torch.Tensor
+    padding_mask: Optional[PaddingMask]
+
+
+class _PosEncoderInfo:
+    def __init__(self, max_seq_len: int):
+        self.max_seq_len = max_seq_len
+
+
+class _FrontendInfo:
+    def __init__(self, max_seq_len: int):
+        self.pos_encoder = _PosEncoderInfo(max_seq_len)
+
+
+class SonarTextTransformerEncoderModel:
+    """Drop-in for the object `TextToEmbeddingModelPipeline` calls as `self.model(batch)`
+    (sonar/inference_pipelines/text.py:244): callable on a SequenceBatch, exposes
+    `.eval()`, `.dtype`, `.encoder_frontend.pos_encoder.max_seq_len` (text.py:202)."""
+
+    def __init__(self, cfg: SonarTextEncoderConfig, state_dict: Mapping[str, torch.Tensor],
+                 device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
+                 return_encoded_seqs: bool = False, max_tokens_hint: int = 0):
+        self.config = cfg
+        self.dtype = dtype
+        self.model_dim = cfg.model_dim
+        self.pooling = cfg.pooling
+        self.return_encoded_seqs = return_encoded_seqs
+        self.encoder_frontend = _FrontendInfo(cfg.model_max_seq_len)
+        self.engine = TextEncoderEngine(cfg, state_dict, device, max_tokens_hint)
+        self.device = self.engine.device
+
+    def eval(self):
+        return self
+
+    def __call__(self, batch: SequenceBatch) -> SonarEncoderOutput:
+        return self.forward(batch)
+
+    @torch.inference_mode()
+    def forward(self, batch: SequenceBatch) -> SonarEncoderOutput:
+        lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else None
+        emb, enc = self.engine.forward(batch.seqs, lens, self.dtype, self.return_encoded_seqs)
+        return SonarEncoderOutput(encoded_seqs=enc, sentence_embeddings=emb, padding_mask=batch.padding_mask)
+
+
+def load_sonar_text_encoder(checkpoint: Union[str, Mapping], arch: str = "basic",
+                            device: Union[str, torch.device] = "cuda:0",
+                            dtype: torch.dtype = torch.float16,
+                            config: Optional[SonarTextEncoderConfig] = None) -> SonarTextTransformerEncoderModel:
+    """hub.load() equivalent for a local checkpoint file or an in-memory dict
+    (reference: sonar/inference_pipelines/text.py:161-162)."""
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    cfg = config or get_text_encoder_config(arch)
+    sd = convert_sonar_text_encoder_checkpoint(checkpoint)
+    return SonarTextTransformerEncoderModel(cfg, sd, device=device, dtype=dtype)

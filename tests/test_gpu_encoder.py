@@ -1,0 +1,127 @@
+"""GPU parity of the text-encoder hot path (through the C ABI) against the CPU oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(d=256, heads=4, ffn=512, layers=2, vocab=1000, pooling="mean"):
+    from oracle.text_encoder import OracleTextEncoderConfig
+    from sonar_amd.text_encoder import SonarTextEncoderConfig, VocabularyInfo
+
+    o = OracleTextEncoderConfig(model_dim=d, num_layers=layers, num_heads=heads, ffn_inner_dim=ffn,
+                                vocab_size=vocab, pooling=pooling)
+    c = SonarTextEncoderConfig(model_dim=d, num_encoder_layers=layers, num_encoder_attn_heads=heads,
+                               ffn_inner_dim=ffn, vocab_info=VocabularyInfo(size=vocab), pooling=pooling,
+                               _from_fairseq=True)
+    return o, c
+
+
+def _cos_err(a, b):
+    return (1 - F.cosine_similarity(a.float().cpu(), b.float().cpu(), dim=-1)).abs().max().item()
+
+
+@pytest.mark.parametrize("pooling", ["mean", "max", "last"])
+@pytest.mark.parametrize("ragged", [True, False])
+def test_encoder_small_vs_oracle(pooling, ragged):
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch, PaddingMask
+
+    ocfg, cfg = _cfgs(pooling=pooling)
+    params = O.make_synthetic_params(ocfg, seed=1234, std=0.08)
+    if ragged:
+        ids, lens = O.synthetic_batch(9, 3, 70, ocfg.vocab_size, seed=0)
+        lens[0] = 1
+    else:
+        ids, lens = O.synthetic_batch(5, 40, 40, ocfg.vocab_size, seed=1)
+    enc_ref, emb_ref = O.text_encoder_forward(params, ocfg, ids, lens if ragged else None)
+
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32,
+                                             return_encoded_seqs=True)
+    mask = PaddingMask(lens, ids.shape[1]) if ragged else None
+    out = model(SequenceBatch(ids.cuda(), mask))
+    torch.cuda.synchronize()
+    emb = out.sentence_embeddings
+    assert emb.shape == (ids.shape[0], ocfg.model_dim) and emb.dtype == torch.float32
+    assert torch.isfinite(emb).all()
+    # north_star tolerance: <= 1e-3 (1 - cosine) against the fp32 CPU path
+    assert _cos_err(emb, emb_ref) <= 1e-3
+    assert (emb.cpu() - emb_ref).abs().max().item() <= 3e-2 * emb_ref.abs().max().item()
+    # encoded_seqs on valid positions
+    enc = out.encoded_seqs.cpu()
+    for i, L in enumerate(lens.tolist() if ragged else [ids.shape[1]] * ids.shape[0]):
+        assert _cos_err(enc[i, :L], enc_ref[i, :L]) <= 2e-3
+        if ragged:
+            assert (enc[i, L:] == 0).all()
+
+
+def test_encoder_batching_invariance():
+    """Reference property (tests/integration_tests/test_text_sonar.py:120-161):
+    embeddings do not depend on how sentences are batched."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch, PaddingMask
+
+    ocfg, cfg = _cfgs()
+    params = O.make_synthetic_params(ocfg, seed=7, std=0.08)
+    ids, lens = O.synthetic_batch(6, 2, 50, ocfg.vocab_size, seed=3)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    full = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+    for i in range(ids.shape[0]):
+        L = int(lens[i])
+        one = model(SequenceBatch(ids[i:i + 1, :L].cuda(), None)).sentence_embeddings
+        assert (one - full[i:i + 1]).abs().max().item() <= 1e-5 * max(1.0, full.abs().max().item())
+
+
+def test_encoder_fp16_out_and_errors():
+    from oracle import text_encoder as O
+    from sonar_amd import _lib
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch
+
+    ocfg, cfg = _cfgs()
+    params = O.make_synthetic_params(ocfg, seed=7, std=0.08)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float16)
+    ids, _ = O.synthetic_batch(4, 16, 16, ocfg.vocab_size, seed=5)
+    _, emb_ref = O.text_encoder_forward(params, ocfg, ids, None)
+    emb = model(SequenceBatch(ids.cuda(), None)).sentence_embeddings
+    assert emb.dtype == torch.float16
+    assert _cos_err(emb, emb_ref) <= 1e-3
+    too_long = torch.zeros(1, cfg.model_max_seq_len + 1, dtype=torch.int64)
+    with pytest.raises(_lib.SmiError):
+        model(SequenceBatch(too_long.cuda(), None))
+
+
+@pytest.mark.parametrize("nx,ny,k", [(300, 517, 1), (1000, 3000, 4), (129, 128, 8), (2048, 4096, 2)])
+def test_xsim_topk_vs_oracle(nx, ny, k):
+    from oracle import xsim as OX
+    from sonar_amd import xsim
+
+    g = torch.Generator().manual_seed(nx + ny + k)
+    d = 256
+    y = torch.randn(ny, d, generator=g)
+    x = y[torch.randint(0, ny, (nx,), generator=g)] + 0.8 * torch.randn(nx, d, generator=g)
+    xh, yh = x.half(), y.half()
+    ref_s, ref_i = OX.cosine_topk(xh.float(), yh.float(), k)
+    s, i = xsim.topk(xh.cuda(), yh.cuda(), k)
+    torch.cuda.synchronize()
+    s, i = s.cpu(), i.cpu().long()
+    # scores agree to fp16-normalisation precision; indices agree wherever the gap is resolvable
+    assert (s - ref_s).abs().max().item() <= 3e-3
+    full = F.normalize(xh.float(), dim=-1) @ F.normalize(yh.float(), dim=-1).T
+    picked = full.gather(1, i)
+    assert (picked - ref_s).abs().max().item() <= 3e-3
+    assert (i[:, 0] == ref_i[:, 0]).float().mean().item() >= 0.995
+    for r in range(nx):
+        assert len(set(i[r].tolist())) == k
+
+
+def test_xsim_error_rate_matches_oracle():
+    from oracle import xsim as OX
+    from sonar_amd import xsim
+
+    x, y, perm = OX.synthetic_pairs(1500, d=256, noise=1.0, seed=2)
+    y_al = y[perm]  # aligned: x[i] <-> y_al[i]
+    for margin in ("cosine", "ratio"):
+        ref = OX.xsim_error_rate(x.half().float(), y_al.half().float(), margin=margin)
+        got, _ = xsim.xsim_error(x.half().cuda(), y_al.half().cuda(), margin=margin)
+        assert abs(got - ref) <= 2e-3, (margin, got, ref)

@@ -1,0 +1,104 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain
+PyTorch fp32 references of the same op on the same fp16-rounded inputs."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sonar_amd import _lib
+
+    lib = _lib.load()
+    _lib.check(lib.smi_init(0))
+    return lib
+
+
+def _stream():
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_tn(lib, m, n, k, epi):
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k + epi)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    ref = x.float() @ w.float().T + bias
+    if epi == 2:
+        resid = torch.randn(m, n, device="cuda", generator=g)
+        out = resid.clone()
+        ref = ref + resid
+    else:
+        out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
+        if epi == 1:
+            ref = torch.relu(ref)
+    _lib.check(lib.smi_gemm_tn(epi, x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, n, _stream()))
+    torch.cuda.synchronize()
+    got = out.float()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1.0)
+    # fp16 output: half-ulp rounding of the result; fp32 residual: accumulation order only
+    allowed = (2e-3 if epi != 2 else 2e-5) * scale
+    assert err <= allowed, (err, scale)
+
+
+@pytest.mark.parametrize("d", [256, 512, 768, 1024, 2048])
+def test_layernorm(lib, d):
+    from sonar_amd import _lib
+
+    rows = 517
+    g = torch.Generator(device="cuda").manual_seed(d)
+    x = torch.randn(rows, d, device="cuda", generator=g) * 3 + 0.7
+    w = torch.randn(d, device="cuda", generator=g)
+    b = torch.randn(d, device="cuda", generator=g)
+    out = torch.empty(rows, d, device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, out.data_ptr(), rows, d, _stream()))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
+    assert (out.float() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+
+
+def _attention_ref(qkv, lens, d, heads):
+    t = qkv.shape[0]
+    out = torch.zeros(t, d, device=qkv.device)
+    start = 0
+    dh = d // heads
+    for L in lens:
+        if L == 0:
+            continue
+        blk = qkv[start:start + L].float()
+        q = blk[:, :d].view(L, heads, dh).transpose(0, 1)
+        k = blk[:, d:2 * d].view(L, heads, dh).transpose(0, 1)
+        v = blk[:, 2 * d:].view(L, heads, dh).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) * dh ** -0.5, dim=-1)
+        out[start:start + L] = (a @ v).transpose(0, 1).reshape(L, d)
+        start += L
+    return out
+
+
+@pytest.mark.parametrize("lens,heads", [([128] * 3, 4), ([1, 5, 64, 65, 127, 129, 200, 33], 4),
+                                        ([514, 300, 7], 2), ([31, 32, 33, 63], 16)])
+def test_attention(lib, lens, heads):
+    from sonar_amd import _lib
+
+    d = heads * 64
+    t = sum(lens)
+    g = torch.Generator(device="cuda").manual_seed(t + heads)
+    qkv = (torch.randn(t, 3 * d, device="cuda", generator=g) * 1.5).half()
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    ctx = torch.full((t, d), float("nan"), device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), len(lens), max(lens), d, heads, _stream()))
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv, lens, d, heads)
+    got = ctx.float()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 6e-3, (got - ref).abs().max().item()
