@@ -115,6 +115,25 @@ int smi_text_encoder_forward(smi_text_encoder* enc, const int64_t* ids, const in
 /* Bytes of device memory currently held by the handle (weights + workspace). */
 int64_t smi_text_encoder_device_bytes(const smi_text_encoder* enc);
 
+/* Per-kernel timing with HIP events recorded on the caller's stream around every
+ * launch of smi_text_encoder_forward (measurement aid for the roofline report; the
+ * reference has no profiler).  Off by default. */
+typedef enum smi_prof_slot {
+  SMI_PROF_EMBED = 0,
+  SMI_PROF_LAYERNORM = 1,
+  SMI_PROF_GEMM_QKV = 2,
+  SMI_PROF_ATTENTION = 3,
+  SMI_PROF_GEMM_OUT = 4,
+  SMI_PROF_GEMM_FFN1 = 5,
+  SMI_PROF_GEMM_FFN2 = 6,
+  SMI_PROF_LN_POOL = 7,
+  SMI_PROF_SLOTS = 8
+} smi_prof_slot;
+int smi_text_encoder_set_profiling(smi_text_encoder* enc, int32_t enable);
+/* Synchronises the recorded events, ADDS elapsed milliseconds and launch counts per
+ * slot into ms[SMI_PROF_SLOTS] / launches[SMI_PROF_SLOTS], then clears the record. */
+int smi_text_encoder_read_profile(smi_text_encoder* enc, double* ms, int64_t* launches);
+
 /* xsim mining ---------------------------------------------------------------
  * Stands in for the similarity search the reference performs as
  * F.normalize(x) @ F.normalize(y).T (tests/integration_tests/test_text_sonar.py:42-53)

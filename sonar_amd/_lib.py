@@ -15,6 +15,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
 SMI_OK = 0
 SMI_F32, SMI_F16 = 0, 1
 SMI_POOL = {"mean": 0, "max": 1, "last": 2}
+PROF_SLOTS = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_ffn1", "gemm_ffn2", "ln_pool"]
 STATUS_NAMES = {
     0: "SMI_OK",
     -1: "SMI_ERR_INVALID_ARG",
@@ -91,6 +92,8 @@ SYMBOLS = {
     "smi_text_encoder_destroy": (None, [_vp]),
     "smi_text_encoder_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "smi_text_encoder_device_bytes": (_i64, [_vp]),
+    "smi_text_encoder_set_profiling": (C.c_int, [_vp, _i32]),
+    "smi_text_encoder_read_profile": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "smi_xsim_padded_rows": (_i64, [_i64]),
     "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),

@@ -126,8 +126,15 @@ struct smi_text_encoder {
   int64_t cu_cap = 0;
   int cu_next = 0;
   int64_t weight_bytes = 0;
+  // optional per-launch event timing
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+  struct ProfRec { int slot; hipEvent_t a, b; };
+  std::vector<ProfRec> prof;
+  size_t ev_used = 0;
 
   ~smi_text_encoder() {
+    for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
     for (int i = 0; i < kCuRing; ++i) {
       if (h_cu[i]) (void)hipHostFree(h_cu[i]);
       if (cu_ev[i]) (void)hipEventDestroy(cu_ev[i]);
@@ -171,6 +178,32 @@ int ensure_workspace(smi_text_encoder* e, int64_t rows) {
   e->cap_rows = rows;
   return SMI_OK;
 }
+
+hipEvent_t prof_event(smi_text_encoder* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+
+// Brackets one launch with events when profiling is on.
+struct ProfScope {
+  smi_text_encoder* e;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  int slot;
+  ProfScope(smi_text_encoder* e_, int slot_, hipStream_t s_) : e(e_), s(s_), slot(slot_) {
+    if (e->profiling && (a = prof_event(e)) && (b = prof_event(e))) (void)hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (a && b) {
+      (void)hipEventRecord(b, s);
+      e->prof.push_back({slot, a, b});
+    }
+  }
+};
 
 int check_cfg(const smi_text_encoder_config& c) {
   if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
@@ -341,21 +374,50 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
 
   if (rows > total)
     HIP_TRY(hipMemsetAsync(x + (size_t)total * d, 0, (size_t)(rows - total) * d * 4, stream));
+  { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
-                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream));
+                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream)); }
   for (int l = 0; l < c.num_layers; ++l) {
     Layer& L = e->layers[l];
-    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream));
+    { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream)); }
+    { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d,
-                           3 * d, stream));
-    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d, stream));
-    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d, stream));
+                           3 * d, stream)); }
+    { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
+    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream)); }
+    { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d, stream)); }
+    { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
+    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream)); }
+    { ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream)); }
+    { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d, stream)); }
   }
+  { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
-                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream));
+                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream)); }
+  return SMI_OK;
+}
+
+int smi_text_encoder_set_profiling(smi_text_encoder* e, int32_t enable) {
+  if (!e) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  e->profiling = enable != 0;
+  return SMI_OK;
+}
+
+int smi_text_encoder_read_profile(smi_text_encoder* e, double* ms, int64_t* launches) {
+  if (!e || !ms || !launches) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  for (auto& r : e->prof) {
+    HIP_TRY(hipEventSynchronize(r.b));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.slot] += t;
+    launches[r.slot] += 1;
+  }
+  e->prof.clear();
+  e->ev_used = 0;
   return SMI_OK;
 }
 

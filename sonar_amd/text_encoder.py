@@ -250,6 +250,17 @@ class TextEncoderEngine:
     def device_bytes(self) -> int:
         return int(self.lib.smi_text_encoder_device_bytes(self._handle))
 
+    def set_profiling(self, enable: bool) -> None:
+        _lib.check(self.lib.smi_text_encoder_set_profiling(self._handle, 1 if enable else 0))
+
+    def read_profile(self) -> Dict[str, Dict[str, float]]:
+        """Per-kernel {ms, launches} accumulated since the last read (synchronises the events)."""
+        n = len(_lib.PROF_SLOTS)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        _lib.check(self.lib.smi_text_encoder_read_profile(self._handle, ms, cnt))
+        return {name: {"ms": ms[i], "launches": int(cnt[i])} for i, name in enumerate(_lib.PROF_SLOTS)}
+
     def forward(self, ids: torch.Tensor, seq_lens: Optional[Union[torch.Tensor, Sequence[int]]],
                 out_dtype: torch.dtype = torch.float16, return_encoded: bool = False):
         """ids: int64 [N,S] on the engine's device; seq_lens: host ints [N] or None."""

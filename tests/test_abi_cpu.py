@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol the header declares;
+the product path has no CPU fallback and never touches the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from sonar_amd import _lib, build
+
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "sonar_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(smi_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    from sonar_amd import _lib
+
+    declared = _header_functions()
+    assert declared, "no functions parsed from the header"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (smi_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+
+
+def test_version_and_helpers(lib):
+    assert b"gfx950" in lib.smi_version()
+    assert lib.smi_xsim_padded_rows(1) == 128 and lib.smi_xsim_padded_rows(128) == 128 and lib.smi_xsim_padded_rows(129) == 256
+    assert lib.smi_xsim_workspace_bytes(0, 5, 1) == 0
+    assert lib.smi_xsim_workspace_bytes(1000, 100000, 4) == 8 * 1024 * 4 * 8
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly(lib):
+    from sonar_amd import _lib
+
+    assert lib.smi_device_count() == 0
+    assert lib.smi_init(0) == -3
+    assert b"no HIP device" in lib.smi_last_error()
+    with pytest.raises(_lib.SmiError):
+        _lib.check(lib.smi_init(0))
+
+
+def test_engine_refuses_cpu_and_missing_library(monkeypatch, tmp_path):
+    from oracle import text_encoder as O
+    from sonar_amd import _lib
+    from sonar_amd.text_encoder import SonarTextEncoderConfig, TextEncoderEngine, VocabularyInfo
+
+    cfg = SonarTextEncoderConfig(model_dim=256, num_encoder_layers=1, num_encoder_attn_heads=4,
+                                 ffn_inner_dim=256, vocab_info=VocabularyInfo(size=50))
+    ocfg = O.OracleTextEncoderConfig(model_dim=256, num_layers=1, num_heads=4, ffn_inner_dim=256, vocab_size=50)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        TextEncoderEngine(cfg, O.make_synthetic_params(ocfg), device="cpu")
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "sonar_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
