@@ -297,7 +297,7 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
       }
     }
   }
-  if (rc == SMI_OK && max_tokens_hint > 0) rc = ensure_workspace(e, (max_tokens_hint + 127) / 128 * 128);
+  if (rc == SMI_OK && max_tokens_hint > 0) rc = ensure_workspace(e, (max_tokens_hint + 255) / 256 * 256);
   if (rc != SMI_OK) {
     delete e;
     return rc;
@@ -362,7 +362,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
       HIP_TRY(hipMemsetAsync(out_encoded, 0, (size_t)n * s * d * (out_dtype == SMI_F32 ? 4 : 2), stream));
     return SMI_OK;
   }
-  const int64_t rows = (total + 127) / 128 * 128;
+  const int64_t rows = (total + 255) / 256 * 256;  // 256-row GEMM tiles
   if (int rc = ensure_workspace(e, rows)) return rc;
   const int M = (int)rows;
 

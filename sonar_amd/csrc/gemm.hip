@@ -3,7 +3,10 @@
 // sonar/models/sonar_text/factory.py:130-153), fp16 in, fp32 accumulate on
 // v_mfma_f32_32x32x16_f16, with the bias / ReLU / residual epilogues fused.
 #include "gemm_tile.hpp"
+#include "gemm_tile256.hpp"
 #include "kernels.hpp"
+
+#include <cstdlib>
 
 namespace smi {
 
@@ -55,6 +58,127 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
   }
 }
 
+// Same epilogues on the 256x256 ping-pong tile engine (gemm_tile256.hpp).
+template <int EPI, int VAR = 0>
+__global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
+                                                                const f16* __restrict__ W,
+                                                                const float* __restrict__ bias,
+                                                                void* __restrict__ out, int M, int N,
+                                                                int K, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n;
+  g2_tile_coords(M / G2_BM, N / G2_BN, tile_m, tile_n);
+  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+
+  GemmTile256Acc acc;
+  g2_mainloop<VAR>(acc, X, W, K, m0, n0, smem);
+
+  // ---- epilogue: stage the C tile through LDS (free after the main loop) so the
+  // global stores are whole 512-B row segments instead of 8-B pieces 32 rows apart.
+  // Row stride 528 B: 16-B aligned and 2-way-or-better on the LDS banks.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
+  constexpr int CS = G2_CSTRIDE;
+  if constexpr (EPI == EPI_RESID_F32) {
+    // fp32 residual accumulate, two passes of 128 columns (pass p = the waves' ni block)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (p) __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)(bias + g2_col(n0, p, q));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc.v[p][mi][q * 4 + e] + b[e];
+          *(f32x4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 32 + 8 * q + 4 * hi) * 4) = v;
+        }
+      }
+      __syncthreads();
+      const int c = lane & 31;
+      const int gcol = n0 + (c >> 3) * 64 + p * 32 + (c & 7) * 4;
+      f32x4 old[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = wave * 32 + it * 2 + hi;
+        old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = wave * 32 + it * 2 + hi;
+        const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
+        *(f32x4*)((float*)out + (size_t)(m0 + row) * ldo + gcol) = old[it] + v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)(bias + g2_col(n0, ni, q));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          half4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc.v[ni][mi][q * 4 + e] + b[e];
+            if constexpr (EPI == EPI_RELU_F16) v = fmaxf(v, 0.f);
+            h[e] = (f16)v;
+          }
+          *(half4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 64 + ni * 32 + 8 * q + 4 * hi) * 2) = h;
+        }
+      }
+    }
+    __syncthreads();
+    const int c = lane & 31;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = wave * 32 + it * 2 + hi;
+      const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
+      *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
+    }
+  }
+}
+
+template <int EPI, int VAR>
+static hipError_t launch_var256(const f16* X, const f16* W, const float* bias, void* out, int M,
+                                int N, int K, int ldo, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, VAR>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G2_KERNEL_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int grid = (M / G2_BM) * (N / G2_BN);
+  hipLaunchKernelGGL((gemm_tn256_kernel<EPI, VAR>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
+                     stream, X, W, bias, out, M, N, K, ldo);
+  return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
+                                int N, int K, int ldo, hipStream_t stream) {
+#ifdef SMI_GEMM_ABLATION
+  // timing ablations of the main loop (wrong results when != 0); see gemm_tile256.hpp
+  static const int var = getenv("SMI_GEMM_VAR") ? atoi(getenv("SMI_GEMM_VAR")) : 0;
+  if (EPI == EPI_RELU_F16 || EPI == EPI_RESID_F32) {
+    switch (var) {
+      case 1: return launch_var256<EPI, 1>(X, W, bias, out, M, N, K, ldo, stream);
+      case 2: return launch_var256<EPI, 2>(X, W, bias, out, M, N, K, ldo, stream);
+      case 3: return launch_var256<EPI, 3>(X, W, bias, out, M, N, K, ldo, stream);
+      case 4: return launch_var256<EPI, 4>(X, W, bias, out, M, N, K, ldo, stream);
+      case 6: return launch_var256<EPI, 6>(X, W, bias, out, M, N, K, ldo, stream);
+      case 7: return launch_var256<EPI, 7>(X, W, bias, out, M, N, K, ldo, stream);
+      case 8: return launch_var256<EPI, 8>(X, W, bias, out, M, N, K, ldo, stream);
+      case 10: return launch_var256<EPI, 10>(X, W, bias, out, M, N, K, ldo, stream);
+    }
+  }
+#endif
+  return launch_var256<EPI, 0>(X, W, bias, out, M, N, K, ldo, stream);
+}
+
 template <int EPI>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream) {
@@ -74,6 +198,15 @@ static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void
 hipError_t launch_gemm_tn(int epi, const f16* X, const f16* W, const float* bias, void* out, int M,
                           int N, int K, int ldo, hipStream_t stream) {
   if (M % GT_BM || N % GT_BN || K % GT_BK || M <= 0) return hipErrorInvalidValue;
+  static const int force128 = getenv("SMI_GEMM_FORCE128") ? atoi(getenv("SMI_GEMM_FORCE128")) : 0;
+  if (!force128 && M % G2_BM == 0 && N % G2_BN == 0) {
+    switch (epi) {
+      case EPI_BIAS_F16: return launch_one256<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
+      case EPI_RELU_F16: return launch_one256<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);
+      case EPI_RESID_F32: return launch_one256<EPI_RESID_F32>(X, W, bias, out, M, N, K, ldo, stream);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
     case EPI_BIAS_F16: return launch_one<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
     case EPI_RELU_F16: return launch_one<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);

@@ -22,7 +22,9 @@ def _stream():
     return int(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192)])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
+                                   (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
+                                   (256, 256, 8192), (1024, 768, 256)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_tn(lib, m, n, k, epi):
     from sonar_amd import _lib
