@@ -141,7 +141,7 @@ int smi_text_encoder_read_profile(smi_text_encoder* enc, double* ms, int64_t* la
  * k (<= 8) most cosine-similar rows of Y, best first.
  *
  * smi_xsim_normalize: dst = f16 row-normalised copy of src, padded with zero
- *   rows to a multiple of 128 rows (dst must hold smi_xsim_padded_rows(rows)*d f16).
+ *   rows to a multiple of 256 rows (dst must hold smi_xsim_padded_rows(rows)*d f16).
  * smi_xsim_topk: Xn/Yn are such normalised, padded matrices.  idx [nx,k] int32
  *   (row index in Y plus y_index_offset; -1 if fewer than k candidates),
  *   score [nx,k] fp32.  workspace: smi_xsim_workspace_bytes() bytes of device memory. */

@@ -422,7 +422,7 @@ int smi_text_encoder_read_profile(smi_text_encoder* e, double* ms, int64_t* laun
 }
 
 // ------------------------------------------------------------------- xsim
-int64_t smi_xsim_padded_rows(int64_t rows) { return (rows + 127) / 128 * 128; }
+int64_t smi_xsim_padded_rows(int64_t rows) { return (rows + 255) / 256 * 256; }
 
 int smi_xsim_normalize(const void* src, int32_t src_dtype, int64_t rows, int32_t d, void* dst,
                        void* stream) {

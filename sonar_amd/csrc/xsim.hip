@@ -12,6 +12,7 @@
 // XCD an 8(x) x 8(chunk) block: its 8 X panels stay L2-resident for the whole
 // walk and every streamed Y tile is shared by 8 workgroups.
 #include "gemm_tile.hpp"
+#include "gemm_tile256.hpp"
 #include "kernels.hpp"
 
 namespace smi {
@@ -125,6 +126,168 @@ __global__ __launch_bounds__(GT_THREADS, 2) void xsim_tile_kernel(const f16* __r
   }
 }
 
+// 256-row variant on the ping-pong tile engine (gemm_tile256.hpp).  The K slices of
+// ALL y tiles of the chunk form one continuous DMA stream through the 4-slot LDS ring:
+// the pipeline is filled once per workgroup, not once per y tile; at every tile
+// boundary the accumulators are folded into the running top-k and cleared.
+template <int K>
+__global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __restrict__ Xn,
+                                                                  const f16* __restrict__ Yn, int d,
+                                                                  int ntx, int nty, int nchunks,
+                                                                  int tiles_per_chunk, int ny,
+                                                                  int nx_pad, float* __restrict__ ps,
+                                                                  int* __restrict__ pi) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, chunk;
+  g2_tile_coords(ntx, nchunks, tile_m, chunk);
+  const int m0 = tile_m * G2_BM;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
+
+  const int t_begin = chunk * tiles_per_chunk;
+  const int ntiles = min(nty, t_begin + tiles_per_chunk) - t_begin;
+  const int nt = d / G2_BK;
+  const int S = max(ntiles, 0) * nt;
+
+  TopK<K> best[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) best[mi].init();
+
+  if (S > 0) {
+    // DMA stream state: slice s = (tile s / nt, k = s % nt)
+    const f16* xg[2];
+    const f16* yg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = (wave * 2 + q) * 16 + (lane >> 2);
+      const int chunk16 = (lane & 3) ^ ((row >> 2) & 3);
+      xg[q] = Xn + (size_t)(m0 + row) * d + chunk16 * 8;
+      yg[q] = Yn + ((size_t)t_begin * G2_BN + row) * d + chunk16 * 8;
+    }
+    int ik = 0, is = 0;
+    auto issue = [&]() {
+      char* slot = smem + (is & 3) * G2_SLOT_BYTES + wave * 2048;
+      const int koff = ik * G2_BK;
+      glds16(xg[0] + koff, slot);
+      glds16(xg[1] + koff, slot + 1024);
+      glds16(yg[0] + koff, slot + G2_BM * G2_BK * 2);
+      glds16(yg[1] + koff, slot + G2_BM * G2_BK * 2 + 1024);
+      ++is;
+      if (++ik == nt) {
+        ik = 0;
+        yg[0] += (size_t)G2_BN * d;
+        yg[1] += (size_t)G2_BN * d;
+      }
+    };
+    const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
+    const int xoff = (wr * 128 + l31) * 64 + t_sw;
+    const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
+
+    GemmTile256Acc acc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+
+    issue();
+    if (S > 1) issue();
+    if (S > 2) issue();
+    if (S > 2) SMI_WAIT_VMCNT(8);
+    else if (S > 1) SMI_WAIT_VMCNT(4);
+    else SMI_WAIT_VMCNT(0);
+    SMI_BARRIER();
+    if (wr == 1) SMI_BARRIER();
+
+    int k = 0, n0 = t_begin * G2_BN;
+    for (int s = 0; s < S; ++s) {
+      const char* slot = smem + (s & 3) * G2_SLOT_BYTES;
+      half8 fx[2][4], fw[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fw[ks][ni] = *(const half8*)(slot + ((woff + ni * 2048) ^ (ks << 5)));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
+      }
+      if (s + 3 < S) {
+        issue();
+        SMI_WAIT_VMCNT(8);
+      } else if (s + 2 < S) {
+        SMI_WAIT_VMCNT(4);
+      } else {
+        SMI_WAIT_VMCNT(0);
+      }
+      SMI_LGKM0_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+            acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      SMI_BARRIER();
+      if (++k == nt) {  // y tile finished: fold the 128x64 scores of this wave into the top-k
+        k = 0;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            float vmax = acc.v[ni][mi][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
+            if (vmax >= best[mi].s[K - 1]) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                if (n < ny) best[mi].push(acc.v[ni][mi][r], n);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc.v[ni][mi][r] = 0.f;
+          }
+        }
+        n0 += G2_BN;
+      }
+    }
+    if (wr == 0) SMI_BARRIER();
+  }
+
+  // merge the 8 lists of every x row (2 lane halves x 4 n-waves) through LDS
+  __syncthreads();
+  float* ls = (float*)smem;  // [256 rows][8][K]
+  int* li = (int*)(smem + 256 * 8 * K * 4);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int row = wr * 128 + mi * 32 + l31;
+    const int slot = wc * 2 + hi;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ls[(row * 8 + slot) * K + j] = best[mi].s[j];
+      li[(row * 8 + slot) * K + j] = best[mi].i[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int row = threadIdx.x;
+    TopK<K> t;
+    t.init();
+    for (int c = 0; c < 8 * K; ++c) t.push(ls[row * 8 * K + c], li[row * 8 * K + c]);
+    const size_t o = ((size_t)chunk * nx_pad + m0 + row) * K;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ps[o + j] = t.s[j];
+      pi[o + j] = t.i[j];
+    }
+  }
+}
+
 // final merge over chunks; one thread per x row.  k_out <= K.
 template <int K>
 __global__ __launch_bounds__(256) void xsim_merge_kernel(const float* __restrict__ ps,
@@ -176,7 +339,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ src, 
 
 hipError_t launch_l2_normalize(const void* src, int src_is_f32, f16* dst, int64_t rows, int d,
                                hipStream_t stream) {
-  const int64_t rows_pad = (rows + GT_BM - 1) / GT_BM * GT_BM;
+  const int64_t rows_pad = (rows + G2_BM - 1) / G2_BM * G2_BM;
   if (rows_pad == 0) return hipSuccess;
   const unsigned blocks = (unsigned)((rows_pad + 3) / 4);
   if (src_is_f32)
@@ -207,14 +370,34 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
-  const int nchunks = xsim_chunks(nty);
-  const int tpc = (nty + nchunks - 1) / nchunks;
   float* ps = (float*)ws;
+  hipError_t e;
+  int nchunks;
+  if constexpr (K <= 4) {
+    // 256x256 tiles, continuous slice stream
+    static bool attr256_done = false;
+    if (!attr256_done) {
+      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+      if (e != hipSuccess) return e;
+      attr256_done = true;
+    }
+    const int ntx = (int)(nx_pad / G2_BM), nty = (int)(ny_pad / G2_BN);
+    nchunks = xsim_chunks(nty);
+    const int tpc = (nty + nchunks - 1) / nchunks;
+    int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
+    hipLaunchKernelGGL(xsim_tile256_kernel<K>, dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES,
+                       stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+  } else {
+    const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
+    nchunks = xsim_chunks(nty);
+    const int tpc = (nty + nchunks - 1) / nchunks;
+    int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
+    hipLaunchKernelGGL(xsim_tile_kernel<K>, dim3(ntx * nchunks), dim3(GT_THREADS), GT_LDS_BYTES,
+                       stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+  }
   int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
-  hipLaunchKernelGGL(xsim_tile_kernel<K>, dim3(ntx * nchunks), dim3(GT_THREADS), GT_LDS_BYTES,
-                     stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
-  hipError_t e = hipGetLastError();
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(xsim_merge_kernel<K>, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream,
                      ps, pi, nchunks, nx, (int)nx_pad, k, y_off, idx, score);
@@ -225,7 +408,7 @@ hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16
                             int64_t ny_pad, int d, int k, int64_t y_off, int32_t* idx, float* score,
                             void* ws, hipStream_t stream) {
   if (nx <= 0 || ny <= 0 || k < 1 || k > 8 || d % GT_BK || nx_pad % GT_BM || ny_pad % GT_BN ||
-      ny_pad > 0x7fffff00LL || nx_pad > 0x7fffff00LL)
+      ny_pad > 0x7fffff00LL || nx_pad > 0x7fffff00LL || nx_pad % G2_BM || ny_pad % G2_BN)
     return hipErrorInvalidValue;
   switch (round_k(k)) {
     case 1: return xsim_run<1>(Xn, nx, nx_pad, Yn, ny, ny_pad, d, k, y_off, idx, score, ws, stream);

@@ -32,7 +32,7 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
 
 
 def normalize_rows(t: torch.Tensor) -> torch.Tensor:
-    """fp16 L2-normalised copy, zero-padded to a multiple of 128 rows (engine layout)."""
+    """fp16 L2-normalised copy, zero-padded to a multiple of 256 rows (engine layout)."""
     t = _prep(t)
     lib = _lib.load()
     rows, d = t.shape

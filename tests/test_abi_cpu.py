@@ -38,7 +38,7 @@ def test_header_symbols_exported_and_bound(lib):
 
 def test_version_and_helpers(lib):
     assert b"gfx950" in lib.smi_version()
-    assert lib.smi_xsim_padded_rows(1) == 128 and lib.smi_xsim_padded_rows(128) == 128 and lib.smi_xsim_padded_rows(129) == 256
+    assert lib.smi_xsim_padded_rows(1) == 256 and lib.smi_xsim_padded_rows(256) == 256 and lib.smi_xsim_padded_rows(257) == 512
     assert lib.smi_xsim_workspace_bytes(0, 5, 1) == 0
     assert lib.smi_xsim_workspace_bytes(1000, 100000, 4) == 8 * 1024 * 4 * 8
 
