@@ -1,0 +1,195 @@
+"""TextToEmbeddingModelPipeline with the reference's interface
+(sonar/inference_pipelines/text.py:140-269), running the model on the MI355X
+engine.  Same argument names, checks, warnings and output order; the fairseq2
+DataPipeline (read -> tokenize -> truncate -> dynamic_bucket -> Collater(pad) ->
+to-device -> prefetch(2) -> model) is restated with a plain background thread.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import warnings
+from contextlib import contextmanager
+from pathlib import Path
+from typing import Iterable, Iterator, List, Optional, Sequence, Union
+
+import torch
+
+from ..text_encoder import SonarTextTransformerEncoderModel, load_sonar_text_encoder
+from ..tokenizer import NllbTokenizer
+from .utils import add_progress_bar, extract_sequence_batch
+
+CPU = torch.device("cpu")
+
+
+@contextmanager
+def precision_context(dtype: torch.dtype) -> Iterator[None]:
+    """sonar/inference_pipelines/text.py:36-54 (kept for interface parity; the
+    engine's own kernels do not consult torch's matmul precision)."""
+    if dtype in (torch.float16, torch.bfloat16):
+        precision = "medium"
+    elif dtype == torch.float32:
+        precision = "high"
+    elif dtype == torch.float64:
+        precision = "highest"
+    else:
+        raise ValueError("Unsupported dtype for precision context")
+    old = torch.get_float32_matmul_precision()
+    torch.set_float32_matmul_precision(precision)
+    try:
+        yield
+    finally:
+        torch.set_float32_matmul_precision(old)
+
+
+def dynamic_bucket(items: Iterable[torch.Tensor], threshold: int, max_num_examples: int,
+                   min_num_examples: int = 1) -> Iterator[List[torch.Tensor]]:
+    """fairseq2 `.dynamic_bucket(threshold, cost_fn=len, min_num_examples, max_num_examples,
+    drop_remainder=False)` as used at text.py:234-240: a bucket closes once its summed
+    length reaches the threshold (and it holds at least `min_num_examples`) or it holds
+    `max_num_examples` sequences."""
+    bucket: List[torch.Tensor] = []
+    cost = 0
+    for it in items:
+        bucket.append(it)
+        cost += len(it)
+        if (cost >= threshold and len(bucket) >= min_num_examples) or len(bucket) >= max_num_examples:
+            yield bucket
+            bucket, cost = [], 0
+    if bucket:
+        yield bucket
+
+
+def collate(seqs: Sequence[torch.Tensor], pad_value: int) -> dict:
+    """fairseq2 Collater(pad_value): right-pad to the batch maximum."""
+    lens = torch.tensor([len(s) for s in seqs], dtype=torch.int32)
+    s_max = int(lens.max()) if len(seqs) else 0
+    out = torch.full((len(seqs), s_max), pad_value, dtype=torch.int64)
+    for i, s in enumerate(seqs):
+        out[i, : len(s)] = s
+    return {"seqs": out, "seq_lens": lens, "is_ragged": bool((lens != s_max).any())}
+
+
+def _prefetch(it: Iterator, depth: int) -> Iterator:
+    """`.prefetch(depth)`: run the upstream stages on a background thread."""
+    q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
+    end = object()
+
+    def work():
+        try:
+            for x in it:
+                q.put(x)
+            q.put(end)
+        except BaseException as e:  # propagate to the consumer
+            q.put(e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    while True:
+        x = q.get()
+        if x is end:
+            break
+        if isinstance(x, BaseException):
+            raise x
+        yield x
+    th.join()
+
+
+class TextToEmbeddingModelPipeline(torch.nn.Module):
+    model: SonarTextTransformerEncoderModel
+    tokenizer: NllbTokenizer
+
+    def __init__(self, encoder: Union[str, Path, SonarTextTransformerEncoderModel],
+                 tokenizer: Union[str, Path, NllbTokenizer],
+                 device: torch.device = CPU, dtype: Optional[torch.dtype] = None) -> None:
+        """
+        Args:
+            encoder: a checkpoint path (fairseq or fairseq2 layout, `basic` arch) or a model object
+            tokenizer: a SentencePiece model path or a tokenizer object
+            device: the HIP device to run on.  The reference defaults to CPU; this engine has no
+                CPU path, so a CPU device raises here instead of silently running elsewhere.
+            dtype: dtype of the returned embeddings (float16 default, float32 supported).
+        """
+        super().__init__()
+        device = torch.device(device)
+        if isinstance(encoder, (str, Path)):
+            if device.type != "cuda":
+                raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
+            encoder = load_sonar_text_encoder(str(encoder), device=device, dtype=dtype or torch.float16)
+        if isinstance(tokenizer, (str, Path)):
+            tokenizer = NllbTokenizer(tokenizer)
+        self.tokenizer = tokenizer
+        self.model = encoder.eval()
+        self.device = getattr(encoder, "device", device)
+        self.dtype = dtype
+
+    @torch.inference_mode()
+    def predict(self, input: Union[Path, Sequence[str]], source_lang: str,
+                batch_size: Optional[int] = 5, batch_max_tokens: Optional[int] = None,
+                max_seq_len: Optional[int] = None, progress_bar: bool = False,
+                target_device: Optional[torch.device] = None) -> torch.Tensor:
+        """Transform the input texts (a list of strings or a text file) into a matrix of their
+        embeddings; texts are truncated to `max_seq_len` tokens or to the model maximum."""
+        if batch_max_tokens is None and batch_size is None:
+            raise ValueError("at least one of `batch_size` or `batch_max_tokens` should be provided")
+        if batch_max_tokens is not None and batch_max_tokens <= 0:
+            raise ValueError("`batch_max_tokens` should be strictly positive")
+        if batch_size is not None and batch_size <= 0:
+            raise ValueError("`batch_size` should be strictly positive")
+
+        tokenizer_encoder = self.tokenizer.create_encoder(lang=source_lang)
+        model_max_len = self.model.encoder_frontend.pos_encoder.max_seq_len
+        if max_seq_len is None:
+            max_seq_len = model_max_len
+        if max_seq_len is not None and model_max_len is not None and max_seq_len > model_max_len:
+            raise ValueError(f"max_seq_len cannot be larger than max_seq_len of the encoder model: {model_max_len}")
+
+        n_truncated = 0
+
+        def truncate(x: torch.Tensor) -> torch.Tensor:
+            nonlocal n_truncated
+            if max_seq_len is None:
+                return x
+            if x.shape[0] > max_seq_len:
+                n_truncated += 1
+            return x[:max_seq_len]
+
+        if isinstance(input, (str, Path)):
+            with open(Path(input), "r", encoding="utf-8") as fh:
+                texts: Sequence[str] = [line.rstrip("\n") for line in fh]
+            order: Iterable[int] = range(len(texts))
+            sorting_index = None
+        else:
+            texts = input
+            # sort by CHARACTER length, as the reference does (text.py:226)
+            sorting_index = torch.argsort(torch.tensor(list(map(len, texts)), dtype=torch.int64))
+            order = sorting_index.tolist()
+
+        pad_idx = self.tokenizer.vocab_info.pad_idx
+        dev = self.device
+
+        def upstream():
+            toks = (truncate(tokenizer_encoder(texts[i])) for i in order)
+            for bucket in dynamic_bucket(toks, batch_max_tokens or 2**31, batch_size or 20_000):
+                yield extract_sequence_batch(collate(bucket, pad_idx), dev)
+
+        pipeline: Iterable = _prefetch(upstream(), 2)
+        if progress_bar:
+            pipeline = add_progress_bar(pipeline, inputs=texts,
+                                        batch_size=batch_size if batch_max_tokens is None else None)
+        results: List[torch.Tensor] = []
+        with precision_context(self.model.dtype):
+            for batch in pipeline:
+                out = self.model(batch)
+                results.append(out.sentence_embeddings.to(target_device or self.device))
+
+        if n_truncated:
+            warnings.warn(f"For {n_truncated} input tensors for SONAR text encoder, "
+                          f"the length was truncated to {max_seq_len} elements.")
+        if not results:
+            return torch.empty((0, self.model.model_dim), dtype=self.model.dtype, device=target_device or self.device)
+        sentence_embeddings = torch.cat(results, dim=0)
+        if sorting_index is not None:
+            reversed_index = torch.argsort(sorting_index)
+            sentence_embeddings = sentence_embeddings[reversed_index.to(sentence_embeddings.device)]
+        return sentence_embeddings

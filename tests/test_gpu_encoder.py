@@ -125,3 +125,45 @@ def test_xsim_error_rate_matches_oracle():
         ref = OX.xsim_error_rate(x.half().float(), y_al.half().float(), margin=margin)
         got, _ = xsim.xsim_error(x.half().cuda(), y_al.half().cuda(), margin=margin)
         assert abs(got - ref) <= 2e-3, (margin, got, ref)
+
+
+def test_predict_pipeline_end_to_end(tmp_path):
+    """TextToEmbeddingModelPipeline.predict() on the engine == oracle on the same token ids,
+    in input order, for several batchings (reference: test_text_sonar.py:120-161)."""
+    import sentencepiece as spm
+
+    from oracle import text_encoder as O
+    from sonar_amd.inference_pipelines import TextToEmbeddingModelPipeline
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel
+    from sonar_amd.tokenizer import NllbTokenizer
+
+    words = ["hello", "world", "my", "name", "is", "paul", "teacher", "working", "bonjour", "monde",
+             "je", "travaille", "comme", "professeur", "the", "quick", "brown", "fox", "jumps", "over"]
+    g = torch.Generator().manual_seed(0)
+    corpus = tmp_path / "c.txt"
+    with open(corpus, "w") as fh:
+        for _ in range(400):
+            n = int(torch.randint(2, 12, (1,), generator=g))
+            fh.write(" ".join(words[int(i)] for i in torch.randint(0, len(words), (n,), generator=g)) + "\n")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "toy"), vocab_size=48,
+                                   model_type="unigram", hard_vocab_limit=False, bos_id=1, eos_id=2,
+                                   unk_id=0, pad_id=-1, minloglevel=2)
+    tok = NllbTokenizer(str(tmp_path / "toy.model"))
+    ocfg, cfg = _cfgs(vocab=tok.vocab_info.size)
+    params = O.make_synthetic_params(ocfg, seed=11, std=0.08)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    pipe = TextToEmbeddingModelPipeline(model, tok, device=torch.device("cuda:0"))
+    texts = ["hello world my name is paul", "hello", "the quick brown fox jumps over the teacher",
+             "bonjour monde", "je travaille comme professeur", "fox"]
+    enc = tok.create_encoder(lang="eng_Latn")
+    ref = []
+    for t in texts:
+        ids = enc(t).unsqueeze(0)
+        ref.append(O.text_encoder_forward(params, ocfg, ids, None)[1])
+    ref = torch.cat(ref)
+    for kw in (dict(batch_size=2), dict(batch_size=1), dict(batch_size=None, batch_max_tokens=5), dict(batch_size=6)):
+        out = pipe.predict(texts, source_lang="eng_Latn", **kw)
+        assert out.shape == ref.shape and out.device.type == "cuda"
+        assert _cos_err(out, ref) <= 1e-3, kw
+        assert (out.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    assert pipe.predict(texts[:2], "eng_Latn", target_device=torch.device("cpu")).device.type == "cpu"

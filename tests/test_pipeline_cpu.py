@@ -1,0 +1,163 @@
+"""CPU: host-side logic of the pipeline mirror (tokenizer ids, bucketing, ordering,
+errors and warnings) with a stand-in model object -- no compute kernels involved."""
+import os
+import warnings
+
+import pytest
+import torch
+
+from sonar_amd.inference_pipelines.text import (TextToEmbeddingModelPipeline, collate, dynamic_bucket)
+from sonar_amd.nllb_langs import NLLB_EXTRA_CONTROL, NLLB_LANGS
+from sonar_amd.text_encoder import SonarEncoderOutput, convert_sonar_text_encoder_checkpoint
+from sonar_amd.tokenizer import NllbTokenizer
+
+REF_CARD = "/root/reference/sonar/cards/text_sonar_basic_encoder.yaml"
+
+
+@pytest.fixture(scope="module")
+def spm_model(tmp_path_factory):
+    import sentencepiece as spm
+
+    d = tmp_path_factory.mktemp("spm")
+    corpus = d / "corpus.txt"
+    words = ["hello", "world", "my", "name", "is", "paul", "teacher", "working", "bonjour", "monde",
+             "je", "travaille", "comme", "professeur", "the", "quick", "brown", "fox", "jumps", "over"]
+    g = torch.Generator().manual_seed(0)
+    with open(corpus, "w") as fh:
+        for _ in range(400):
+            n = int(torch.randint(2, 12, (1,), generator=g))
+            fh.write(" ".join(words[int(i)] for i in torch.randint(0, len(words), (n,), generator=g)) + "\n")
+    prefix = str(d / "toy")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=prefix, vocab_size=48, model_type="unigram", hard_vocab_limit=False,
+                                   bos_id=1, eos_id=2, unk_id=0, pad_id=-1, minloglevel=2)
+    return prefix + ".model"
+
+
+def test_lang_token_ids_match_reference_facts():
+    # SURVEY a14 / notebook cell 44: eng_Latn -> 256047, fra_Latn -> 256057, vocab 256206
+    assert 256001 + NLLB_LANGS.index("eng_Latn") == 256047
+    assert 256001 + NLLB_LANGS.index("fra_Latn") == 256057
+    assert 256001 + len(NLLB_LANGS) + len(NLLB_EXTRA_CONTROL) == 256206
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CARD), reason="reference tree not present")
+def test_lang_order_matches_reference_card():
+    import yaml
+
+    card = yaml.safe_load(open(REF_CARD))
+    assert card["langs"] == NLLB_LANGS
+
+
+def test_tokenizer_layout(spm_model):
+    tok = NllbTokenizer(spm_model)
+    assert tok.vocab_info.pad_idx == 0 and tok.vocab_info.eos_idx == 3
+    enc = tok.create_encoder(lang="fra_Latn")
+    ids = enc("bonjour monde")
+    assert ids.dtype == torch.int64
+    assert ids[0].item() == tok.lang_idx("fra_Latn") and ids[-1].item() == 3
+    assert all(4 <= i < tok.lang_base for i in ids[1:-1].tolist())
+    assert tok.decode(ids) == "bonjour monde"
+    tgt = tok.create_encoder(lang="eng_Latn", mode="target")
+    assert tgt("hello").tolist()[:2] == [3, tok.lang_idx("eng_Latn")]
+    assert enc.encode_batch(["bonjour monde", "je travaille"])[0] == ids.tolist()
+    with pytest.raises(ValueError):
+        tok.create_encoder(lang="xx_Nope")
+
+
+def test_dynamic_bucket_and_collate():
+    seqs = [torch.arange(n) for n in (3, 4, 5, 1, 2, 9)]
+    assert [len(b) for b in dynamic_bucket(iter(seqs), 2**31, 4)] == [4, 2]
+    # threshold 7 tokens: [3,4] closes at 7, [5,1,2] closes at 8, [9]
+    assert [[len(s) for s in b] for b in dynamic_bucket(iter(seqs), 7, 100)] == [[3, 4], [5, 1, 2], [9]]
+    c = collate(seqs[:3], 0)
+    assert c["seqs"].shape == (3, 5) and c["is_ragged"] and c["seq_lens"].tolist() == [3, 4, 5]
+    assert c["seqs"][0].tolist() == [0, 1, 2, 0, 0]
+    assert not collate([torch.arange(4), torch.arange(4)], 0)["is_ragged"]
+
+
+class _StubEncoder:
+    """Deterministic stand-in: embedding = [sum of ids, length] (host logic tests only)."""
+
+    model_dim = 2
+    dtype = torch.float32
+    device = torch.device("cpu")
+
+    class _F:
+        class _P:
+            max_seq_len = 16
+        pos_encoder = _P()
+    encoder_frontend = _F()
+
+    def __init__(self):
+        self.batches = []
+
+    def eval(self):
+        return self
+
+    def __call__(self, batch):
+        seqs = batch.seqs
+        lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else torch.full((seqs.shape[0],), seqs.shape[1])
+        self.batches.append((tuple(seqs.shape), batch.padding_mask is None))
+        mask = torch.arange(seqs.shape[1]).unsqueeze(0) < lens.unsqueeze(1)
+        emb = torch.stack([(seqs * mask).sum(1).float(), lens.float()], dim=1)
+        return SonarEncoderOutput(None, emb, batch.padding_mask)
+
+
+def test_predict_order_bucketing_and_truncation(spm_model, tmp_path):
+    tok = NllbTokenizer(spm_model)
+    stub = _StubEncoder()
+    pipe = TextToEmbeddingModelPipeline(stub, tok, device=torch.device("cpu"))
+    texts = ["hello world my name is paul", "hello", "the quick brown fox jumps over the teacher", "bonjour monde"]
+    enc = tok.create_encoder(lang="eng_Latn")
+    expect = torch.tensor([[float(enc(t).sum()), float(len(enc(t)))] for t in texts])
+    out = pipe.predict(texts, source_lang="eng_Latn", batch_size=2)
+    assert torch.equal(out, expect)  # input order restored after the length sort
+    assert len(stub.batches) == 2
+    # batching invariance of the host path (reference: test_text_sonar.py:120-161)
+    for kw in (dict(batch_size=1), dict(batch_size=None, batch_max_tokens=5), dict(batch_max_tokens=30)):
+        assert torch.equal(pipe.predict(texts, source_lang="eng_Latn", **kw), expect)
+    # file input keeps file order, no sorting
+    f = tmp_path / "in.txt"
+    f.write_text("\n".join(texts) + "\n")
+    assert torch.equal(pipe.predict(f, source_lang="eng_Latn", batch_size=3), expect)
+    # truncation warns and clips to the model maximum (reference: test_text_sonar.py:55-59)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        long_out = pipe.predict(["hello " * 100], source_lang="eng_Latn")
+    assert any("truncated to 16" in str(x.message) for x in w)
+    assert long_out[0, 1].item() == 16
+
+
+def test_predict_argument_errors(spm_model):
+    pipe = TextToEmbeddingModelPipeline(_StubEncoder(), NllbTokenizer(spm_model), device=torch.device("cpu"))
+    with pytest.raises(ValueError, match="at least one of"):
+        pipe.predict(["a"], "eng_Latn", batch_size=None, batch_max_tokens=None)
+    with pytest.raises(ValueError, match="strictly positive"):
+        pipe.predict(["a"], "eng_Latn", batch_size=0)
+    with pytest.raises(ValueError, match="strictly positive"):
+        pipe.predict(["a"], "eng_Latn", batch_max_tokens=-1)
+    with pytest.raises(ValueError, match="max_seq_len cannot be larger"):
+        pipe.predict(["a"], "eng_Latn", max_seq_len=17)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        TextToEmbeddingModelPipeline("/nonexistent/ckpt.pt", NllbTokenizer(spm_model), device=torch.device("cpu"))
+
+
+def test_checkpoint_conversion_layouts():
+    # fairseq1 layout -> renamed keys + control-token row permutation (handler.py:71-92)
+    emb = torch.arange(24, dtype=torch.float32).reshape(6, 4)
+    sd = {"embed_tokens.weight": emb.clone(), "layers.0.fc1.weight": torch.ones(2, 2),
+          "layers.0.self_attn.out_proj.bias": torch.zeros(2), "layers.0.final_layer_norm.weight": torch.ones(2),
+          "layer_norm.weight": torch.ones(2), "version": torch.tensor([1.0]),
+          "embed_positions._float_tensor": torch.zeros(1)}
+    out = convert_sonar_text_encoder_checkpoint({"state_dict": sd})
+    assert set(out) == {"encoder_frontend.embed.weight", "encoder.layers.0.ffn.inner_proj.weight",
+                        "encoder.layers.0.self_attn.output_proj.bias", "encoder.layers.0.ffn_layer_norm.weight",
+                        "layer_norm.weight"}
+    assert torch.equal(out["encoder_frontend.embed.weight"][:4], emb[[1, 3, 0, 2]])
+    assert torch.equal(out["encoder_frontend.embed.weight"][4:], emb[4:])
+    assert torch.equal(sd["embed_tokens.weight"], emb)  # caller's tensor untouched
+    # fairseq2 layout passes through
+    m = {"model": {"encoder_frontend.embed.weight": emb}}
+    assert convert_sonar_text_encoder_checkpoint(m)["encoder_frontend.embed.weight"] is emb
+    with pytest.raises(ValueError):
+        convert_sonar_text_encoder_checkpoint({"weights": {}})
