@@ -62,7 +62,7 @@ def synthetic_state_dict(device, seed=1234):
     return sd
 
 
-def cpu_baseline(n_sent=64):
+def cpu_baseline(n_sent=16):
     """Reference-equivalent op sequence (the oracle, kind 'port') on the host cores."""
     import torch
 
@@ -74,7 +74,7 @@ def cpu_baseline(n_sent=64):
     params = O.make_synthetic_params(cfg, seed=1234)
     log(f"[cpu_baseline] built fp32 oracle weights in {time.time() - t0:.1f}s")
     ids, _ = O.synthetic_batch(n_sent, SEQ, SEQ, cfg.vocab_size, seed=0)
-    O.text_encoder_forward(params, cfg, ids[:4], None)  # warm-up
+    O.text_encoder_forward(params, cfg, ids[:2], None)  # warm-up
     t0 = time.time()
     O.text_encoder_forward(params, cfg, ids, None)
     dt = time.time() - t0
@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--no-xsim", action="store_true")
     ap.add_argument("--xsim-nx", type=int, default=65536, help="X rows per rank")
     ap.add_argument("--xsim-ny", type=int, default=1 << 20, help="total Y rows (sharded over ranks)")
-    ap.add_argument("--cpu-sentences", type=int, default=64)
+    ap.add_argument("--cpu-sentences", type=int, default=16)
     args = ap.parse_args()
 
     import torch
