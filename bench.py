@@ -62,13 +62,19 @@ def synthetic_state_dict(device, seed=1234):
     return sd
 
 
-def cpu_baseline(n_sent=16):
+def cpu_baseline(n_sent=96):
     """Reference-equivalent op sequence (the oracle, kind 'port') on the host cores."""
     import torch
 
     from oracle import text_encoder as O
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # measured on the MI355X box's host (2 x EPYC 9575F, 256 hw threads, shared): the torch CPU
+    # oracle peaks at 16 threads (6.3 sent/s) and degrades with more (1.4 sent/s at 128)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))
     cfg = O.OracleTextEncoderConfig()
     t0 = time.time()
     params = O.make_synthetic_params(cfg, seed=1234)
@@ -91,7 +97,7 @@ def main():
     ap.add_argument("--no-xsim", action="store_true")
     ap.add_argument("--xsim-nx", type=int, default=65536, help="X rows per rank")
     ap.add_argument("--xsim-ny", type=int, default=1 << 20, help="total Y rows (sharded over ranks)")
-    ap.add_argument("--cpu-sentences", type=int, default=16)
+    ap.add_argument("--cpu-sentences", type=int, default=96)
     args = ap.parse_args()
 
     import torch
