@@ -134,6 +134,74 @@ int smi_text_encoder_set_profiling(smi_text_encoder* enc, int32_t enable);
  * slot into ms[SMI_PROF_SLOTS] / launches[SMI_PROF_SLOTS], then clears the record. */
 int smi_text_encoder_read_profile(smi_text_encoder* enc, double* ms, int64_t* launches);
 
+/* Text decoder + beam search ---------------------------------------------------
+ * Stands in for: SonarTextDecoderFactory.create_model + checkpoint load
+ * (sonar/models/sonar_text/factory.py:229-315, handler.py:122-172), the
+ * SonarEncoderDecoderModel.encode/decode/project calls of one generation step
+ * (sonar/models/sonar_translation/model.py:48-78, DummyEncoderModel :81-95) and fairseq2's
+ * BeamSearchSeq2SeqGenerator as driven by EmbeddingToTextModelPipeline.predict
+ * (sonar/inference_pipelines/text.py:305-346). */
+typedef struct smi_text_decoder_config {
+  int32_t model_dim;     /* 1024 = num_heads*64 */
+  int32_t num_layers;    /* 24 */
+  int32_t num_heads;     /* 16 */
+  int32_t ffn_inner_dim; /* 8192 */
+  int64_t vocab_size;    /* 256206 */
+  int32_t max_seq_len;   /* 512: longest target sequence incl. prompt (config.py:197-219) */
+  int32_t pos_offset;    /* 2 = model pad_idx + 1 (_legacy_pad_idx, factory.py:248-252) */
+  int32_t input_dim;     /* conditioning vector dimension (= model_dim) */
+  float embed_scale;     /* sqrt(model_dim) */
+  float ln_eps;          /* 1e-5 */
+  int32_t pad_idx, unk_idx, bos_idx, eos_idx; /* TOKENIZER ids: 0, 1, 2, 3 */
+} smi_text_decoder_config;
+
+/* encoder_decoder_attn q/k projections and its LayerNorm are not needed: the encoder output is
+ * ONE vector, so the attention weight is 1 and the block reduces to W_o (W_v e + b_v) + b_o. */
+typedef struct smi_text_decoder_layer {
+  smi_tensor self_attn_layer_norm_w, self_attn_layer_norm_b;
+  smi_tensor q_w, q_b, k_w, k_b, v_w, v_b, out_w, out_b;
+  smi_tensor cross_v_w, cross_v_b, cross_out_w, cross_out_b;
+  smi_tensor ffn_layer_norm_w, ffn_layer_norm_b;
+  smi_tensor ffn_inner_w, ffn_inner_b, ffn_out_w, ffn_out_b;
+} smi_text_decoder_layer;
+
+typedef struct smi_text_decoder_weights {
+  smi_tensor embed;     /* decoder_frontend.embed.weight [vocab, model_dim]; also the tied final_proj */
+  smi_tensor pos_table; /* sinusoidal table [max_seq_len + pos_offset, model_dim] fp32 */
+  smi_tensor final_layer_norm_w, final_layer_norm_b; /* decoder.layer_norm */
+  const smi_text_decoder_layer* layers;
+} smi_text_decoder_weights;
+
+typedef struct smi_beam_search_params {
+  int32_t beam_size;        /* 1..8 (fairseq2 default 5) */
+  int32_t max_seq_len;      /* min(prompt_len + max_gen_len, model max): EOS is forced at max_seq_len-1 */
+  int32_t min_seq_len;      /* prompt_len + min_gen_len: EOS blocked while step < min_seq_len */
+  int32_t normalize_scores; /* 1: score / (len - 1)^len_penalty */
+  float len_penalty;        /* 1.0 */
+  float unk_penalty;        /* 0.0 */
+  float temperature;        /* 1.0 */
+  int32_t reserved;
+} smi_beam_search_params;
+
+typedef struct smi_text_decoder smi_text_decoder; /* opaque */
+
+int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_decoder_weights* w,
+                            smi_text_decoder** out);
+void smi_text_decoder_destroy(smi_text_decoder* dec);
+
+/* Teacher-forced logits (the reference test's call, tests/integration_tests/test_text_sonar.py:61-105):
+ * emb device [n, model_dim] (emb_dtype), prev_tokens device int64 [n, t], out_logits device fp32 [n, t, vocab]. */
+int smi_text_decoder_logits(smi_text_decoder* dec, const void* emb, int32_t emb_dtype, int32_t n,
+                            const int64_t* prev_tokens, int32_t t, float* out_logits, void* stream);
+
+/* Beam search for n sentence embeddings.  prompt: HOST int64 [prompt_len] (= [</s>, __lang__]).
+ * Outputs (device): out_tokens int32 [n, beam, max_seq_len] generated tokens after the prompt incl. the
+ * final EOS, -1 padded; out_lens int32 [n, beam]; out_scores fp32 [n, beam]; hypotheses best first
+ * (the reference decodes hypotheses[0]).  Synchronises `stream` every 8 steps to test for completion. */
+int smi_text_decoder_generate(smi_text_decoder* dec, const void* emb, int32_t emb_dtype, int32_t n,
+                              const int64_t* prompt, int32_t prompt_len, const smi_beam_search_params* params,
+                              int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
+
 /* xsim mining ---------------------------------------------------------------
  * Stands in for the similarity search the reference performs as
  * F.normalize(x) @ F.normalize(y).T (tests/integration_tests/test_text_sonar.py:42-53)
@@ -154,8 +222,10 @@ int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny
                   void* stream);
 
 /* Building blocks (exported for the parity tests and microbenchmarks) ------ */
-/* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi: 0 f16 out, 1 f16 ReLU out,
- * 2 fp32 residual accumulate (out += ...).  m%128==0, n%128==0, k%64==0. */
+/* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi & 0xff: 0 f16 out, 1 f16 ReLU out,
+ * 2 fp32 residual accumulate (out += ...), 3 fp32 store (bias may be NULL);
+ * epi >> 8 selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0).
+ * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out_f16,

@@ -79,6 +79,61 @@ class smi_text_encoder_weights(C.Structure):
     ]
 
 
+class smi_text_decoder_config(C.Structure):
+    _fields_ = [
+        ("model_dim", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("ffn_inner_dim", C.c_int32),
+        ("vocab_size", C.c_int64),
+        ("max_seq_len", C.c_int32),
+        ("pos_offset", C.c_int32),
+        ("input_dim", C.c_int32),
+        ("embed_scale", C.c_float),
+        ("ln_eps", C.c_float),
+        ("pad_idx", C.c_int32),
+        ("unk_idx", C.c_int32),
+        ("bos_idx", C.c_int32),
+        ("eos_idx", C.c_int32),
+    ]
+
+
+_DEC_LAYER_FIELDS = [
+    "self_attn_layer_norm_w", "self_attn_layer_norm_b",
+    "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "out_w", "out_b",
+    "cross_v_w", "cross_v_b", "cross_out_w", "cross_out_b",
+    "ffn_layer_norm_w", "ffn_layer_norm_b",
+    "ffn_inner_w", "ffn_inner_b", "ffn_out_w", "ffn_out_b",
+]
+
+
+class smi_text_decoder_layer(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in _DEC_LAYER_FIELDS]
+
+
+class smi_text_decoder_weights(C.Structure):
+    _fields_ = [
+        ("embed", smi_tensor),
+        ("pos_table", smi_tensor),
+        ("final_layer_norm_w", smi_tensor),
+        ("final_layer_norm_b", smi_tensor),
+        ("layers", C.POINTER(smi_text_decoder_layer)),
+    ]
+
+
+class smi_beam_search_params(C.Structure):
+    _fields_ = [
+        ("beam_size", C.c_int32),
+        ("max_seq_len", C.c_int32),
+        ("min_seq_len", C.c_int32),
+        ("normalize_scores", C.c_int32),
+        ("len_penalty", C.c_float),
+        ("unk_penalty", C.c_float),
+        ("temperature", C.c_float),
+        ("reserved", C.c_int32),
+    ]
+
+
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -94,6 +149,12 @@ SYMBOLS = {
     "smi_text_encoder_device_bytes": (_i64, [_vp]),
     "smi_text_encoder_set_profiling": (C.c_int, [_vp, _i32]),
     "smi_text_encoder_read_profile": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "smi_text_decoder_create": (C.c_int, [C.POINTER(smi_text_decoder_config),
+                                          C.POINTER(smi_text_decoder_weights), C.POINTER(_vp)]),
+    "smi_text_decoder_destroy": (None, [_vp]),
+    "smi_text_decoder_logits": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "smi_text_decoder_generate": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
+                                            C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
     "smi_xsim_padded_rows": (_i64, [_i64]),
     "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),

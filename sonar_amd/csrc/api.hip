@@ -12,62 +12,19 @@
 #include <string>
 #include <vector>
 
-#include "../../include/sonar_mi355.h"
-#include "kernels.hpp"
+#include "api_common.hpp"
 
 using namespace smi;
 
-namespace {
+namespace smi_host {
 
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
+std::string& last_error() {
+  thread_local std::string err;
+  return err;
 }
 
-#define HIP_TRY(expr)                                                                      \
-  do {                                                                                     \
-    hipError_t _e = (expr);                                                                \
-    if (_e != hipSuccess)                                                                  \
-      return fail(_e == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "%s failed: %s",  \
-                  #expr, hipGetErrorString(_e));                                           \
-  } while (0)
-
-bool have_device() {
-  int n = 0;
-  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
-}
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-  hipError_t alloc(size_t n) {
-    release();
-    if (n == 0) return hipSuccess;
-    hipError_t e = hipMalloc(&p, n);
-    if (e == hipSuccess) bytes = n;
-    return e;
-  }
-  template <typename T>
-  T* as() const {
-    return (T*)p;
-  }
-};
-
-// Copy a caller tensor into a freshly allocated device buffer as fp16 or fp32.
-int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst, const char* name) {
+int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst, const char* name,
+           int64_t pad_numel) {
   if (!t.data) return fail(SMI_ERR_INVALID_ARG, "weight %s: null data", name);
   if (t.numel != expect_numel)
     return fail(SMI_ERR_INVALID_ARG, "weight %s: numel %lld, expected %lld", name,
@@ -75,9 +32,11 @@ int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst
   if (t.dtype != SMI_F32 && t.dtype != SMI_F16)
     return fail(SMI_ERR_INVALID_ARG, "weight %s: bad dtype %d", name, t.dtype);
   const size_t n = (size_t)t.numel;
+  const size_t total = std::max<size_t>(n, (size_t)pad_numel);
   const size_t src_es = t.dtype == SMI_F32 ? 4 : 2;
   const size_t dst_es = want_f16 ? 2 : 4;
-  HIP_TRY(dst.alloc(n * dst_es));
+  HIP_TRY(dst.alloc(total * dst_es));
+  if (total > n) HIP_TRY(hipMemset((char*)dst.p + n * dst_es, 0, (total - n) * dst_es));
   const bool same = (t.dtype == SMI_F16) == want_f16;
   const hipMemcpyKind kind = t.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   if (same) {
@@ -103,6 +62,12 @@ int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst
   }
   return SMI_OK;
 }
+
+}  // namespace smi_host
+
+using namespace smi_host;
+
+namespace {
 
 struct Layer {
   DevBuf ln1_w, ln1_b, w_qkv, b_qkv, w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2;
@@ -225,7 +190,7 @@ int check_cfg(const smi_text_encoder_config& c) {
 extern "C" {
 
 const char* smi_version(void) { return "sonar_mi355 0.1.0 (gfx950)"; }
-const char* smi_last_error(void) { return g_err.c_str(); }
+const char* smi_last_error(void) { return smi_host::last_error().c_str(); }
 
 int smi_device_count(void) {
   int n = 0;
@@ -453,8 +418,9 @@ int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_
 // -------------------------------------------------------- building blocks
 int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, void* out, int32_t m,
                 int32_t n, int32_t k, int32_t ldo, void* stream) {
-  if (!x || !w || !bias || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
-  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || epi < 0 || epi > 2 || ldo < n)
+  if (!x || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || (epi & 0xff) > 3 || (epi >> 8) > 2 ||
+      epi < 0 || ldo < n || ((epi >> 8) == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));

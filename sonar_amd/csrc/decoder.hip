@@ -1,0 +1,696 @@
+// Device side of the EmbeddingToText hot path: one incremental decoder step and the
+// beam-search bookkeeping, all on the GPU (no host round trip per step, no KV-cache copy).
+//
+// Reference behaviour restated here:
+//  * decoder frontend / layer / final LN / tied projection:
+//      sonar/models/sonar_text/factory.py:229-315, sonar/nn/conditional_decoder_model.py:66-94
+//  * the sentence embedding is a length-1 encoder output
+//      (sonar/models/sonar_translation/model.py:48-53): the cross-attention softmax is 1,
+//      so cross_attn(x) = W_o (W_v e + b_v) + b_o, a per-sentence per-layer constant that is
+//      precomputed once per generate() call (the reference recomputes q/k/softmax every step);
+//  * beam search: fairseq2 ~=0.4 BeamSearchSeq2SeqGenerator + StandardBeamSearchAlgorithm
+//      (SURVEY a24): fp32 log-softmax, PAD never, EOS blocked below min length and forced at
+//      max length, top-(2*beam) over beam x vocab, EOS candidates among the first `beam`
+//      finish (score / (len-1)^len_penalty), the rest continue.
+//
+// Beam re-indexing: every step's fused q|k|v GEMM output IS the cache slab of that position
+// (kv[layer][pos][row][3d]); a hypothesis is an ancestry table anc[row][pos] -> row slot that
+// produced that position.  Reordering beams copies 4 B per (row, pos) instead of 4 KB per
+// (row, pos, layer) -- fairseq2's index_select on the whole cache is ~7 GB/step at t = 64.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace smi {
+
+// ------------------------------------------------------------- embed one position
+// x[r,:] = E[tok[r]] * scale + PE[pos + off]; one wave per row.
+__global__ __launch_bounds__(256) void dec_embed_kernel(const int32_t* __restrict__ tok,
+                                                        const f16* __restrict__ table,
+                                                        const float* __restrict__ pe_row, float scale,
+                                                        float* __restrict__ x, int rows, int d,
+                                                        int64_t vocab) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  int64_t t = tok[r];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const f16* e = table + (size_t)t * d;
+  float* o = x + (size_t)r * d;
+  for (int c = lane * 8; c < d; c += 512) {
+    const half8 ev = *(const half8*)(e + c);
+    const f32x4 p0 = *(const f32x4*)(pe_row + c);
+    const f32x4 p1 = *(const f32x4*)(pe_row + c + 4);
+    f32x4 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o0[i] = (float)(f16)((float)ev[i] * scale) + p0[i];
+      o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
+    }
+    *(f32x4*)(o + c) = o0;
+    *(f32x4*)(o + c + 4) = o1;
+  }
+}
+
+hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* pe_row, float scale,
+                            float* x, int rows, int d, int64_t vocab, hipStream_t stream) {
+  hipLaunchKernelGGL(dec_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, tok, table, pe_row,
+                     scale, x, rows, d, vocab);
+  return hipGetLastError();
+}
+
+// ------------------------------------------- x += c[row / group]; h = LN(x)  (fused)
+template <int NV>
+__global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const float* __restrict__ c,
+                                                     int group, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float eps,
+                                                     f16* __restrict__ h, int rows) {
+  constexpr int D = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* xr = x + (size_t)r * D;
+  const float* cr = c + (size_t)(r / group) * D;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4) + *(const f32x4*)(cr + k * 256 + lane * 4);
+    *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  constexpr float inv_d = 1.0f / D;
+  const float mean = wave_sum(s) * inv_d;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = v[k][i] - mean;
+      v[k][i] = t;
+      q += t * t;
+    }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const f32x4 wv = *(const f32x4*)(w + k * 256 + lane * 4);
+    const f32x4 bv = *(const f32x4*)(b + k * 256 + lane * 4);
+    half4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f16)(v[k][i] * rstd * wv[i] + bv[i]);
+    *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+  }
+}
+
+hipError_t launch_add_layernorm(float* x, const float* c, int group, const float* w, const float* b,
+                                float eps, f16* h, int rows, int d, hipStream_t stream) {
+  const int blocks = (rows + 3) / 4;
+#define SMI_AL_CASE(NV)                                                                          \
+  case NV * 256:                                                                                 \
+    hipLaunchKernelGGL(add_ln_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, c, group, w, b, \
+                       eps, h, rows);                                                            \
+    break;
+  switch (d) {
+    SMI_AL_CASE(1)
+    SMI_AL_CASE(2)
+    SMI_AL_CASE(3)
+    SMI_AL_CASE(4)
+    SMI_AL_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef SMI_AL_CASE
+  return hipGetLastError();
+}
+
+// -------------------------------------------------- single-query (decode) attention
+// One wave per (row, head).  kv: [pos][rows_pad][3d] (q|k|v), anc: [rows][anc_stride].
+// QK^T: lane j owns position j (128-B contiguous K row per lane); softmax across lanes;
+// PV: lane owns one of the 64 head dims, positions are broadcast with readlane-style shuffles.
+__global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restrict__ kv,
+                                                            const int32_t* __restrict__ anc,
+                                                            int anc_stride, f16* __restrict__ ctx,
+                                                            int rows, int rows_pad, int d, int heads,
+                                                            int pos, float sl2e) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= rows * heads) return;
+  const int r = wid / heads, h = wid % heads;
+  const int lane = threadIdx.x & 63;
+  const size_t ld = (size_t)3 * d;
+  const size_t slab = (size_t)rows_pad * ld;
+  const f16* qp = kv + (size_t)pos * slab + (size_t)r * ld + h * 64;
+  half8 q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) q[i] = *(const half8*)(qp + i * 8);
+
+  const int32_t* ar = anc + (size_t)r * anc_stride;
+  float m = -1e30f, l = 0.f, o = 0.f;  // o: this lane's head-dim accumulator
+  for (int j0 = 0; j0 <= pos; j0 += 64) {
+    const int j = j0 + lane;
+    float s = -INFINITY;
+    int src = 0;
+    if (j <= pos) {
+      src = j == pos ? r : ar[j];
+      const f16* kp = kv + (size_t)j * slab + (size_t)src * ld + d + h * 64;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const half8 kk = *(const half8*)(kp + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)q[i][e] * (float)kk[e];
+      }
+      s = acc * sl2e;
+    }
+    const float mx = wave_max(s);
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    const float p = __builtin_amdgcn_exp2f(s - m_new);  // 0 for masked lanes
+    l = l * alpha + wave_sum(p);
+    o *= alpha;
+    m = m_new;
+    const int cnt = min(64, pos + 1 - j0);
+    for (int t = 0; t < cnt; ++t) {
+      const float pt = __shfl(p, t, 64);
+      const int st = __shfl(src, t, 64);
+      const f16* vp = kv + (size_t)(j0 + t) * slab + (size_t)st * ld + 2 * d + h * 64;
+      o += pt * (float)vp[lane];
+    }
+  }
+  ctx[(size_t)r * d + h * 64 + lane] = (f16)(o / l);
+}
+
+hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
+                                int rows_pad, int d, int heads, int pos, hipStream_t stream) {
+  const float sl2e = 0.125f * 1.4426950408889634f;
+  const int waves = rows * heads;
+  hipLaunchKernelGGL(dec_attention_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, kv, anc,
+                     anc_stride, ctx, rows, rows_pad, d, heads, pos, sl2e);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------- vocabulary scan (per row, per chunk)
+// For logits[row][c0 .. c0+4096): chunk max, sum exp(x - max) and the top-K2 entries by
+// value among tokens that may be generated (PAD excluded; EOS excluded when blocked).
+constexpr int VS_CHUNK = 4096;
+constexpr int VS_K2MAX = 16;
+
+__device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) {
+  return a > b || (a == b && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void vocab_scan_kernel(const float* __restrict__ logits, int ldl,
+                                                         int vocab, int k2, float inv_temp,
+                                                         int pad_idx, int eos_idx, int unk_idx,
+                                                         float unk_penalty, int block_eos,
+                                                         float* __restrict__ pmax,
+                                                         float* __restrict__ psum,
+                                                         float* __restrict__ pval,
+                                                         int* __restrict__ pidx, int nchunks) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_red[4];
+  const int row = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c0 = chunk * VS_CHUNK;
+  const float* lp = logits + (size_t)row * ldl + c0;
+  float v[16];
+  int id[16];
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int off = k * 1024 + tid * 4;
+    f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (c0 + off + 3 < vocab) {
+      x = *(const f32x4*)(lp + off);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + off + e < vocab) x[e] = lp[off + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k * 4 + e] = x[e] * inv_temp;
+      id[k * 4 + e] = c0 + off + e;
+      tmax = fmaxf(tmax, v[k * 4 + e]);
+    }
+  }
+  // chunk max / sum-exp over ALL vocabulary entries (softmax normaliser)
+  float wm = wave_max(tmax);
+  if (lane == 0) s_red[wv] = wm;
+  __syncthreads();
+  const float cmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) se += (v[k] == -INFINITY) ? 0.f : __expf(v[k] - cmax);
+  se = wave_sum(se);
+  __syncthreads();
+  if (lane == 0) s_red[wv] = se;
+  __syncthreads();
+  if (tid == 0) {
+    pmax[(size_t)row * nchunks + chunk] = cmax;
+    psum[(size_t)row * nchunks + chunk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+  }
+  // candidates: apply the generation masks (they act on log-probs AFTER the softmax)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (id[k] == pad_idx || (block_eos && id[k] == eos_idx) || id[k] >= vocab) v[k] = -INFINITY;
+    else if (id[k] == unk_idx) v[k] -= unk_penalty;
+  }
+  for (int round = 0; round < k2; ++round) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (cand_better(v[k], id[k], bv, bi)) {
+        bv = v[k];
+        bi = id[k];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (cand_better(ov, oi, bv, bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      s_val[wv] = bv;
+      s_idx[wv] = bi;
+    }
+    __syncthreads();
+    bv = s_val[0];
+    bi = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (cand_better(s_val[w], s_idx[w], bv, bi)) {
+        bv = s_val[w];
+        bi = s_idx[w];
+      }
+    if (tid == 0) {
+      pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bv;
+      pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bi;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (id[k] == bi) v[k] = -INFINITY;  // taken
+  }
+}
+
+hipError_t launch_vocab_scan(const float* logits, int ldl, int rows, int vocab, int k2, float inv_temp,
+                             int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int block_eos,
+                             float* pmax, float* psum, float* pval, int* pidx, hipStream_t stream) {
+  const int nchunks = (vocab + VS_CHUNK - 1) / VS_CHUNK;
+  hipLaunchKernelGGL(vocab_scan_kernel, dim3(nchunks, rows), dim3(256), 0, stream, logits, ldl, vocab,
+                     k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval,
+                     pidx, nchunks);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- beam step (per sentence)
+// One workgroup (256 threads) per sentence.  Merges the chunk partials of each live row,
+// forms the 2*beam best (row, token) continuations and applies the fairseq2 EOS rules.
+struct BeamState {
+  int32_t* tok;        // [R] token fed at the current position
+  float* cum;          // [R] cumulative log-prob
+  int32_t* nactive;    // [n] live rows of the sentence (1 until the first expansion)
+  int32_t* done;       // [n]
+  int32_t* ndone;      // [1]
+  int32_t* parent;     // [R] out: parent row (global slot) of the row's next state
+  int32_t* new_tok;    // [R] out
+  float* new_cum;      // [R] out
+  const int32_t* hist; // [R][hist_stride] tokens of every position <= pos
+  int32_t* fin_tok;    // [n][beam][hist_stride]
+  int32_t* fin_len;    // [n][beam]
+  float* fin_score;    // [n][beam]
+  int32_t* fin_count;  // [n]
+};
+
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logits,
+                                                        int ldl, const float* __restrict__ pmax,
+                                                        const float* __restrict__ psum,
+                                                        const float* __restrict__ pval,
+                                                        const int* __restrict__ pidx, int nchunks,
+                                                        int beam, int k2, int pos, int prompt_len,
+                                                        int forced_tok, int max_len, float inv_temp,
+                                                        float len_penalty, int normalize, int eos_idx,
+                                                        int hist_stride) {
+  __shared__ float s_lse[8];
+  __shared__ float c_val[8 * VS_K2MAX];
+  __shared__ int c_tok[8 * VS_K2MAX];
+  __shared__ int c_row[8 * VS_K2MAX];
+  __shared__ float w_val[4];
+  __shared__ int w_slot[4];
+  __shared__ int f_row[8];
+  __shared__ float f_score[8];
+  __shared__ int f_n, f_base;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int base = s * beam;
+  const int step_nr = pos + 1;  // index of the token chosen now
+  if (st.done[s]) {  // keep the rows inert
+    if (tid < beam) {
+      st.parent[base + tid] = base + tid;
+      st.new_tok[base + tid] = st.tok[base + tid];
+      st.new_cum[base + tid] = st.cum[base + tid];
+    }
+    return;
+  }
+  const int na = st.nactive[s];
+  // (1) log-sum-exp of every live row
+  for (int r = wv; r < na; r += 4) {
+    const size_t o = (size_t)(base + r) * nchunks;
+    float m = -INFINITY;
+    for (int c = lane; c < nchunks; c += 64) m = fmaxf(m, pmax[o + c]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < nchunks; c += 64) sum += psum[o + c] * __expf(pmax[o + c] - m);
+    sum = wave_sum(sum);
+    if (lane == 0) s_lse[r] = m + __logf(sum);
+  }
+  __syncthreads();
+
+  const bool forced_prompt = step_nr < prompt_len;
+  const bool force_eos = !forced_prompt && step_nr == max_len - 1;
+  if (forced_prompt || force_eos) {
+    // candidate of every live row is one given token
+    if (tid < na) {
+      const int tk = forced_prompt ? forced_tok : eos_idx;
+      const float lp = logits[(size_t)(base + tid) * ldl + tk] * inv_temp - s_lse[tid];
+      c_val[tid] = st.cum[base + tid] + lp;
+      c_tok[tid] = tk;
+      c_row[tid] = base + tid;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (forced_prompt) {
+        for (int r = 0; r < beam; ++r) {
+          const bool live = r < na;
+          st.parent[base + r] = base + r;
+          st.new_tok[base + r] = live ? c_tok[r] : st.tok[base + r];
+          st.new_cum[base + r] = live ? c_val[r] : st.cum[base + r];
+        }
+        f_n = 0;
+      } else {
+        // sort the <= beam EOS candidates by score (desc, row asc) and finish them all
+        int order[8];
+        for (int r = 0; r < na; ++r) order[r] = r;
+        for (int a = 1; a < na; ++a)
+          for (int b = a; b > 0 && cand_better(c_val[order[b]], order[b], c_val[order[b - 1]], order[b - 1]); --b) {
+            const int t = order[b];
+            order[b] = order[b - 1];
+            order[b - 1] = t;
+          }
+        int cnt = st.fin_count[s];
+        f_base = cnt;
+        int nf = 0;
+        for (int a = 0; a < na && cnt < beam; ++a) {
+          f_row[nf] = c_row[order[a]];
+          f_score[nf] = c_val[order[a]];
+          ++nf;
+          ++cnt;
+        }
+        f_n = nf;
+        st.fin_count[s] = cnt;
+        st.done[s] = 1;  // nothing can continue past the maximum length
+        atomicAdd(st.ndone, 1);
+        for (int r = 0; r < beam; ++r) {
+          st.parent[base + r] = base + r;
+          st.new_tok[base + r] = st.tok[base + r];
+          st.new_cum[base + r] = st.cum[base + r];
+        }
+      }
+    }
+  } else {
+    // (2) per live row: best k2 tokens over its chunk partials (value desc, token asc)
+    for (int r = 0; r < na; ++r) {
+      const size_t o = (size_t)(base + r) * nchunks * VS_K2MAX;
+      const int total = nchunks * VS_K2MAX;
+      // each thread scans a strided subset; taken entries are tracked by (token) comparison
+      float last_v = INFINITY;
+      int last_i = -1;
+      for (int round = 0; round < k2; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int e = tid; e < total; e += 256) {
+          if ((e % VS_K2MAX) >= k2) continue;
+          const float v = pval[o + e];
+          const int i = pidx[o + e];
+          // strictly after the previous pick in the (value desc, token asc) order
+          if (!(v < last_v || (v == last_v && i > last_i))) continue;
+          if (cand_better(v, i, bv, bi)) {
+            bv = v;
+            bi = i;
+          }
+        }
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) {
+          const float ov = __shfl_xor(bv, of, 64);
+          const int oi = __shfl_xor(bi, of, 64);
+          if (cand_better(ov, oi, bv, bi)) {
+            bv = ov;
+            bi = oi;
+          }
+        }
+        __syncthreads();
+        if (lane == 0) {
+          w_val[wv] = bv;
+          w_slot[wv] = bi;
+        }
+        __syncthreads();
+        bv = w_val[0];
+        bi = w_slot[0];
+        for (int w = 1; w < 4; ++w)
+          if (cand_better(w_val[w], w_slot[w], bv, bi)) {
+            bv = w_val[w];
+            bi = w_slot[w];
+          }
+        last_v = bv;
+        last_i = bi;
+        if (tid == 0) {
+          c_val[r * VS_K2MAX + round] = bv == -INFINITY ? -INFINITY : st.cum[base + r] + bv - s_lse[r];
+          c_tok[r * VS_K2MAX + round] = bi;
+          c_row[r * VS_K2MAX + round] = base + r;
+        }
+      }
+    }
+    __syncthreads();
+    // (3) thread 0: overall top-k2 (score desc, flat index row*V+token asc) + EOS handling
+    if (tid == 0) {
+      float tv[VS_K2MAX];
+      int tt[VS_K2MAX], tr[VS_K2MAX];
+      bool used[8 * VS_K2MAX];
+      for (int i = 0; i < na * VS_K2MAX; ++i) used[i] = false;
+      int nsel = 0;
+      for (int sel = 0; sel < k2; ++sel) {
+        int best = -1;
+        for (int r = 0; r < na; ++r)
+          for (int q = 0; q < k2; ++q) {
+            const int i = r * VS_K2MAX + q;
+            if (used[i] || c_val[i] == -INFINITY) continue;
+            if (best < 0 || c_val[i] > c_val[best] ||
+                (c_val[i] == c_val[best] && (c_row[i] < c_row[best] || (c_row[i] == c_row[best] && c_tok[i] < c_tok[best]))))
+              best = i;
+          }
+        if (best < 0) break;
+        used[best] = true;
+        tv[nsel] = c_val[best];
+        tt[nsel] = c_tok[best];
+        tr[nsel] = c_row[best];
+        ++nsel;
+      }
+      int cnt = st.fin_count[s];
+      f_base = cnt;
+      int nf = 0;
+      bool finished_all = false;
+      for (int i = 0; i < nsel && i < beam; ++i) {
+        if (tt[i] == eos_idx) {
+          f_row[nf] = tr[i];
+          f_score[nf] = tv[i];
+          ++nf;
+          if (++cnt == beam) {
+            finished_all = true;
+            break;
+          }
+        }
+      }
+      f_n = nf;
+      st.fin_count[s] = cnt;
+      if (finished_all) {
+        st.done[s] = 1;
+        atomicAdd(st.ndone, 1);
+        for (int r = 0; r < beam; ++r) {
+          st.parent[base + r] = base + r;
+          st.new_tok[base + r] = st.tok[base + r];
+          st.new_cum[base + r] = st.cum[base + r];
+        }
+      } else {
+        int w = 0;
+        for (int i = 0; i < nsel && w < beam; ++i) {
+          if (tt[i] == eos_idx) continue;
+          st.parent[base + w] = tr[i];
+          st.new_tok[base + w] = tt[i];
+          st.new_cum[base + w] = tv[i];
+          ++w;
+        }
+        st.nactive[s] = w;
+        for (; w < beam; ++w) {  // unreachable with vocab > 2*beam; keep the slot inert
+          st.parent[base + w] = base + w;
+          st.new_tok[base + w] = st.tok[base + w];
+          st.new_cum[base + w] = -INFINITY;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // (4) copy out the hypotheses that finished at this step: generated tokens + EOS
+  const int nf = f_n;
+  for (int f = 0; f < nf; ++f) {
+    const int slot = f_base + f;
+    const int row = f_row[f];
+    const int glen = step_nr - prompt_len;  // generated tokens before the EOS
+    int32_t* dst = st.fin_tok + ((size_t)s * beam + slot) * hist_stride;
+    const int32_t* src = st.hist + (size_t)row * hist_stride + prompt_len;
+    for (int i = tid; i < glen; i += 256) dst[i] = src[i];
+    if (tid == 0) {
+      dst[glen] = eos_idx;
+      st.fin_len[s * beam + slot] = glen + 1;
+      const float seq_len = (float)(step_nr + 1);
+      st.fin_score[s * beam + slot] = normalize ? f_score[f] / __powf(seq_len - 1.f, len_penalty) : f_score[f];
+    }
+  }
+}
+
+hipError_t launch_beam_step(const BeamStepArgs& a, hipStream_t stream) {
+  BeamState st{a.tok, a.cum, a.nactive, a.done, a.ndone, a.parent, a.new_tok, a.new_cum,
+               a.hist, a.fin_tok, a.fin_len, a.fin_score, a.fin_count};
+  hipLaunchKernelGGL(beam_step_kernel, dim3(a.n), dim3(256), 0, stream, st, a.logits, a.ldl, a.pmax,
+                     a.psum, a.pval, a.pidx, a.nchunks, a.beam, a.k2, a.pos, a.prompt_len, a.forced_tok,
+                     a.max_len, a.inv_temp, a.len_penalty, a.normalize, a.eos_idx, a.hist_stride);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------ beam reorder
+// new_anc[r][j] = anc[parent[r]][j] (j < pos), new_anc[r][pos] = parent[r];
+// new_hist[r][j] = hist[parent[r]][j] (j <= pos), new_hist[r][pos+1] = new_tok[r];
+// tok/cum take their new values.
+__global__ __launch_bounds__(256) void beam_reorder_kernel(const int32_t* __restrict__ parent,
+                                                           const int32_t* __restrict__ new_tok,
+                                                           const float* __restrict__ new_cum,
+                                                           const int32_t* __restrict__ anc,
+                                                           int32_t* __restrict__ anc2,
+                                                           const int32_t* __restrict__ hist,
+                                                           int32_t* __restrict__ hist2,
+                                                           int32_t* __restrict__ tok,
+                                                           float* __restrict__ cum, int stride,
+                                                           int pos) {
+  const int r = blockIdx.x;
+  const int p = parent[r];
+  for (int j = threadIdx.x; j <= pos; j += 256) {
+    anc2[(size_t)r * stride + j] = j == pos ? p : anc[(size_t)p * stride + j];
+    hist2[(size_t)r * stride + j] = hist[(size_t)p * stride + j];
+  }
+  if (threadIdx.x == 0) {
+    hist2[(size_t)r * stride + pos + 1] = new_tok[r];
+    tok[r] = new_tok[r];
+    cum[r] = new_cum[r];
+  }
+}
+
+hipError_t launch_beam_reorder(const int32_t* parent, const int32_t* new_tok, const float* new_cum,
+                               const int32_t* anc, int32_t* anc2, const int32_t* hist, int32_t* hist2,
+                               int32_t* tok, float* cum, int rows, int stride, int pos,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL(beam_reorder_kernel, dim3(rows), dim3(256), 0, stream, parent, new_tok, new_cum,
+                     anc, anc2, hist, hist2, tok, cum, stride, pos);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- small helpers
+__global__ void beam_init_kernel(int32_t* tok, float* cum, int32_t* nactive, int32_t* done,
+                                 int32_t* ndone, int32_t* fin_count, int32_t* hist, int32_t* anc,
+                                 int rows, int n, int stride, int first_tok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) {
+    tok[i] = first_tok;
+    cum[i] = 0.f;
+    hist[(size_t)i * stride] = first_tok;
+    anc[(size_t)i * stride] = i;
+  }
+  if (i < n) {
+    nactive[i] = 1;
+    done[i] = 0;
+    fin_count[i] = 0;
+  }
+  if (i == 0) *ndone = 0;
+}
+
+hipError_t launch_beam_init(int32_t* tok, float* cum, int32_t* nactive, int32_t* done, int32_t* ndone,
+                            int32_t* fin_count, int32_t* hist, int32_t* anc, int rows, int n, int stride,
+                            int first_tok, hipStream_t stream) {
+  const int total = rows > n ? rows : n;
+  hipLaunchKernelGGL(beam_init_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tok, cum, nactive,
+                     done, ndone, fin_count, hist, anc, rows, n, stride, first_tok);
+  return hipGetLastError();
+}
+
+// finished hypotheses of each sentence sorted best first -> caller buffers
+__global__ void beam_output_kernel(const int32_t* __restrict__ fin_tok, const int32_t* __restrict__ fin_len,
+                                   const float* __restrict__ fin_score, const int32_t* __restrict__ fin_count,
+                                   int beam, int stride, int out_stride, int32_t* __restrict__ out_tok,
+                                   int32_t* __restrict__ out_len, float* __restrict__ out_score) {
+  __shared__ int order[8];
+  const int s = blockIdx.x;
+  const int cnt = fin_count[s];
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < cnt; ++i) order[i] = i;
+    for (int a = 1; a < cnt; ++a)  // stable insertion sort, score descending
+      for (int b = a; b > 0 && fin_score[s * beam + order[b]] > fin_score[s * beam + order[b - 1]]; --b) {
+        const int t = order[b];
+        order[b] = order[b - 1];
+        order[b - 1] = t;
+      }
+  }
+  __syncthreads();
+  for (int h = 0; h < beam; ++h) {
+    int32_t* dst = out_tok + ((size_t)s * beam + h) * out_stride;
+    if (h < cnt) {
+      const int src = order[h];
+      const int len = fin_len[s * beam + src];
+      for (int i = threadIdx.x; i < out_stride; i += blockDim.x)
+        dst[i] = i < len ? fin_tok[((size_t)s * beam + src) * stride + i] : -1;
+      if (threadIdx.x == 0) {
+        out_len[s * beam + h] = len;
+        out_score[s * beam + h] = fin_score[s * beam + src];
+      }
+    } else {
+      for (int i = threadIdx.x; i < out_stride; i += blockDim.x) dst[i] = -1;
+      if (threadIdx.x == 0) {
+        out_len[s * beam + h] = 0;
+        out_score[s * beam + h] = -INFINITY;
+      }
+    }
+  }
+}
+
+hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, const float* fin_score,
+                              const int32_t* fin_count, int n, int beam, int stride, int out_stride,
+                              int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream) {
+  hipLaunchKernelGGL(beam_output_kernel, dim3(n), dim3(128), 0, stream, fin_tok, fin_len, fin_score,
+                     fin_count, beam, stride, out_stride, out_tok, out_len, out_score);
+  return hipGetLastError();
+}
+
+// tok[r] = (int32) src[r * src_stride + col]   (teacher forcing in smi_text_decoder_logits)
+__global__ void gather_tokens_kernel(const int64_t* __restrict__ src, int src_stride, int col,
+                                     int32_t* __restrict__ tok, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) tok[i] = (int32_t)src[(size_t)i * src_stride + col];
+}
+
+hipError_t launch_gather_tokens(const int64_t* src, int src_stride, int col, int32_t* tok, int rows,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL(gather_tokens_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, src,
+                     src_stride, col, tok, rows);
+  return hipGetLastError();
+}
+
+}  // namespace smi

@@ -1,0 +1,348 @@
+// C-ABI implementation of the text decoder / beam search (see include/sonar_mi355.h).
+// Host runtime: weight packing, workspace, and the per-step launch schedule
+// (reference op order: sonar/models/sonar_text/factory.py:261-307, pre-LN decoder layers,
+// final LayerNorm, tied projection; generation control: fairseq2 BeamSearchSeq2SeqGenerator).
+#include <cmath>
+#include <vector>
+
+#include "api_common.hpp"
+
+using namespace smi;
+using namespace smi_host;
+
+namespace {
+
+struct DecLayer {
+  DevBuf ln1_w, ln1_b, w_qkv, b_qkv, w_o, b_o;
+  DevBuf wc_v, bc_v, wc_o, bc_o;  // encoder_decoder_attn value / output projections
+  DevBuf ln3_w, ln3_b, w_1, b_1, w_2, b_2;
+};
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct smi_text_decoder {
+  smi_text_decoder_config cfg;
+  int64_t vocab_pad = 0;
+  DevBuf embed, pos, lnf_w, lnf_b;
+  std::vector<DecLayer> layers;
+  // per-call workspace (grow-only)
+  DevBuf x, h, ctx, ffn, logits, kv, cc, cvtmp, emb16;
+  DevBuf tok, cum, parent, new_tok, new_cum, nactive, done, ndone, fin_count, fin_len, fin_score, fin_tok;
+  DevBuf anc[2], hist[2];
+  DevBuf pmax, psum, pval, pidx;
+  DevBuf zero_cc;
+  int64_t weight_bytes = 0;
+  int kv_positions = 0;  // positions per layer in the current kv allocation
+};
+
+namespace {
+
+int check_dec_cfg(const smi_text_decoder_config& c) {
+  if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
+    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must equal num_heads %d * 64", c.model_dim, c.num_heads);
+  if (c.model_dim % 256 || (c.model_dim / 256 > 4 && c.model_dim != 2048))
+    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must be 256/512/768/1024/2048", c.model_dim);
+  if (c.ffn_inner_dim <= 0 || c.ffn_inner_dim % 128)
+    return fail(SMI_ERR_UNSUPPORTED, "ffn_inner_dim %d must be a multiple of 128", c.ffn_inner_dim);
+  if (c.num_layers < 0 || c.vocab_size <= 16 || c.max_seq_len <= 1 || c.pos_offset < 0)
+    return fail(SMI_ERR_INVALID_ARG, "bad num_layers/vocab_size/max_seq_len/pos_offset");
+  if (c.input_dim != c.model_dim)
+    return fail(SMI_ERR_UNSUPPORTED, "input_dim %d != model_dim %d is not covered", c.input_dim, c.model_dim);
+  return SMI_OK;
+}
+
+// per-sentence cross-attention constants cc[l][s] = W_o (W_v e_s + b_v) + b_o  (fp32 [L][n_pad][d])
+int compute_cross_constants(smi_text_decoder* D, const void* emb, int emb_dtype, int n, int n_pad,
+                            hipStream_t stream) {
+  const int d = D->cfg.model_dim;
+  HIP_TRY(D->emb16.reserve((size_t)n_pad * d * 2));
+  HIP_TRY(D->cvtmp.reserve((size_t)n_pad * d * 2));
+  HIP_TRY(D->cc.reserve((size_t)D->cfg.num_layers * n_pad * d * 4));
+  HIP_TRY(hipMemsetAsync(D->emb16.p, 0, (size_t)n_pad * d * 2, stream));
+  if (emb_dtype == SMI_F32)
+    HIP_TRY(launch_f32_to_f16((const float*)emb, D->emb16.as<f16>(), (size_t)n * d, stream));
+  else
+    HIP_TRY(hipMemcpyAsync(D->emb16.p, emb, (size_t)n * d * 2, hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D->cc.p, 0, (size_t)D->cfg.num_layers * n_pad * d * 4, stream));
+  for (int l = 0; l < D->cfg.num_layers; ++l) {
+    DecLayer& L = D->layers[l];
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, D->emb16.as<f16>(), L.wc_v.as<f16>(), L.bc_v.as<float>(),
+                           D->cvtmp.p, n_pad, d, d, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, D->cvtmp.as<f16>(), L.wc_o.as<f16>(), L.bc_o.as<float>(),
+                           D->cc.as<float>() + (size_t)l * n_pad * d, n_pad, d, d, d, stream));
+  }
+  return SMI_OK;
+}
+
+// one decoder step at position `pos` for `rows` rows (rows_pad GEMM rows); logits -> D->logits
+int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_pad, int pos,
+                 const int32_t* anc, int anc_stride, hipStream_t stream) {
+  const smi_text_decoder_config& c = D->cfg;
+  const int d = c.model_dim, f = c.ffn_inner_dim;
+  float* x = D->x.as<float>();
+  f16* h = D->h.as<f16>();
+  f16* ctx = D->ctx.as<f16>();
+  f16* ffn = D->ffn.as<f16>();
+  const size_t slab = (size_t)rows_pad * 3 * d;  // elements per (layer, pos)
+  const int P = D->kv_positions;
+  HIP_TRY(launch_dec_embed(D->tok.as<int32_t>(), D->embed.as<f16>(),
+                           D->pos.as<float>() + (size_t)(pos + c.pos_offset) * d, c.embed_scale, x, rows, d,
+                           c.vocab_size, stream));
+  for (int l = 0; l < c.num_layers; ++l) {
+    DecLayer& L = D->layers[l];
+    f16* kvl = D->kv.as<f16>() + (size_t)l * P * slab;
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
+                           rows_pad, 3 * d, d, 3 * d, stream));
+    HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, rows_pad, d, d, d, stream));
+    HIP_TRY(launch_add_layernorm(x, D->cc.as<float>() + (size_t)l * n_pad * d, group, L.ln3_w.as<float>(),
+                                 L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, rows_pad, d, f, d, stream));
+  }
+  HIP_TRY(launch_layernorm(x, D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+  HIP_TRY(launch_gemm_tn(EPI_STORE_F32, h, D->embed.as<f16>(), nullptr, D->logits.p, rows_pad, (int)D->vocab_pad, d,
+                         (int)D->vocab_pad, stream));
+  return SMI_OK;
+}
+
+int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
+  const smi_text_decoder_config& c = D->cfg;
+  const size_t d = c.model_dim, f = c.ffn_inner_dim;
+  const size_t before = D->x.bytes + D->h.bytes + D->ctx.bytes + D->ffn.bytes;
+  HIP_TRY(D->x.reserve((size_t)rows_pad * d * 4));
+  HIP_TRY(D->h.reserve((size_t)rows_pad * d * 2));
+  HIP_TRY(D->ctx.reserve((size_t)rows_pad * d * 2));
+  HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * 2));
+  HIP_TRY(D->logits.reserve((size_t)rows_pad * D->vocab_pad * 4));
+  // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM)
+  HIP_TRY(D->kv.reserve((size_t)c.num_layers * positions * rows_pad * 3 * d * 2));
+  D->kv_positions = positions;
+  if (D->x.bytes + D->h.bytes + D->ctx.bytes + D->ffn.bytes != before) {
+    // tile-padding rows are read by the GEMMs: keep them finite
+    HIP_TRY(hipMemset(D->x.p, 0, D->x.bytes));
+    HIP_TRY(hipMemset(D->h.p, 0, D->h.bytes));
+    HIP_TRY(hipMemset(D->ctx.p, 0, D->ctx.bytes));
+    HIP_TRY(hipMemset(D->ffn.p, 0, D->ffn.bytes));
+  }
+  return SMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_decoder_weights* w,
+                            smi_text_decoder** out) {
+  if (!cfg || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (int rc = check_dec_cfg(*cfg)) return rc;
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  if (cfg->num_layers > 0 && !w->layers) return fail(SMI_ERR_INVALID_ARG, "null layers");
+  smi_text_decoder* D = new smi_text_decoder();
+  D->cfg = *cfg;
+  D->vocab_pad = round_up(cfg->vocab_size, 256);
+  const int64_t d = cfg->model_dim, f = cfg->ffn_inner_dim;
+  int rc = SMI_OK;
+  auto up = [&](const smi_tensor& t, int64_t numel, bool f16w, DevBuf& dst, const char* name, int64_t pad = 0) {
+    if (rc == SMI_OK) rc = upload(t, numel, f16w, dst, name, pad);
+  };
+  // the tied output projection multiplies by the embedding table: pad it to 256-row tiles
+  up(w->embed, cfg->vocab_size * d, true, D->embed, "decoder_frontend.embed.weight", D->vocab_pad * d);
+  up(w->pos_table, (int64_t)(cfg->max_seq_len + cfg->pos_offset) * d, false, D->pos, "pos_table");
+  up(w->final_layer_norm_w, d, false, D->lnf_w, "decoder.layer_norm.weight");
+  up(w->final_layer_norm_b, d, false, D->lnf_b, "decoder.layer_norm.bias");
+  D->layers.resize(cfg->num_layers);
+  for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
+    const smi_text_decoder_layer& s = w->layers[l];
+    DecLayer& L = D->layers[l];
+    up(s.self_attn_layer_norm_w, d, false, L.ln1_w, "self_attn_layer_norm.weight");
+    up(s.self_attn_layer_norm_b, d, false, L.ln1_b, "self_attn_layer_norm.bias");
+    up(s.ffn_layer_norm_w, d, false, L.ln3_w, "ffn_layer_norm.weight");
+    up(s.ffn_layer_norm_b, d, false, L.ln3_b, "ffn_layer_norm.bias");
+    up(s.out_w, d * d, true, L.w_o, "self_attn.output_proj.weight");
+    up(s.out_b, d, false, L.b_o, "self_attn.output_proj.bias");
+    up(s.cross_v_w, d * d, true, L.wc_v, "encoder_decoder_attn.v_proj.weight");
+    up(s.cross_v_b, d, false, L.bc_v, "encoder_decoder_attn.v_proj.bias");
+    up(s.cross_out_w, d * d, true, L.wc_o, "encoder_decoder_attn.output_proj.weight");
+    up(s.cross_out_b, d, false, L.bc_o, "encoder_decoder_attn.output_proj.bias");
+    up(s.ffn_inner_w, f * d, true, L.w_1, "ffn.inner_proj.weight");
+    up(s.ffn_inner_b, f, false, L.b_1, "ffn.inner_proj.bias");
+    up(s.ffn_out_w, d * f, true, L.w_2, "ffn.output_proj.weight");
+    up(s.ffn_out_b, d, false, L.b_2, "ffn.output_proj.bias");
+    if (rc == SMI_OK) {
+      DevBuf tq, tk, tv, bq, bk, bv;
+      up(s.q_w, d * d, true, tq, "self_attn.q_proj.weight");
+      up(s.k_w, d * d, true, tk, "self_attn.k_proj.weight");
+      up(s.v_w, d * d, true, tv, "self_attn.v_proj.weight");
+      up(s.q_b, d, false, bq, "self_attn.q_proj.bias");
+      up(s.k_b, d, false, bk, "self_attn.k_proj.bias");
+      up(s.v_b, d, false, bv, "self_attn.v_proj.bias");
+      if (rc == SMI_OK) {
+        hipError_t he = L.w_qkv.alloc((size_t)3 * d * d * 2);
+        if (he == hipSuccess) he = L.b_qkv.alloc((size_t)3 * d * 4);
+        const size_t wb = (size_t)d * d * 2, bb = (size_t)d * 4;
+        if (he == hipSuccess) he = hipMemcpy(L.w_qkv.p, tq.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + wb, tk.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + 2 * wb, tv.p, wb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy(L.b_qkv.p, bq.p, bb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.b_qkv.p + bb, bk.p, bb, hipMemcpyDeviceToDevice);
+        if (he == hipSuccess) he = hipMemcpy((char*)L.b_qkv.p + 2 * bb, bv.p, bb, hipMemcpyDeviceToDevice);
+        if (he != hipSuccess)
+          rc = fail(he == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "packing qkv: %s", hipGetErrorString(he));
+      }
+    }
+  }
+  if (rc != SMI_OK) {
+    delete D;
+    return rc;
+  }
+  D->weight_bytes = (int64_t)(D->embed.bytes + D->pos.bytes);
+  for (auto& L : D->layers)
+    D->weight_bytes += (int64_t)(L.w_qkv.bytes + L.w_o.bytes + L.wc_v.bytes + L.wc_o.bytes + L.w_1.bytes + L.w_2.bytes);
+  *out = D;
+  return SMI_OK;
+}
+
+void smi_text_decoder_destroy(smi_text_decoder* dec) {
+  if (!dec) return;
+  (void)hipDeviceSynchronize();
+  delete dec;
+}
+
+int smi_text_decoder_logits(smi_text_decoder* D, const void* emb, int32_t emb_dtype, int32_t n,
+                            const int64_t* prev_tokens, int32_t t, float* out_logits, void* stream_v) {
+  if (!D || !emb || !prev_tokens || !out_logits) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || t <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (t > D->cfg.max_seq_len) return fail(SMI_ERR_INVALID_ARG, "t=%d exceeds max_seq_len %d", t, D->cfg.max_seq_len);
+  if (emb_dtype != SMI_F32 && emb_dtype != SMI_F16) return fail(SMI_ERR_INVALID_ARG, "bad emb dtype");
+  hipStream_t stream = (hipStream_t)stream_v;
+  const int rows_pad = (int)round_up(n, 256), n_pad = rows_pad;
+  if (int rc = ensure_step_workspace(D, rows_pad, t)) return rc;
+  HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
+  // teacher forcing, one hypothesis per sentence: the ancestry is the identity and is never read
+  // for j < pos only through anc[r][j] = r
+  const int stride = D->cfg.max_seq_len + 1;
+  HIP_TRY(D->anc[0].reserve((size_t)rows_pad * stride * 4));
+  {
+    std::vector<int32_t> ident((size_t)n * stride);
+    for (int r = 0; r < n; ++r)
+      for (int j = 0; j < stride; ++j) ident[(size_t)r * stride + j] = r;
+    HIP_TRY(hipMemcpyAsync(D->anc[0].p, ident.data(), ident.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  if (int rc = compute_cross_constants(D, emb, emb_dtype, n, n_pad, stream)) return rc;
+  for (int pos = 0; pos < t; ++pos) {
+    HIP_TRY(launch_gather_tokens(prev_tokens, t, pos, D->tok.as<int32_t>(), n, stream));
+    if (int rc = decoder_step(D, n, rows_pad, 1, n_pad, pos, D->anc[0].as<int32_t>(), stride, stream)) return rc;
+    HIP_TRY(hipMemcpy2DAsync(out_logits + (size_t)pos * D->cfg.vocab_size, (size_t)t * D->cfg.vocab_size * 4,
+                             D->logits.p, (size_t)D->vocab_pad * 4, (size_t)D->cfg.vocab_size * 4, n,
+                             hipMemcpyDeviceToDevice, stream));
+  }
+  return SMI_OK;
+}
+
+int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_dtype, int32_t n,
+                              const int64_t* prompt, int32_t prompt_len, const smi_beam_search_params* bp,
+                              int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream_v) {
+  if (!D || !emb || !prompt || !bp || !out_tokens || !out_lens || !out_scores)
+    return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || prompt_len <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (emb_dtype != SMI_F32 && emb_dtype != SMI_F16) return fail(SMI_ERR_INVALID_ARG, "bad emb dtype");
+  const smi_text_decoder_config& c = D->cfg;
+  const int beam = bp->beam_size;
+  if (beam < 1 || beam > 8) return fail(SMI_ERR_UNSUPPORTED, "beam_size %d outside [1,8]", beam);
+  if (2 * beam >= c.vocab_size) return fail(SMI_ERR_UNSUPPORTED, "vocabulary too small for beam %d", beam);
+  const int max_len = bp->max_seq_len, min_len = bp->min_seq_len;
+  if (max_len > c.max_seq_len || max_len <= prompt_len)
+    return fail(SMI_ERR_INVALID_ARG, "max_seq_len %d must be in (prompt_len %d, model max %d]", max_len, prompt_len,
+                c.max_seq_len);
+  if (!(bp->temperature > 0.f)) return fail(SMI_ERR_INVALID_ARG, "temperature must be positive");
+  for (int i = 0; i < prompt_len; ++i)
+    if (prompt[i] < 0 || prompt[i] >= c.vocab_size) return fail(SMI_ERR_INVALID_ARG, "prompt token out of range");
+  hipStream_t stream = (hipStream_t)stream_v;
+
+  const int rows = n * beam;
+  const int rows_pad = (int)round_up(rows, 256), n_pad = (int)round_up(n, 256);
+  const int stride = c.max_seq_len + 1;
+  const int k2 = 2 * beam;
+  const int nchunks = (int)((c.vocab_size + kVocabScanChunk - 1) / kVocabScanChunk);
+  if (int rc = ensure_step_workspace(D, rows_pad, max_len)) return rc;
+  HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
+  HIP_TRY(D->cum.reserve((size_t)rows * 4));
+  HIP_TRY(D->parent.reserve((size_t)rows * 4));
+  HIP_TRY(D->new_tok.reserve((size_t)rows * 4));
+  HIP_TRY(D->new_cum.reserve((size_t)rows * 4));
+  HIP_TRY(D->nactive.reserve((size_t)n * 4));
+  HIP_TRY(D->done.reserve((size_t)n * 4));
+  HIP_TRY(D->ndone.reserve(4));
+  HIP_TRY(D->fin_count.reserve((size_t)n * 4));
+  HIP_TRY(D->fin_len.reserve((size_t)rows * 4));
+  HIP_TRY(D->fin_score.reserve((size_t)rows * 4));
+  HIP_TRY(D->fin_tok.reserve((size_t)rows * stride * 4));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(D->anc[i].reserve((size_t)rows_pad * stride * 4));
+    HIP_TRY(D->hist[i].reserve((size_t)rows_pad * stride * 4));
+  }
+  HIP_TRY(D->pmax.reserve((size_t)rows * nchunks * 4));
+  HIP_TRY(D->psum.reserve((size_t)rows * nchunks * 4));
+  HIP_TRY(D->pval.reserve((size_t)rows * nchunks * kVocabScanK2Max * 4));
+  HIP_TRY(D->pidx.reserve((size_t)rows * nchunks * kVocabScanK2Max * 4));
+
+  if (int rc = compute_cross_constants(D, emb, emb_dtype, n, n_pad, stream)) return rc;
+  HIP_TRY(launch_beam_init(D->tok.as<int32_t>(), D->cum.as<float>(), D->nactive.as<int32_t>(),
+                           D->done.as<int32_t>(), D->ndone.as<int32_t>(), D->fin_count.as<int32_t>(),
+                           D->hist[0].as<int32_t>(), D->anc[0].as<int32_t>(), rows, n, stride, (int)prompt[0], stream));
+  const float inv_temp = 1.0f / bp->temperature;
+  int cur = 0;
+  for (int pos = 0; pos + 1 < max_len; ++pos) {
+    const int step_nr = pos + 1;
+    if (int rc = decoder_step(D, rows, rows_pad, beam, n_pad, pos, D->anc[cur].as<int32_t>(), stride, stream)) return rc;
+    const bool forced_prompt = step_nr < prompt_len;
+    const bool force_eos = !forced_prompt && step_nr == max_len - 1;
+    if (!forced_prompt && !force_eos) {
+      HIP_TRY(launch_vocab_scan(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size, k2, inv_temp,
+                                c.pad_idx, c.eos_idx, c.unk_idx, bp->unk_penalty, step_nr < min_len ? 1 : 0,
+                                D->pmax.as<float>(), D->psum.as<float>(), D->pval.as<float>(), D->pidx.as<int>(), stream));
+    } else {
+      // only the softmax normaliser is needed (the candidate is a given token)
+      HIP_TRY(launch_vocab_scan(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size, 0, inv_temp,
+                                c.pad_idx, c.eos_idx, c.unk_idx, 0.f, 0, D->pmax.as<float>(), D->psum.as<float>(),
+                                D->pval.as<float>(), D->pidx.as<int>(), stream));
+    }
+    BeamStepArgs a{};
+    a.tok = D->tok.as<int32_t>(); a.cum = D->cum.as<float>(); a.nactive = D->nactive.as<int32_t>();
+    a.done = D->done.as<int32_t>(); a.ndone = D->ndone.as<int32_t>();
+    a.parent = D->parent.as<int32_t>(); a.new_tok = D->new_tok.as<int32_t>(); a.new_cum = D->new_cum.as<float>();
+    a.hist = D->hist[cur].as<int32_t>(); a.fin_tok = D->fin_tok.as<int32_t>(); a.fin_len = D->fin_len.as<int32_t>();
+    a.fin_score = D->fin_score.as<float>(); a.fin_count = D->fin_count.as<int32_t>();
+    a.logits = D->logits.as<float>(); a.ldl = (int)D->vocab_pad;
+    a.pmax = D->pmax.as<float>(); a.psum = D->psum.as<float>(); a.pval = D->pval.as<float>(); a.pidx = D->pidx.as<int>();
+    a.nchunks = nchunks; a.n = n; a.beam = beam; a.k2 = k2; a.pos = pos; a.prompt_len = prompt_len;
+    a.forced_tok = forced_prompt ? (int)prompt[step_nr] : -1; a.max_len = max_len;
+    a.inv_temp = inv_temp; a.len_penalty = bp->len_penalty; a.normalize = bp->normalize_scores;
+    a.eos_idx = c.eos_idx; a.hist_stride = stride;
+    HIP_TRY(launch_beam_step(a, stream));
+    HIP_TRY(launch_beam_reorder(D->parent.as<int32_t>(), D->new_tok.as<int32_t>(), D->new_cum.as<float>(),
+                                D->anc[cur].as<int32_t>(), D->anc[cur ^ 1].as<int32_t>(), D->hist[cur].as<int32_t>(),
+                                D->hist[cur ^ 1].as<int32_t>(), D->tok.as<int32_t>(), D->cum.as<float>(), rows, stride,
+                                pos, stream));
+    cur ^= 1;
+    // every 8 steps: has every sentence collected its `beam` hypotheses?
+    if ((step_nr & 7) == 0 || force_eos) {
+      int32_t nd = 0;
+      HIP_TRY(hipMemcpyAsync(&nd, D->ndone.p, 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (nd >= n) break;
+    }
+  }
+  HIP_TRY(launch_beam_output(D->fin_tok.as<int32_t>(), D->fin_len.as<int32_t>(), D->fin_score.as<float>(),
+                             D->fin_count.as<int32_t>(), n, beam, stride, max_len, out_tokens, out_lens, out_scores,
+                             stream));
+  return SMI_OK;
+}
+
+}  // extern "C"

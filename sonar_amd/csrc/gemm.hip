@@ -13,6 +13,7 @@ namespace smi {
 // EPI_BIAS_F16 : out_h[m][n]  = f16(acc + bias[n])
 // EPI_RELU_F16 : out_h[m][n]  = f16(max(acc + bias[n], 0))
 // EPI_RESID_F32: resid[m][n] += acc + bias[n]          (fp32 residual stream)
+// EPI_STORE_F32: out_f[m][n]  = acc (+ bias[n] if bias)  (fp32 logits)
 template <int EPI>
 __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int n = gt_col(n0, ni, q);
-      const f32x4 b = *(const f32x4*)(bias + n);
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (bias) b = *(const f32x4*)(bias + n);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int m = gt_row(m0, mi);
@@ -43,6 +45,8 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
           float* p = (float*)out + (size_t)m * ldo + n;
           f32x4 o = *(f32x4*)p;
           *(f32x4*)p = o + v;
+        } else if constexpr (EPI == EPI_STORE_F32) {
+          *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
         } else {
           if constexpr (EPI == EPI_RELU_F16) {
 #pragma unroll
@@ -79,14 +83,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
   constexpr int CS = G2_CSTRIDE;
-  if constexpr (EPI == EPI_RESID_F32) {
-    // fp32 residual accumulate, two passes of 128 columns (pass p = the waves' ni block)
+  if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+    // fp32 residual accumulate / fp32 store, two passes of 128 columns (pass p = the waves' ni block)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (p) __syncthreads();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(bias + g2_col(n0, p, q));
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = *(const f32x4*)(bias + g2_col(n0, p, q));
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           f32x4 v;
@@ -102,7 +107,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = wave * 32 + it * 2 + hi;
-        old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
+        if constexpr (EPI == EPI_RESID_F32)
+          old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
+        else
+          old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(bias + g2_col(n0, ni, q));
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = *(const f32x4*)(bias + g2_col(n0, ni, q));
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           half4 h;
@@ -195,15 +204,22 @@ static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_tn(int epi, const f16* X, const f16* W, const float* bias, void* out, int M,
-                          int N, int K, int ldo, hipStream_t stream) {
+hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out,
+                          int M, int N, int K, int ldo, hipStream_t stream) {
+  // epi_sel = epilogue | (kernel selector << 8): 0 auto, 1 force 128x128, 2 force 256x256
+  const int epi = epi_sel & 0xff, sel = epi_sel >> 8;
   if (M % GT_BM || N % GT_BN || K % GT_BK || M <= 0) return hipErrorInvalidValue;
-  static const int force128 = getenv("SMI_GEMM_FORCE128") ? atoi(getenv("SMI_GEMM_FORCE128")) : 0;
-  if (!force128 && M % G2_BM == 0 && N % G2_BN == 0) {
+  const bool can256 = M % G2_BM == 0 && N % G2_BN == 0;
+  if (sel == 2 && !can256) return hipErrorInvalidValue;
+  // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
+  // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
+  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
+  if (use256) {
     switch (epi) {
       case EPI_BIAS_F16: return launch_one256<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
       case EPI_RELU_F16: return launch_one256<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);
       case EPI_RESID_F32: return launch_one256<EPI_RESID_F32>(X, W, bias, out, M, N, K, ldo, stream);
+      case EPI_STORE_F32: return launch_one256<EPI_STORE_F32>(X, W, bias, out, M, N, K, ldo, stream);
     }
     return hipErrorInvalidValue;
   }
@@ -211,6 +227,7 @@ hipError_t launch_gemm_tn(int epi, const f16* X, const f16* W, const float* bias
     case EPI_BIAS_F16: return launch_one<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
     case EPI_RELU_F16: return launch_one<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);
     case EPI_RESID_F32: return launch_one<EPI_RESID_F32>(X, W, bias, out, M, N, K, ldo, stream);
+    case EPI_STORE_F32: return launch_one<EPI_STORE_F32>(X, W, bias, out, M, N, K, ldo, stream);
   }
   return hipErrorInvalidValue;
 }

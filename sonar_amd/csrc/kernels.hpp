@@ -8,10 +8,10 @@ namespace smi {
 
 typedef _Float16 f16;
 
-enum GemmEpilogue { EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2 };
+enum GemmEpilogue { EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3 };
 
 // C = X[M,K] * W[N,K]^T (+bias, epilogue).  M%128==0, N%128==0, K%64==0.
-hipError_t launch_gemm_tn(int epi, const f16* X, const f16* W, const float* bias, void* out, int M,
+hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
                           int N, int K, int ldo, hipStream_t stream);
 
 // x[row(n,p), :] = E[ids[n*S+p], :] * scale + PE[p + pos_offset, :]   (packed rows)
@@ -45,5 +45,40 @@ size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k);
 hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
                             int64_t ny_pad, int d, int k, int64_t y_index_offset, int32_t* idx,
                             float* score, void* workspace, hipStream_t stream);
+
+// ---- decoder / beam search (decoder.hip) ----
+hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* pe_row, float scale,
+                            float* x, int rows, int d, int64_t vocab, hipStream_t stream);
+hipError_t launch_add_layernorm(float* x, const float* c, int group, const float* w, const float* b,
+                                float eps, f16* h, int rows, int d, hipStream_t stream);
+hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
+                                int rows_pad, int d, int heads, int pos, hipStream_t stream);
+constexpr int kVocabScanChunk = 4096;
+constexpr int kVocabScanK2Max = 16;
+hipError_t launch_vocab_scan(const float* logits, int ldl, int rows, int vocab, int k2, float inv_temp,
+                             int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int block_eos,
+                             float* pmax, float* psum, float* pval, int* pidx, hipStream_t stream);
+struct BeamStepArgs {
+  int32_t* tok; float* cum; int32_t* nactive; int32_t* done; int32_t* ndone;
+  int32_t* parent; int32_t* new_tok; float* new_cum;
+  const int32_t* hist; int32_t* fin_tok; int32_t* fin_len; float* fin_score; int32_t* fin_count;
+  const float* logits; int ldl;
+  const float* pmax; const float* psum; const float* pval; const int* pidx; int nchunks;
+  int n, beam, k2, pos, prompt_len, forced_tok, max_len;
+  float inv_temp, len_penalty; int normalize, eos_idx, hist_stride;
+};
+hipError_t launch_beam_step(const BeamStepArgs& a, hipStream_t stream);
+hipError_t launch_beam_reorder(const int32_t* parent, const int32_t* new_tok, const float* new_cum,
+                               const int32_t* anc, int32_t* anc2, const int32_t* hist, int32_t* hist2,
+                               int32_t* tok, float* cum, int rows, int stride, int pos,
+                               hipStream_t stream);
+hipError_t launch_beam_init(int32_t* tok, float* cum, int32_t* nactive, int32_t* done, int32_t* ndone,
+                            int32_t* fin_count, int32_t* hist, int32_t* anc, int rows, int n, int stride,
+                            int first_tok, hipStream_t stream);
+hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, const float* fin_score,
+                              const int32_t* fin_count, int n, int beam, int stride, int out_stride,
+                              int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream);
+hipError_t launch_gather_tokens(const int64_t* src, int src_stride, int col, int32_t* tok, int rows,
+                                hipStream_t stream);
 
 }  // namespace smi

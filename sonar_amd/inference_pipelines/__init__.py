@@ -1,1 +1,1 @@
-from .text import TextToEmbeddingModelPipeline  # noqa: F401
+from .text import EmbeddingToTextModelPipeline, TextToEmbeddingModelPipeline  # noqa: F401

@@ -193,3 +193,48 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
             reversed_index = torch.argsort(sorting_index)
             sentence_embeddings = sentence_embeddings[reversed_index.to(sentence_embeddings.device)]
         return sentence_embeddings
+
+
+class EmbeddingToTextModelPipeline(torch.nn.Module):
+    """sonar/inference_pipelines/text.py:270-346 on the MI355X engine: embeddings -> texts by
+    beam search (fairseq2 BeamSearchSeq2SeqGenerator defaults; `generator_kwargs` accepts
+    beam_size, min_gen_len, max_gen_len, max_seq_len, normalize_scores, len_penalty,
+    unk_penalty, temperature).  Sampling generators are not covered."""
+
+    def __init__(self, decoder, tokenizer: Union[str, Path, NllbTokenizer], device: torch.device = CPU,
+                 dtype: Optional[torch.dtype] = None) -> None:
+        super().__init__()
+        from ..text_decoder import ConditionalTransformerDecoderModel, load_sonar_text_decoder
+
+        device = torch.device(device)
+        if isinstance(decoder, (str, Path)):
+            if device.type != "cuda":
+                raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
+            decoder = load_sonar_text_decoder(str(decoder), device=device, dtype=dtype or torch.float16)
+        if isinstance(tokenizer, (str, Path)):
+            tokenizer = NllbTokenizer(tokenizer)
+        self.tokenizer = tokenizer
+        self.model = decoder.eval()
+        self.device = getattr(decoder, "device", device)
+
+    @torch.inference_mode()
+    def predict(self, inputs: torch.Tensor, target_lang: str, batch_size: int = 5, progress_bar: bool = False,
+                sampler=None, **generator_kwargs) -> List[str]:
+        if sampler is not None:
+            raise NotImplementedError("sampling generators are not covered by the MI355X engine (beam search only)")
+        if batch_size <= 0:
+            raise ValueError("`batch_size` should be strictly positive")
+        prompt = self.tokenizer.create_encoder(task="translation", lang=target_lang, mode="target").prefix
+        decode = self.tokenizer.create_decoder()
+        rows = list(inputs)
+        batches: Iterable = [rows[i:i + batch_size] for i in range(0, len(rows), batch_size)]
+        if progress_bar:
+            batches = add_progress_bar(batches, inputs=rows, batch_size=batch_size)
+        texts: List[str] = []
+        for chunk in batches:
+            emb = torch.stack(chunk).to(self.device)
+            toks, lens, _ = self.model.engine.generate(emb, prompt, **generator_kwargs)
+            toks, lens = toks.cpu(), lens.cpu()
+            for i in range(emb.shape[0]):
+                texts.append(decode(toks[i, 0, : int(lens[i, 0])]))
+        return texts

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's SONAR text decoder objects, backed by the HIP
+engine (libsonar_mi355.so).
+
+Reference interfaces mirrored (paths relative to facebookresearch/SONAR):
+  * SonarTextDecoderConfig + archs `basic` / `small` / `toy`   sonar/models/sonar_text/config.py:130-255
+  * checkpoint key conversion                                   sonar/models/sonar_text/handler.py:122-172
+  * ConditionalTransformerDecoderModel / SonarEncoderDecoderModel
+        sonar/nn/conditional_decoder_model.py:26-94, sonar/models/sonar_translation/model.py:48-78
+  * BeamSearchSeq2SeqGenerator defaults (fairseq2 ~=0.4) -- run ON DEVICE here:
+    decoder step, fp32 log-softmax, top-2*beam selection, EOS bookkeeping and the beam
+    re-indexing of the KV cache (an ancestry table, no cache copy) are all engine kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import re
+from dataclasses import dataclass, field
+from typing import Dict, List, Mapping, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from .text_encoder import VocabularyInfo, _tensor_view, sinusoidal_table
+
+
+@dataclass
+class SonarTextDecoderConfig:
+    """Same fields as the reference dataclass (config.py:130-190)."""
+
+    model_dim: int = 1024
+    max_seq_len: int = 512
+    vocab_info: VocabularyInfo = field(default_factory=lambda: VocabularyInfo(size=256206))
+    num_encoder_layers: int = 24
+    num_decoder_layers: int = 24
+    num_encoder_attn_heads: int = 16
+    num_decoder_attn_heads: int = 16
+    ffn_inner_dim: int = 1024 * 8
+    activation_fn: str = "ReLU"
+    layernorm_embedding: bool = False
+    no_scale_embedding: bool = False
+    no_token_positional_embeddings: bool = False
+    learned_pos: bool = False
+    emb_dropout_p: float = 0.1
+    attention_dropout_p: float = 0.1
+    activation_dropout_p: float = 0.1
+    normalize_before: bool = True
+    input_dim: Optional[int] = None
+
+    @property
+    def pos_offset(self) -> int:
+        return (self.vocab_info.pad_idx or 0) + 1
+
+
+def _basic() -> SonarTextDecoderConfig:
+    return SonarTextDecoderConfig()
+
+
+def _small(vocab_size: int = 32005, depth: int = 6, hidden_dim: int = 1024 * 4) -> SonarTextDecoderConfig:
+    c = _basic()
+    c.vocab_info = VocabularyInfo(size=vocab_size)
+    c.num_encoder_layers = depth
+    c.num_decoder_layers = depth
+    c.ffn_inner_dim = hidden_dim
+    return c
+
+
+def _toy() -> SonarTextDecoderConfig:
+    # the reference's `toy` arch (model_dim 32, 4 heads) has head_dim 8; the engine's attention
+    # kernels are head_dim 64 only, so `toy` is accepted as a config but not runnable on the engine.
+    return SonarTextDecoderConfig(model_dim=32, vocab_info=VocabularyInfo(size=1024), num_encoder_layers=2,
+                                  num_decoder_layers=2, num_encoder_attn_heads=4, num_decoder_attn_heads=4,
+                                  ffn_inner_dim=128)
+
+
+TEXT_DECODER_ARCHS = {"basic": _basic, "small": _small, "toy": _toy}
+
+
+def get_text_decoder_config(arch: str) -> SonarTextDecoderConfig:
+    try:
+        return TEXT_DECODER_ARCHS[arch]()
+    except KeyError:
+        raise ValueError(f"unknown sonar text decoder arch {arch!r}; known: {sorted(TEXT_DECODER_ARCHS)}")
+
+
+_FAIRSEQ1_DECODER_KEY_MAP = [
+    (r"^layers\.([0-9]+)\.self_attn\.out_proj\.", r"decoder.layers.\1.self_attn.output_proj."),
+    (r"^layers\.([0-9]+)\.self_attn\.(q|k|v)_proj\.", r"decoder.layers.\1.self_attn.\2_proj."),
+    (r"^layers\.([0-9]+)\.self_attn_layer_norm\.", r"decoder.layers.\1.self_attn_layer_norm."),
+    (r"^layers\.([0-9]+)\.encoder_attn\.out_proj\.", r"decoder.layers.\1.encoder_decoder_attn.output_proj."),
+    (r"^layers\.([0-9]+)\.encoder_attn\.(q|k|v)_proj\.", r"decoder.layers.\1.encoder_decoder_attn.\2_proj."),
+    (r"^layers\.([0-9]+)\.encoder_attn_layer_norm\.", r"decoder.layers.\1.encoder_decoder_attn_layer_norm."),
+    (r"^layers\.([0-9]+)\.ffn\.(inner|output)_proj\.", r"decoder.layers.\1.ffn.\2_proj."),
+    (r"^layers\.([0-9]+)\.ffn_layer_norm\.", r"decoder.layers.\1.ffn_layer_norm."),
+    (r"^layers\.([0-9]+)\.fc1\.", r"decoder.layers.\1.ffn.inner_proj."),
+    (r"^layers\.([0-9]+)\.fc2\.", r"decoder.layers.\1.ffn.output_proj."),
+    (r"^layers\.([0-9]+)\.final_layer_norm\.", r"decoder.layers.\1.ffn_layer_norm."),
+    (r"^output_projection\.", r"final_proj."),
+    (r"^embed_tokens\.", r"decoder_frontend.embed."),
+    (r"^layer_norm\.", r"decoder.layer_norm."),
+]
+
+
+def convert_sonar_text_decoder_checkpoint(checkpoint: Mapping) -> Dict[str, torch.Tensor]:
+    """Flat fairseq2-style state dict from either layout the reference accepts
+    (handler.py:122-172).  fairseq1 keys are renamed and the control-token rows of the
+    embedding permuted (BOS, PAD, EOS, UNK) -> (PAD, UNK, BOS, EOS).  `final_proj.weight`
+    is dropped: the output projection is tied to the (permuted) embedding
+    (TiedProjection, factory.py:306-307)."""
+    if "model" in checkpoint and "decoder_frontend.embed.weight" in checkpoint["model"]:
+        out = dict(checkpoint["model"])
+        out.pop("final_proj.weight", None)
+        return out
+    if "state_dict" not in checkpoint:
+        if "decoder_frontend.embed.weight" in checkpoint:
+            out = dict(checkpoint)
+            out.pop("final_proj.weight", None)
+            return out
+        raise ValueError("unrecognised SONAR text decoder checkpoint layout")
+    out: Dict[str, torch.Tensor] = {}
+    for key, val in checkpoint["state_dict"].items():
+        if key in ("version", "embed_positions._float_tensor"):
+            continue
+        new = key
+        for pat, rep in _FAIRSEQ1_DECODER_KEY_MAP:
+            new, n = re.subn(pat, rep, new)
+            if n:
+                break
+        out[new] = val
+    emb = out["decoder_frontend.embed.weight"].clone()
+    emb[[0, 1, 2, 3]] = emb[[1, 3, 0, 2]]
+    out["decoder_frontend.embed.weight"] = emb
+    out.pop("final_proj.weight", None)
+    return out
+
+
+# --------------------------------------------------------------------- engine
+class TextDecoderEngine:
+    """Owns one `smi_text_decoder` handle (packed fp16 weights in HBM + generation workspace)."""
+
+    def __init__(self, cfg: SonarTextDecoderConfig, state_dict: Mapping[str, torch.Tensor],
+                 device: Union[str, torch.device] = "cuda:0",
+                 tokenizer_special: Tuple[int, int, int, int] = (0, 1, 2, 3)):
+        if cfg.activation_fn != "ReLU" or cfg.layernorm_embedding or cfg.learned_pos or cfg.no_token_positional_embeddings:
+            raise NotImplementedError("decoder variant not covered by the MI355X engine")
+        if (cfg.input_dim or cfg.model_dim) != cfg.model_dim:
+            raise NotImplementedError("input_dim != model_dim is not covered by the MI355X engine")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the SONAR MI355X engine runs on a HIP device only (no CPU path)")
+        self.lib = _lib.load()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        _lib.check(self.lib.smi_init(idx))
+        d = cfg.model_dim
+        pad, unk, bos, eos = tokenizer_special
+        ccfg = _lib.smi_text_decoder_config(
+            model_dim=d, num_layers=cfg.num_decoder_layers, num_heads=cfg.num_decoder_attn_heads,
+            ffn_inner_dim=cfg.ffn_inner_dim, vocab_size=cfg.vocab_info.size, max_seq_len=cfg.max_seq_len,
+            pos_offset=cfg.pos_offset, input_dim=cfg.input_dim or d,
+            embed_scale=1.0 if cfg.no_scale_embedding else math.sqrt(d), ln_eps=1e-5,
+            pad_idx=pad, unk_idx=unk, bos_idx=bos, eos_idx=eos)
+        keep: List[torch.Tensor] = []
+
+        def tv(name: str) -> _lib.smi_tensor:
+            if name not in state_dict:
+                raise KeyError(f"checkpoint is missing {name}")
+            return _tensor_view(state_dict[name], keep)
+
+        layers = (_lib.smi_text_decoder_layer * max(cfg.num_decoder_layers, 1))()
+        for i in range(cfg.num_decoder_layers):
+            p = f"decoder.layers.{i}."
+            L = layers[i]
+            L.self_attn_layer_norm_w = tv(p + "self_attn_layer_norm.weight")
+            L.self_attn_layer_norm_b = tv(p + "self_attn_layer_norm.bias")
+            L.q_w, L.q_b = tv(p + "self_attn.q_proj.weight"), tv(p + "self_attn.q_proj.bias")
+            L.k_w, L.k_b = tv(p + "self_attn.k_proj.weight"), tv(p + "self_attn.k_proj.bias")
+            L.v_w, L.v_b = tv(p + "self_attn.v_proj.weight"), tv(p + "self_attn.v_proj.bias")
+            L.out_w, L.out_b = tv(p + "self_attn.output_proj.weight"), tv(p + "self_attn.output_proj.bias")
+            L.cross_v_w = tv(p + "encoder_decoder_attn.v_proj.weight")
+            L.cross_v_b = tv(p + "encoder_decoder_attn.v_proj.bias")
+            L.cross_out_w = tv(p + "encoder_decoder_attn.output_proj.weight")
+            L.cross_out_b = tv(p + "encoder_decoder_attn.output_proj.bias")
+            L.ffn_layer_norm_w = tv(p + "ffn_layer_norm.weight")
+            L.ffn_layer_norm_b = tv(p + "ffn_layer_norm.bias")
+            L.ffn_inner_w, L.ffn_inner_b = tv(p + "ffn.inner_proj.weight"), tv(p + "ffn.inner_proj.bias")
+            L.ffn_out_w, L.ffn_out_b = tv(p + "ffn.output_proj.weight"), tv(p + "ffn.output_proj.bias")
+        w = _lib.smi_text_decoder_weights()
+        w.embed = tv("decoder_frontend.embed.weight")
+        w.pos_table = _tensor_view(sinusoidal_table(cfg.max_seq_len + cfg.pos_offset, d), keep)
+        w.final_layer_norm_w = tv("decoder.layer_norm.weight")
+        w.final_layer_norm_b = tv("decoder.layer_norm.bias")
+        w.layers = C.cast(layers, C.POINTER(_lib.smi_text_decoder_layer))
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_decoder_create(C.byref(ccfg), C.byref(w), C.byref(handle)))
+        self._handle = handle
+        del keep
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                self.lib.smi_text_decoder_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def _emb(self, embeddings: torch.Tensor) -> torch.Tensor:
+        if embeddings.dim() != 2 or embeddings.shape[1] != self.cfg.model_dim:
+            raise ValueError(f"embeddings must be [n, {self.cfg.model_dim}]")
+        e = embeddings.to(self.device)
+        if e.dtype not in (torch.float16, torch.float32):
+            e = e.float()
+        return e.contiguous()
+
+    def logits(self, embeddings: torch.Tensor, prev_tokens: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced logits fp32 [n, t, vocab] (cf. test_text_sonar.py:61-105)."""
+        e = self._emb(embeddings)
+        prev = prev_tokens.to(self.device, torch.int64).contiguous()
+        n, t = prev.shape
+        if n != e.shape[0]:
+            raise ValueError("one embedding per token row expected")
+        out = torch.empty((n, t, self.cfg.vocab_info.size), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_decoder_logits(
+                self._handle, e.data_ptr(), _lib.SMI_F32 if e.dtype == torch.float32 else _lib.SMI_F16, n,
+                prev.data_ptr(), t, out.data_ptr(), _lib.current_stream_ptr()))
+        return out
+
+    def generate(self, embeddings: torch.Tensor, prompt: Sequence[int], beam_size: int = 5, min_gen_len: int = 1,
+                 max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
+                 normalize_scores: bool = True, len_penalty: float = 1.0, unk_penalty: float = 0.0,
+                 temperature: float = 1.0):
+        """Beam search with fairseq2's BeamSearchSeq2SeqGenerator defaults.
+        Returns (tokens int32 [n, beam, L] (-1 padded), lens int32 [n, beam], scores fp32 [n, beam]),
+        hypotheses best first; tokens are the generated part (after the prompt) incl. the final EOS."""
+        e = self._emb(embeddings)
+        n = e.shape[0]
+        plen = len(prompt)
+        model_max = max_seq_len if max_seq_len is not None else self.cfg.max_seq_len
+        if model_max > self.cfg.max_seq_len:
+            raise ValueError(f"max_seq_len cannot be larger than the decoder's {self.cfg.max_seq_len}")
+        gen_cap = int(max_gen_len[0] * 1 + max_gen_len[1])  # source length is 1 (one sentence vector)
+        max_len = min(plen + gen_cap, model_max)
+        min_len = min(plen + min_gen_len, max_len)
+        bp = _lib.smi_beam_search_params(beam_size=beam_size, max_seq_len=max_len, min_seq_len=min_len,
+                                         normalize_scores=1 if normalize_scores else 0, len_penalty=len_penalty,
+                                         unk_penalty=unk_penalty, temperature=temperature, reserved=0)
+        toks = torch.empty((n, beam_size, max_len), dtype=torch.int32, device=self.device)
+        lens = torch.empty((n, beam_size), dtype=torch.int32, device=self.device)
+        scores = torch.empty((n, beam_size), dtype=torch.float32, device=self.device)
+        prompt_arr = (C.c_int64 * plen)(*[int(t) for t in prompt])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_decoder_generate(
+                self._handle, e.data_ptr(), _lib.SMI_F32 if e.dtype == torch.float32 else _lib.SMI_F16, n,
+                prompt_arr, plen, C.byref(bp), toks.data_ptr(), lens.data_ptr(), scores.data_ptr(),
+                _lib.current_stream_ptr()))
+        return toks, lens, scores
+
+
+class ConditionalTransformerDecoderModel:
+    """Drop-in for the object `EmbeddingToTextModelPipeline` receives as `decoder`
+    (sonar/nn/conditional_decoder_model.py:26-94): exposes model_dim, max_target_seq_len and the
+    engine's on-device generation."""
+
+    def __init__(self, cfg: SonarTextDecoderConfig, state_dict: Mapping[str, torch.Tensor],
+                 device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16):
+        self.config = cfg
+        self.model_dim = cfg.model_dim
+        self.max_target_seq_len = cfg.max_seq_len
+        self.dtype = dtype
+        self.engine = TextDecoderEngine(cfg, state_dict, device)
+        self.device = self.engine.device
+
+    def eval(self):
+        return self
+
+
+def load_sonar_text_decoder(checkpoint: Union[str, Mapping], arch: str = "basic",
+                            device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
+                            config: Optional[SonarTextDecoderConfig] = None) -> ConditionalTransformerDecoderModel:
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    cfg = config or get_text_decoder_config(arch)
+    return ConditionalTransformerDecoderModel(cfg, convert_sonar_text_decoder_checkpoint(checkpoint), device, dtype)

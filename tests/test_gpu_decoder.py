@@ -1,0 +1,134 @@
+"""GPU parity of the EmbeddingToText hot path (decoder step + on-device beam search, through the
+C ABI) against the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(d=256, heads=4, ffn=512, layers=2, vocab=1000, max_seq_len=64):
+    from oracle.text_decoder import OracleTextDecoderConfig
+    from sonar_amd.text_decoder import SonarTextDecoderConfig
+    from sonar_amd.text_encoder import VocabularyInfo
+
+    o = OracleTextDecoderConfig(model_dim=d, num_layers=layers, num_heads=heads, ffn_inner_dim=ffn,
+                                vocab_size=vocab, max_seq_len=max_seq_len)
+    c = SonarTextDecoderConfig(model_dim=d, num_decoder_layers=layers, num_decoder_attn_heads=heads,
+                               ffn_inner_dim=ffn, vocab_info=VocabularyInfo(size=vocab), max_seq_len=max_seq_len)
+    return o, c
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from oracle import text_decoder as OD
+    from sonar_amd.text_decoder import TextDecoderEngine
+
+    ocfg, cfg = _cfgs()
+    params = OD.make_synthetic_params(ocfg, seed=4321, std=0.09)
+    eng = TextDecoderEngine(cfg, params, device="cuda:0")
+    return OD, ocfg, params, eng
+
+
+def test_decoder_logits_vs_oracle(setup):
+    OD, ocfg, params, eng = setup
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(5, ocfg.model_dim, generator=g) * 0.3
+    prev = torch.randint(4, ocfg.vocab_size, (5, 11), generator=g)
+    prev[:, 0] = 3
+    ref = OD.decoder_logits(params, ocfg, emb, prev)
+    got = eng.logits(emb.cuda(), prev.cuda()).cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 1.5e-2 * scale, ((got - ref).abs().max().item(), scale)
+    # fp16 embeddings in, same answer
+    got16 = eng.logits(emb.half().cuda(), prev.cuda()).cpu()
+    assert (got16 - ref).abs().max().item() <= 2e-2 * scale
+    # the reference test's shape: one sentence, prev tokens [[3, 333]] (test_text_sonar.py:69)
+    one = eng.logits(emb[:1].cuda(), torch.tensor([[3, 333]]).cuda()).cpu()
+    assert (one - OD.decoder_logits(params, ocfg, emb[:1], torch.tensor([[3, 333]]))).abs().max().item() <= 1.5e-2 * scale
+
+
+def _rescored(OD, params, ocfg, e, prompt, seq):
+    full = torch.tensor([list(prompt) + seq])
+    lp = torch.log_softmax(OD.decoder_logits(params, ocfg, e.unsqueeze(0), full[:, :-1]), dim=-1)
+    return lp[0, torch.arange(full.shape[1] - 1), full[0, 1:]].sum().item()
+
+
+@pytest.mark.parametrize("beam", [1, 3, 5])
+def test_beam_search_vs_oracle(setup, beam):
+    OD, ocfg, params, eng = setup
+    g = torch.Generator().manual_seed(10 + beam)
+    n = 7
+    emb = torch.randn(n, ocfg.model_dim, generator=g) * 0.3
+    prompt = [3, 700]
+    kw = dict(beam_size=beam, max_gen_len=(1, 12))
+    ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
+    toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
+    torch.cuda.synchronize()
+    toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
+    exact = 0
+    for i in range(n):
+        L = int(lens[i, 0])
+        seq = toks[i, 0, :L].tolist()
+        assert L >= 2 and seq[-1] == 3 and 0 not in seq and all(t >= 0 for t in seq)
+        assert (toks[i, 0, L:] == -1).all()
+        # the engine's best hypothesis is a valid hypothesis with the score the oracle assigns to it
+        total = _rescored(OD, params, ocfg, emb[i], prompt, seq)
+        norm = total / (len(prompt) + L - 1)
+        assert abs(norm - scores[i, 0].item()) <= 2e-2, (norm, scores[i, 0].item())
+        # and it is as good as the oracle's best (identical unless two candidates tie within fp16 noise)
+        assert scores[i, 0].item() >= ref[i][0].score - 2e-2
+        exact += int(seq == ref[i][0].seq.tolist())
+        # hypotheses come out best first
+        k = int((lens[i] > 0).sum())
+        assert k == beam
+        assert all(scores[i, j] >= scores[i, j + 1] - 1e-6 for j in range(k - 1))
+    assert exact >= n - 1, f"only {exact}/{n} best hypotheses identical to the oracle"
+
+
+def test_beam_search_forced_eos_and_min_len(setup):
+    OD, ocfg, params, eng = setup
+    emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3
+    toks, lens, scores = eng.generate(emb.cuda(), [3, 701], beam_size=2, max_gen_len=(1, 3), min_gen_len=2)
+    lens = lens.cpu()
+    toks = toks.cpu()
+    assert toks.shape[2] == 2 + 4
+    for i in range(3):
+        for j in range(2):
+            L = int(lens[i, j])
+            assert 3 <= L <= 4 and toks[i, j, L - 1].item() == 3   # >= min_gen_len tokens before EOS, <= cap
+            assert 3 not in toks[i, j, :L - 1].tolist()
+
+
+def test_embedding_to_text_pipeline(setup, tmp_path):
+    import sentencepiece as spm
+
+    from sonar_amd.inference_pipelines import EmbeddingToTextModelPipeline
+    from sonar_amd.text_decoder import ConditionalTransformerDecoderModel
+    from sonar_amd.tokenizer import NllbTokenizer
+
+    OD, _, _, _ = setup
+    words = ["hello", "world", "my", "name", "is", "paul", "teacher", "working", "bonjour", "monde"]
+    corpus = tmp_path / "c.txt"
+    g = torch.Generator().manual_seed(0)
+    with open(corpus, "w") as fh:
+        for _ in range(300):
+            n = int(torch.randint(2, 10, (1,), generator=g))
+            fh.write(" ".join(words[int(i)] for i in torch.randint(0, len(words), (n,), generator=g)) + "\n")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "toy"), vocab_size=40,
+                                   model_type="unigram", hard_vocab_limit=False, bos_id=1, eos_id=2,
+                                   unk_id=0, pad_id=-1, minloglevel=2)
+    tok = NllbTokenizer(str(tmp_path / "toy.model"))
+    ocfg, cfg = _cfgs(vocab=tok.vocab_info.size)
+    params = OD.make_synthetic_params(ocfg, seed=77, std=0.09)
+    model = ConditionalTransformerDecoderModel(cfg, params, device="cuda:0")
+    pipe = EmbeddingToTextModelPipeline(model, tok, device=torch.device("cuda:0"))
+    emb = torch.randn(6, ocfg.model_dim, generator=torch.Generator().manual_seed(9)) * 0.3
+    texts = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8))
+    assert len(texts) == 6 and all(isinstance(t, str) for t in texts)
+    prompt = tok.create_encoder(lang="fra_Latn", mode="target").prefix
+    ref = OD.beam_search(params, ocfg, emb, prompt, beam_size=5, max_gen_len=(1, 8))
+    same = sum(texts[i] == tok.decode(ref[i][0].seq) for i in range(6))
+    assert same >= 5
+    with pytest.raises(NotImplementedError):
+        pipe.predict(emb, target_lang="fra_Latn", sampler=object())

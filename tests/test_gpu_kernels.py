@@ -25,7 +25,7 @@ def _stream():
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
                                    (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
                                    (256, 256, 8192), (1024, 768, 256)])
-@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_tn(lib, m, n, k, epi):
     from sonar_amd import _lib
 
@@ -33,24 +33,31 @@ def test_gemm_tn(lib, m, n, k, epi):
     x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
     w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
     bias = torch.randn(n, device="cuda", generator=g)
-    ref = x.float() @ w.float().T + bias
-    if epi == 2:
-        resid = torch.randn(m, n, device="cuda", generator=g)
-        out = resid.clone()
-        ref = ref + resid
-    else:
-        out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
-        if epi == 1:
-            ref = torch.relu(ref)
-    _lib.check(lib.smi_gemm_tn(epi, x.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, n, _stream()))
-    torch.cuda.synchronize()
-    got = out.float()
-    assert torch.isfinite(got).all()
-    err = (got - ref).abs().max().item()
-    scale = max(ref.abs().max().item(), 1.0)
-    # fp16 output: half-ulp rounding of the result; fp32 residual: accumulation order only
-    allowed = (2e-3 if epi != 2 else 2e-5) * scale
-    assert err <= allowed, (err, scale)
+    base = x.float() @ w.float().T
+    # both tile engines: 1 = 128x128, 2 = 256x256 ping-pong (needs multiples of 256)
+    for sel in ([1, 2] if m % 256 == 0 and n % 256 == 0 else [1]):
+        use_bias = not (epi == 3 and sel == 1)  # fp32 store also runs without a bias (logits GEMM)
+        ref = base + bias if use_bias else base.clone()
+        if epi == 2:
+            resid = torch.randn(m, n, device="cuda", generator=g)
+            out = resid.clone()
+            ref = ref + resid
+        elif epi == 3:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
+        else:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
+            if epi == 1:
+                ref = torch.relu(ref)
+        _lib.check(lib.smi_gemm_tn(epi | (sel << 8), x.data_ptr(), w.data_ptr(), bias.data_ptr() if use_bias else None,
+                                   out.data_ptr(), m, n, k, n, _stream()))
+        torch.cuda.synchronize()
+        got = out.float()
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs().max().item()
+        scale = max(ref.abs().max().item(), 1.0)
+        # fp16 output: half-ulp rounding of the result; fp32 outputs: accumulation order only
+        allowed = (2e-3 if epi < 2 else 2e-5) * scale
+        assert err <= allowed, (sel, err, scale)
 
 
 @pytest.mark.parametrize("d", [256, 512, 768, 1024, 2048])
