@@ -58,10 +58,14 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
   return hipGetLastError();
 }
 
-// ------------------------------------------- x += c[row / group]; h = LN(x)  (fused)
+// ---------------------- x += sum_z parts[z] (+ c[row / group]); h = LN(x)  (fused)
+// parts: split-K slabs of the preceding projection GEMM (fp32 [nparts][rows_pad][d]); c: the
+// per-sentence cross-attention constant.  Either may be null.
 template <int NV>
-__global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, const float* __restrict__ c,
-                                                     int group, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, const float* __restrict__ parts,
+                                                     int nparts, size_t part_stride,
+                                                     const float* __restrict__ c, int group,
+                                                     const float* __restrict__ w,
                                                      const float* __restrict__ b, float eps,
                                                      f16* __restrict__ h, int rows) {
   constexpr int D = NV * 256;
@@ -69,12 +73,14 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, cons
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   float* xr = x + (size_t)r * D;
-  const float* cr = c + (size_t)(r / group) * D;
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4) + *(const f32x4*)(cr + k * 256 + lane * 4);
+    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    for (int z = 0; z < nparts; ++z)
+      v[k] += *(const f32x4*)(parts + (size_t)z * part_stride + (size_t)r * D + k * 256 + lane * 4);
+    if (c) v[k] += *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4);
     *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
@@ -101,13 +107,15 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* __restrict__ x, cons
   }
 }
 
-hipError_t launch_add_layernorm(float* x, const float* c, int group, const float* w, const float* b,
-                                float eps, f16* h, int rows, int d, hipStream_t stream) {
+hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
+                                const float* c, int group, const float* w, const float* b, float eps,
+                                f16* h, int rows, int d, hipStream_t stream) {
   const int blocks = (rows + 3) / 4;
-#define SMI_AL_CASE(NV)                                                                          \
-  case NV * 256:                                                                                 \
-    hipLaunchKernelGGL(add_ln_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, c, group, w, b, \
-                       eps, h, rows);                                                            \
+  if (!parts) nparts = 0;
+#define SMI_AL_CASE(NV)                                                                            \
+  case NV * 256:                                                                                   \
+    hipLaunchKernelGGL(sum_ln_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, parts, nparts,    \
+                       part_stride, c, group, w, b, eps, h, rows);                                 \
     break;
   switch (d) {
     SMI_AL_CASE(1)
@@ -204,8 +212,6 @@ __global__ __launch_bounds__(256) void vocab_scan_kernel(const float* __restrict
                                                          float* __restrict__ psum,
                                                          float* __restrict__ pval,
                                                          int* __restrict__ pidx, int nchunks) {
-  __shared__ float s_val[4];
-  __shared__ int s_idx[4];
   __shared__ float s_red[4];
   const int row = blockIdx.y, chunk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -254,6 +260,76 @@ __global__ __launch_bounds__(256) void vocab_scan_kernel(const float* __restrict
     if (id[k] == pad_idx || (block_eos && id[k] == eos_idx) || id[k] >= vocab) v[k] = -INFINITY;
     else if (id[k] == unk_idx) v[k] -= unk_penalty;
   }
+  // Top-k2 of the chunk.  Fast path: per wave, the k2-th largest LANE maximum is a lower
+  // bound of the k2-th largest element, so only entries >= that threshold can be in the
+  // top-k2; the few survivors of the 4 waves are compacted into LDS as sortable 64-bit keys
+  // (value desc, token asc) and ranked by wave 0.  Slow exact path if the survivor list
+  // overflows (massive ties).
+  constexpr int CAP = 128;
+  __shared__ unsigned long long surv[CAP];
+  __shared__ int surv_n;
+  __shared__ float w_val[4 * VS_K2MAX];
+  __shared__ int w_idx[4 * VS_K2MAX];
+  if (k2 == 0) return;
+  if (tid == 0) surv_n = 0;
+  float lmax = v[0];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) lmax = fmaxf(lmax, v[k]);
+  float thr = -INFINITY;
+  {
+    float t = lmax;
+    for (int round = 0; round < k2; ++round) {
+      const float mval = wave_max(t);
+      thr = mval;
+      if (mval == -INFINITY) break;
+      const unsigned long long owners = __ballot(t == mval);
+      if (lane == __ffsll((long long)owners) - 1) t = -INFINITY;
+    }
+  }
+  __syncthreads();  // surv_n = 0 visible
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (v[k] >= thr && v[k] != -INFINITY) {
+      const int slot = atomicAdd(&surv_n, 1);
+      if (slot < CAP) {
+        unsigned u = __float_as_uint(v[k]);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        surv[slot] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)id[k]);
+      }
+    }
+  }
+  __syncthreads();
+  const int ns = surv_n;
+  if (ns <= CAP) {
+    if (wv == 0) {
+      unsigned long long k0 = lane < ns ? surv[lane] : 0ull;
+      unsigned long long k1 = lane + 64 < ns ? surv[lane + 64] : 0ull;
+      for (int round = 0; round < k2; ++round) {
+        unsigned long long best = k0 > k1 ? k0 : k1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long other = __shfl_xor(best, o, 64);
+          best = other > best ? other : best;
+        }
+        if (lane == 0) {
+          float val = -INFINITY;
+          int idx = 0x7fffffff;
+          if (best != 0ull) {
+            unsigned u = (unsigned)(best >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            val = __uint_as_float(u);
+            idx = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+          }
+          pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = val;
+          pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = idx;
+        }
+        if (k0 == best) k0 = 0ull;
+        if (k1 == best) k1 = 0ull;
+      }
+    }
+    return;
+  }
+  // ---- slow exact path: every wave extracts the k2 best of its 1024 entries ...
   for (int round = 0; round < k2; ++round) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -272,27 +348,38 @@ __global__ __launch_bounds__(256) void vocab_scan_kernel(const float* __restrict
         bi = oi;
       }
     }
-    __syncthreads();
     if (lane == 0) {
-      s_val[wv] = bv;
-      s_idx[wv] = bi;
-    }
-    __syncthreads();
-    bv = s_val[0];
-    bi = s_idx[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (cand_better(s_val[w], s_idx[w], bv, bi)) {
-        bv = s_val[w];
-        bi = s_idx[w];
-      }
-    if (tid == 0) {
-      pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bv;
-      pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bi;
+      w_val[wv * VS_K2MAX + round] = bv;
+      w_idx[wv * VS_K2MAX + round] = bi;
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k)
       if (id[k] == bi) v[k] = -INFINITY;  // taken
+  }
+  __syncthreads();
+  // ... and wave 0 merges the 4 x k2 lists (one candidate per lane)
+  if (wv == 0) {
+    const int src = (lane / k2) * VS_K2MAX + (lane % k2);
+    float cv = lane < 4 * k2 ? w_val[src] : -INFINITY;
+    const int ci = lane < 4 * k2 ? w_idx[src] : 0x7fffffff;
+    for (int round = 0; round < k2; ++round) {
+      float bv = cv;
+      int bi = ci;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (cand_better(ov, oi, bv, bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      if (lane == 0) {
+        pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bv;
+        pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bi;
+      }
+      if (ci == bi) cv = -INFINITY;
+    }
   }
 }
 
@@ -338,8 +425,6 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
   __shared__ float c_val[8 * VS_K2MAX];
   __shared__ int c_tok[8 * VS_K2MAX];
   __shared__ int c_row[8 * VS_K2MAX];
-  __shared__ float w_val[4];
-  __shared__ int w_slot[4];
   __shared__ int f_row[8];
   __shared__ float f_score[8];
   __shared__ int f_n, f_base;
@@ -420,27 +505,33 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
       }
     }
   } else {
-    // (2) per live row: best k2 tokens over its chunk partials (value desc, token asc)
-    for (int r = 0; r < na; ++r) {
+    // (2) per live row: best k2 tokens over its chunk partials (value desc, token asc).
+    // One wave per row; its <= 1024 partial candidates sit in registers (16 per lane).
+    for (int r = wv; r < na; r += 4) {
       const size_t o = (size_t)(base + r) * nchunks * VS_K2MAX;
-      const int total = nchunks * VS_K2MAX;
-      // each thread scans a strided subset; taken entries are tracked by (token) comparison
-      float last_v = INFINITY;
-      int last_i = -1;
+      const int total = nchunks * k2;
+      float cv[16];
+      int ci[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int e = q * 64 + lane;
+        cv[q] = -INFINITY;
+        ci[q] = 0x7fffffff;
+        if (e < total) {
+          const int off = (e / k2) * VS_K2MAX + (e % k2);
+          cv[q] = pval[o + off];
+          ci[q] = pidx[o + off];
+        }
+      }
       for (int round = 0; round < k2; ++round) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int e = tid; e < total; e += 256) {
-          if ((e % VS_K2MAX) >= k2) continue;
-          const float v = pval[o + e];
-          const int i = pidx[o + e];
-          // strictly after the previous pick in the (value desc, token asc) order
-          if (!(v < last_v || (v == last_v && i > last_i))) continue;
-          if (cand_better(v, i, bv, bi)) {
-            bv = v;
-            bi = i;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (cand_better(cv[q], ci[q], bv, bi)) {
+            bv = cv[q];
+            bi = ci[q];
           }
-        }
 #pragma unroll
         for (int of = 32; of > 0; of >>= 1) {
           const float ov = __shfl_xor(bv, of, 64);
@@ -450,53 +541,69 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
             bi = oi;
           }
         }
-        __syncthreads();
         if (lane == 0) {
-          w_val[wv] = bv;
-          w_slot[wv] = bi;
-        }
-        __syncthreads();
-        bv = w_val[0];
-        bi = w_slot[0];
-        for (int w = 1; w < 4; ++w)
-          if (cand_better(w_val[w], w_slot[w], bv, bi)) {
-            bv = w_val[w];
-            bi = w_slot[w];
-          }
-        last_v = bv;
-        last_i = bi;
-        if (tid == 0) {
           c_val[r * VS_K2MAX + round] = bv == -INFINITY ? -INFINITY : st.cum[base + r] + bv - s_lse[r];
           c_tok[r * VS_K2MAX + round] = bi;
           c_row[r * VS_K2MAX + round] = base + r;
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (ci[q] == bi) cv[q] = -INFINITY;
       }
     }
     __syncthreads();
-    // (3) thread 0: overall top-k2 (score desc, flat index row*V+token asc) + EOS handling
-    if (tid == 0) {
-      float tv[VS_K2MAX];
-      int tt[VS_K2MAX], tr[VS_K2MAX];
-      bool used[8 * VS_K2MAX];
-      for (int i = 0; i < na * VS_K2MAX; ++i) used[i] = false;
+    // (3) wave 0: overall top-k2 over the na*k2 row candidates (score desc, row asc, token asc),
+    //     two candidates per lane; then thread 0 applies the EOS rules on the sorted list.
+    __shared__ float t_val[VS_K2MAX];
+    __shared__ int t_tok[VS_K2MAX], t_row[VS_K2MAX];
+    __shared__ int t_n;
+    if (wv == 0) {
+      float v2[2];
+      int r2[2], k2t[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = u * 64 + lane;  // candidate id = row * VS_K2MAX + rank
+        const bool ok = e < na * VS_K2MAX && (e % VS_K2MAX) < k2;
+        v2[u] = ok ? c_val[e] : -INFINITY;
+        r2[u] = ok ? c_row[e] : 0x7fffffff;
+        k2t[u] = ok ? c_tok[e] : 0x7fffffff;
+      }
       int nsel = 0;
       for (int sel = 0; sel < k2; ++sel) {
-        int best = -1;
-        for (int r = 0; r < na; ++r)
-          for (int q = 0; q < k2; ++q) {
-            const int i = r * VS_K2MAX + q;
-            if (used[i] || c_val[i] == -INFINITY) continue;
-            if (best < 0 || c_val[i] > c_val[best] ||
-                (c_val[i] == c_val[best] && (c_row[i] < c_row[best] || (c_row[i] == c_row[best] && c_tok[i] < c_tok[best]))))
-              best = i;
+        // lane-local best of its two, then wave arg-best
+        int u = (v2[1] > v2[0] || (v2[1] == v2[0] && (r2[1] < r2[0] || (r2[1] == r2[0] && k2t[1] < k2t[0])))) ? 1 : 0;
+        float bv = v2[u];
+        int br = r2[u], bt = k2t[u];
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) {
+          const float ov = __shfl_xor(bv, of, 64);
+          const int orow = __shfl_xor(br, of, 64);
+          const int otok = __shfl_xor(bt, of, 64);
+          if (ov > bv || (ov == bv && (orow < br || (orow == br && otok < bt)))) {
+            bv = ov;
+            br = orow;
+            bt = otok;
           }
-        if (best < 0) break;
-        used[best] = true;
-        tv[nsel] = c_val[best];
-        tt[nsel] = c_tok[best];
-        tr[nsel] = c_row[best];
+        }
+        if (bv == -INFINITY) break;
+        if (lane == 0) {
+          t_val[sel] = bv;
+          t_tok[sel] = bt;
+          t_row[sel] = br;
+        }
         ++nsel;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+          if (r2[w] == br && k2t[w] == bt) v2[w] = -INFINITY;
       }
+      if (lane == 0) t_n = nsel;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int nsel = t_n;
+      const float* tv = t_val;
+      const int* tt = t_tok;
+      const int* tr = t_row;
       int cnt = st.fin_count[s];
       f_base = cnt;
       int nf = 0;

@@ -28,7 +28,7 @@ struct smi_text_decoder {
   DevBuf embed, pos, lnf_w, lnf_b;
   std::vector<DecLayer> layers;
   // per-call workspace (grow-only)
-  DevBuf x, h, ctx, ffn, logits, kv, cc, cvtmp, emb16;
+  DevBuf x, h, ctx, ffn, logits, kv, cc, cvtmp, emb16, parts;
   DevBuf tok, cum, parent, new_tok, new_cum, nactive, done, ndone, fin_count, fin_len, fin_score, fin_tok;
   DevBuf anc[2], hist[2];
   DevBuf pmax, psum, pval, pidx;
@@ -87,23 +87,31 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
   f16* ffn = D->ffn.as<f16>();
   const size_t slab = (size_t)rows_pad * 3 * d;  // elements per (layer, pos)
   const int P = D->kv_positions;
+  float* parts = D->parts.as<float>();
+  const size_t part_stride = (size_t)rows_pad * d;  // elements
+  const int ks_out = d % 256 == 0 ? 4 : 1, ks_ffn = f % 512 == 0 ? 8 : (f % 256 == 0 ? 4 : 1);
   HIP_TRY(launch_dec_embed(D->tok.as<int32_t>(), D->embed.as<f16>(),
                            D->pos.as<float>() + (size_t)(pos + c.pos_offset) * d, c.embed_scale, x, rows, d,
                            c.vocab_size, stream));
   for (int l = 0; l < c.num_layers; ++l) {
     DecLayer& L = D->layers[l];
     f16* kvl = D->kv.as<f16>() + (size_t)l * P * slab;
-    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+    // x += FFN-out slabs of the previous layer (split-K), then LN1
+    HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ks_ffn, part_stride, nullptr, 1, L.ln1_w.as<float>(),
+                                 L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
                            rows_pad, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, rows_pad, d, d, d, stream));
-    HIP_TRY(launch_add_layernorm(x, D->cc.as<float>() + (size_t)l * n_pad * d, group, L.ln3_w.as<float>(),
-                                 L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
+    // the two N = d projections have too few tiles to fill 256 CUs at decode batch sizes:
+    // split K into fp32 slabs that the next fused sum+LayerNorm folds into the residual stream
+    HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
+    HIP_TRY(launch_sum_layernorm(x, parts, ks_out, part_stride, D->cc.as<float>() + (size_t)l * n_pad * d, group,
+                                 L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, rows_pad, d, f, d, stream));
+    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream));
   }
-  HIP_TRY(launch_layernorm(x, D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+  HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,
+                               D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
   HIP_TRY(launch_gemm_tn(EPI_STORE_F32, h, D->embed.as<f16>(), nullptr, D->logits.p, rows_pad, (int)D->vocab_pad, d,
                          (int)D->vocab_pad, stream));
   return SMI_OK;
@@ -118,6 +126,7 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   HIP_TRY(D->ctx.reserve((size_t)rows_pad * d * 2));
   HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * 2));
   HIP_TRY(D->logits.reserve((size_t)rows_pad * D->vocab_pad * 4));
+  HIP_TRY(D->parts.reserve((size_t)8 * rows_pad * d * 4));
   // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM)
   HIP_TRY(D->kv.reserve((size_t)c.num_layers * positions * rows_pad * 3 * d * 2));
   D->kv_positions = positions;

@@ -19,14 +19,23 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 void* __restrict__ out, int M, int N,
-                                                                int K, int ldo) {
+                                                                int K, int ldo, int ksplit,
+                                                                size_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int tile_m, tile_n;
   gt_tile_coords(M / GT_BM, N / GT_BN, tile_m, tile_n);
   const int m0 = tile_m * GT_BM, n0 = tile_n * GT_BN;
 
   GemmTileAcc acc;
-  gt_mainloop(acc, X, W, K, m0, n0, smem);
+  // split-K (EPI_STORE_F32 only): blockIdx.y owns K/ksplit columns and its own output slab;
+  // the consumer sums the slabs (decode-time GEMMs have too few tiles to fill 256 CUs otherwise)
+  const int kz = blockIdx.y;
+  const int klen = K / ksplit;
+  gt_mainloop(acc, X, W, K, m0, n0, smem, kz * klen, klen);
+  if (kz > 0) {
+    bias = nullptr;
+    out = (char*)out + (size_t)kz * part_stride;
+  }
 
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni) {
@@ -190,7 +199,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
 
 template <int EPI>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
-                             int K, int ldo, hipStream_t stream) {
+                             int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI>,
@@ -199,8 +208,8 @@ static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void
     attr_done = true;
   }
   const int grid = (M / GT_BM) * (N / GT_BN);
-  hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(grid), dim3(GT_THREADS), GT_LDS_BYTES, stream, X, W,
-                     bias, out, M, N, K, ldo);
+  hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(grid, ksplit), dim3(GT_THREADS), GT_LDS_BYTES, stream, X,
+                     W, bias, out, M, N, K, ldo, ksplit, part_stride);
   return hipGetLastError();
 }
 
@@ -230,6 +239,14 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     case EPI_STORE_F32: return launch_one<EPI_STORE_F32>(X, W, bias, out, M, N, K, ldo, stream);
   }
   return hipErrorInvalidValue;
+}
+
+// Split-K GEMM into `ksplit` fp32 slabs: parts[z][m][n] = X[:, Kz] . W[:, Kz]^T (+ bias for z = 0);
+// the consumer (launch_sum_layernorm) adds the slabs to the residual stream.
+hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
+                                 int N, int K, int ksplit, hipStream_t stream) {
+  if (M % GT_BM || N % GT_BN || ksplit < 1 || K % (GT_BK * ksplit) || M <= 0) return hipErrorInvalidValue;
+  return launch_one<EPI_STORE_F32>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
 }
 
 }  // namespace smi

@@ -67,11 +67,12 @@ __device__ __forceinline__ void gt_compute(GemmTileAcc& acc, const char* stage, 
   }
 }
 
-// Full K loop for the 128x128 tile at (m0, n0).  X: [*, K] row-major, W: [*, K].
-// Rows m0..m0+127 of X and n0..n0+127 of W must be readable.  K % 64 == 0.
+// K loop for the 128x128 tile at (m0, n0) over columns [k0, k0 + klen) of X: [*, K] and
+// W: [*, K] (row-major, row stride K).  Rows m0..m0+127 of X and n0..n0+127 of W must be
+// readable.  k0 % 64 == 0, klen % 64 == 0 (klen < K: one slice of a split-K GEMM).
 __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restrict__ X,
                                             const f16* __restrict__ W, int K, int m0, int n0,
-                                            char* smem) {
+                                            char* smem, int k0 = 0, int klen = -1) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,8 +87,8 @@ __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restr
     const int c = wave * 4 + q;
     const int row = c * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    xg[q] = X + (size_t)(m0 + row) * K + chunk * 8;
-    wg[q] = W + (size_t)(n0 + row) * K + chunk * 8;
+    xg[q] = X + (size_t)(m0 + row) * K + k0 + chunk * 8;
+    wg[q] = W + (size_t)(n0 + row) * K + k0 + chunk * 8;
   }
 
   // Fragment read offsets: row = w*64 + blk*32 + (lane&31); f(row) = ((lane&31)>>1)&7.
@@ -103,7 +104,7 @@ __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
 
-  const int nt = K / GT_BK;
+  const int nt = (klen < 0 ? K : klen) / GT_BK;
   gt_issue(xg, wg, 0, smem, wave);
   for (int t = 0; t < nt; ++t) {
     // The compiler drains the outstanding LDS DMA (vmcnt(0)) ahead of this

@@ -14,6 +14,9 @@ enum GemmEpilogue { EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_S
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
                           int N, int K, int ldo, hipStream_t stream);
 
+hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
+                                 int N, int K, int ksplit, hipStream_t stream);
+
 // x[row(n,p), :] = E[ids[n*S+p], :] * scale + PE[p + pos_offset, :]   (packed rows)
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu_seqlens, const f16* table,
                              const float* pos_table, float scale, int pos_offset, float* x, int N,
@@ -49,8 +52,10 @@ hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16
 // ---- decoder / beam search (decoder.hip) ----
 hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* pe_row, float scale,
                             float* x, int rows, int d, int64_t vocab, hipStream_t stream);
-hipError_t launch_add_layernorm(float* x, const float* c, int group, const float* w, const float* b,
-                                float eps, f16* h, int rows, int d, hipStream_t stream);
+// x[r] += sum_z parts[z][r] (+ c[r / group] if c); h[r] = LN(x[r])   (parts/c may be null)
+hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
+                                const float* c, int group, const float* w, const float* b, float eps,
+                                f16* h, int rows, int d, hipStream_t stream);
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream);
 constexpr int kVocabScanChunk = 4096;
