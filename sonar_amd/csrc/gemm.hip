@@ -191,6 +191,13 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
       case 7: return launch_var256<EPI, 7>(X, W, bias, out, M, N, K, ldo, stream);
       case 8: return launch_var256<EPI, 8>(X, W, bias, out, M, N, K, ldo, stream);
       case 10: return launch_var256<EPI, 10>(X, W, bias, out, M, N, K, ldo, stream);
+      case 11: return launch_var256<EPI, 11>(X, W, bias, out, M, N, K, ldo, stream);
+      case 12: return launch_var256<EPI, 12>(X, W, bias, out, M, N, K, ldo, stream);
+      case 13: return launch_var256<EPI, 13>(X, W, bias, out, M, N, K, ldo, stream);
+      case 14: return launch_var256<EPI, 14>(X, W, bias, out, M, N, K, ldo, stream);
+      case 16: return launch_var256<EPI, 16>(X, W, bias, out, M, N, K, ldo, stream);
+      case 17: return launch_var256<EPI, 17>(X, W, bias, out, M, N, K, ldo, stream);
+      case 18: return launch_var256<EPI, 18>(X, W, bias, out, M, N, K, ldo, stream);
     }
   }
 #endif

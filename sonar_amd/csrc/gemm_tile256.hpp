@@ -73,7 +73,11 @@ __device__ __forceinline__ void g2_issue(const f16* const (&xg)[2], const f16* c
 //   1 no in-loop DMA, 2 DMA reads full 128-B lines (wrong rows), 3 no MFMA,
 //   4 no DMA + fragments read once, 6 DMA issued but never waited for,
 //   7 half the DMA, 8 DMA always re-reads slice 0 (cache-hot), 10 DMA issued inside the
-//   multiply segment (CORRECT results).
+//   multiply segment (CORRECT results), 11 half the fragment reads (ks=1 reuses ks=0),
+//   12 no MFMA + full-line DMA, 13 DMA only (no MFMA, no fragment reads, no barriers),
+//   14 as 13 but cache-hot addresses, 16 as 13 but plain global_load_dwordx4 to VGPRs (no LDS),
+//   17 as 13 with tile-major (contiguous 16 KiB per slice) source addresses, 18 full kernel with
+//   tile-major source addresses (wrong data, right traffic pattern).
 template <int VAR = 0>
 __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __restrict__ X,
                                             const f16* __restrict__ W, int K, int m0, int n0,
@@ -89,13 +93,21 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
   for (int q = 0; q < 2; ++q) {
     int row = (wave * 2 + q) * 16 + (lane >> 2);
     int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    if constexpr (VAR == 2) {
+    if constexpr (VAR == 2 || VAR == 12) {
       row = (wave * 2 + q) * 8 + (lane >> 3);
       chunk = lane & 7;
     }
     xg[q] = X + (size_t)(m0 + row) * K + chunk * 8;
     wg[q] = W + (size_t)(n0 + row) * K + chunk * 8;
+    if constexpr (VAR == 17 || VAR == 18) {
+      // block (rb, kb) of 256 rows x 32 k is 16 KiB contiguous; slice t advances by 8192 halfs.
+      // (koff = t*32 is added later: scale it to t*8192 by pre-multiplying the base and using
+      // a 256x stride: emulate with pointer arithmetic below)
+      xg[q] = X + (size_t)(m0 / 256) * (size_t)K * 256 + (wave * 2 + q) * 512 + lane * 8;
+      wg[q] = W + (size_t)(n0 / 256) * (size_t)K * 256 + (wave * 2 + q) * 512 + lane * 8;
+    }
   }
+  constexpr int KSTEP = (VAR == 17 || VAR == 18) ? 256 : 1;  // slice stride multiplier
 
   const int l31 = lane & 31, hi = lane >> 5;
   const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
@@ -110,9 +122,9 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
 
   const int nt = K / G2_BK;
-  g2_issue(xg, wg, 0, smem, wave);
-  if (nt > 1) g2_issue(xg, wg, 1, smem, wave);
-  if (nt > 2) g2_issue(xg, wg, 2, smem, wave);
+  g2_issue(xg, wg, 0, smem, wave, 0);
+  if (nt > 1) g2_issue(xg, wg, 1, smem, wave, 1 * KSTEP);
+  if (nt > 2) g2_issue(xg, wg, 2, smem, wave, 2 * KSTEP);
   if (nt > 2) SMI_WAIT_VMCNT(8);
   else if (nt > 1) SMI_WAIT_VMCNT(4);
   else SMI_WAIT_VMCNT(0);
@@ -123,13 +135,19 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
     // ---- read segment: fragments of slice t -> VGPRs, DMA for slice t+3 ----
     const char* slot = smem + (t & 3) * G2_SLOT_BYTES;
     half8 fx[2][4], fw[2][2];
-    if (VAR != 4 || t == 0)
+    if ((VAR != 4 && VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) || t == 0)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < (VAR == 11 ? 1 : 2); ++ks) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) fw[ks][ni] = *(const half8*)(slot + ((woff + ni * 2048) ^ (ks << 5)));
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
+    }
+    if constexpr (VAR == 11) {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) fw[1][ni] = fw[0][ni];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fx[1][mi] = fx[0][mi];
     }
     if (VAR == 1 || VAR == 4) {
     } else if (VAR == 10) {
@@ -138,8 +156,14 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       else SMI_WAIT_VMCNT(0);
     } else if (t + 3 < nt) {
       if (VAR == 7) g2_issue<1>(xg, wg, t + 3, smem, wave);
-      else if (VAR == 8) g2_issue(xg, wg, t + 3, smem, wave, 0);
-      else g2_issue(xg, wg, t + 3, smem, wave);
+      else if (VAR == 8 || VAR == 14) g2_issue(xg, wg, t + 3, smem, wave, 0);
+      else if (VAR == 16) {
+        const int koff = (t + 3) * G2_BK;
+        half8 a0 = *(const half8*)(xg[0] + koff), a1 = *(const half8*)(xg[1] + koff);
+        half8 a2 = *(const half8*)(wg[0] + koff), a3 = *(const half8*)(wg[1] + koff);
+        asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      }
+      else g2_issue(xg, wg, t + 3, smem, wave, (t + 3) * KSTEP);
       if (VAR == 7) SMI_WAIT_VMCNT(4);
       else if (VAR != 6) SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
     } else if (t + 2 < nt) {
@@ -147,7 +171,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
     } else {
       SMI_WAIT_VMCNT(0);
     }
-    SMI_LGKM0_BARRIER();
+    if (VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) SMI_LGKM0_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
     // ---- multiply segment ----
     __builtin_amdgcn_s_setprio(1);
@@ -158,7 +182,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
         {
-          if constexpr (VAR == 3) {
+          if constexpr (VAR == 3 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 16 || VAR == 17) {
             asm volatile("" ::"v"(fw[ks][ni]), "v"(fx[ks][mi]));
           } else {
             acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
@@ -170,7 +194,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
         }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    SMI_BARRIER();
+    if (VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) SMI_BARRIER();
   }
   if (wr == 0) SMI_BARRIER();  // balance group 1's extra barrier
 }
