@@ -202,6 +202,79 @@ int smi_text_decoder_generate(smi_text_decoder* dec, const void* emb, int32_t em
                               const int64_t* prompt, int32_t prompt_len, const smi_beam_search_params* params,
                               int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 
+/* Speech encoder -------------------------------------------------------------------
+ * Stands in for: WaveformToFbankConverter(num_mel_bins=80, waveform_scale=2**15,
+ * standardize=True) (sonar/inference_pipelines/speech.py:283-290), SonarSpeechEncoderFactory +
+ * checkpoint load (sonar/models/sonar_speech/factory.py:53-152, handler.py:46-110) and
+ * SonarSpeechEncoderModel.forward (sonar/models/sonar_speech/model.py:59-77) as invoked by
+ * SpeechToEmbeddingModelPipeline.predict (speech.py:431-474). */
+typedef struct smi_speech_encoder_config {
+  int32_t model_dim;        /* 1024 = num_heads*64 */
+  int32_t num_layers;       /* 24 conformer blocks */
+  int32_t num_heads;        /* 16 */
+  int32_t ffn_inner_dim;    /* 4096 */
+  int32_t conv_kernel;      /* 31 (7 also built, for tests) */
+  int32_t num_mel_bins;     /* 80; two frames are stacked -> feature_dim 160 */
+  int32_t pooler_layers;    /* 3 ("english") / 6 ("non_english") */
+  int32_t pooler_heads;     /* 16 */
+  int32_t pooler_ffn_dim;   /* 4096 */
+  int32_t pooler_vocab;     /* rows of the pooler embedding (= model_dim, factory.py:94-100) */
+  int32_t bos_idx;          /* 2 */
+  int32_t max_frames;       /* largest number of STACKED frames per clip (rel-pos table), e.g. 4096 */
+  float ln_eps, bn_eps;     /* 1e-5, 1e-5 */
+} smi_speech_encoder_config;
+
+typedef struct smi_conformer_layer {
+  smi_tensor ffn1_layer_norm_w, ffn1_layer_norm_b, ffn1_inner_w, ffn1_inner_b, ffn1_out_w, ffn1_out_b;
+  smi_tensor self_attn_layer_norm_w, self_attn_layer_norm_b;
+  smi_tensor q_w, q_b, k_w, k_b, v_w, v_b, out_w, out_b;
+  smi_tensor r_proj_w, u_bias, v_bias;             /* self_attn.sdpa.* */
+  smi_tensor conv_layer_norm_w, conv_layer_norm_b;
+  smi_tensor pointwise_conv1_w;                    /* [2d, d] (kernel size 1 squeezed), no bias */
+  smi_tensor depthwise_conv_w;                     /* [d, k] */
+  smi_tensor batch_norm_w, batch_norm_b, batch_norm_mean, batch_norm_var;
+  smi_tensor pointwise_conv2_w;                    /* [d, d] */
+  smi_tensor ffn2_layer_norm_w, ffn2_layer_norm_b, ffn2_inner_w, ffn2_inner_b, ffn2_out_w, ffn2_out_b;
+  smi_tensor layer_norm_w, layer_norm_b;           /* final LayerNorm of the block */
+} smi_conformer_layer;
+
+/* POST-norm decoder layer of the attention pooler.  The self-attention runs over ONE token, so
+ * its q/k projections cannot influence the output and are not needed. */
+typedef struct smi_pooler_layer {
+  smi_tensor self_v_w, self_v_b, self_out_w, self_out_b, self_attn_layer_norm_w, self_attn_layer_norm_b;
+  smi_tensor cross_q_w, cross_q_b, cross_k_w, cross_k_b, cross_v_w, cross_v_b, cross_out_w, cross_out_b;
+  smi_tensor cross_layer_norm_w, cross_layer_norm_b;
+  smi_tensor ffn_inner_w, ffn_inner_b, ffn_out_w, ffn_out_b, ffn_layer_norm_w, ffn_layer_norm_b;
+} smi_pooler_layer;
+
+typedef struct smi_speech_encoder_weights {
+  smi_tensor post_extract_layer_norm_w, post_extract_layer_norm_b; /* [2*num_mel_bins] */
+  smi_tensor model_dim_proj_w, model_dim_proj_b;                   /* [d, 2*num_mel_bins], [d] */
+  smi_tensor layer_norm_w, layer_norm_b;                           /* model-level LN (handler.py:102-108) */
+  smi_tensor pooler_embed;                                         /* [pooler_vocab, d] */
+  smi_tensor pooler_projection_out_w;                              /* [d, d], no bias */
+  const smi_conformer_layer* layers;
+  const smi_pooler_layer* pooler;
+} smi_speech_encoder_weights;
+
+typedef struct smi_speech_encoder smi_speech_encoder; /* opaque */
+
+int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_speech_encoder_weights* w,
+                              smi_speech_encoder** out);
+void smi_speech_encoder_destroy(smi_speech_encoder* enc);
+
+/* fbank: device fp32 [n, t, num_mel_bins] zero-padded, t even (Collater pad_to_multiple=2,
+ * speech.py:444); fbank_lens: HOST int32 [n] frames per clip or NULL; out_emb device [n, model_dim]. */
+int smi_speech_encoder_forward(smi_speech_encoder* enc, const float* fbank, const int32_t* fbank_lens,
+                               int32_t n, int32_t t, void* out_emb, int32_t out_dtype, void* stream);
+
+/* Kaldi-compatible log-mel filterbank of ONE 16 kHz clip: wave device fp32 [nsamples] in [-1, 1],
+ * out device fp32 [smi_fbank_num_frames(nsamples), 80].  25 ms / 10 ms frames, povey window,
+ * pre-emphasis 0.97, DC removal, 512-point FFT, 80 mel bins from 20 Hz, log power, snip_edges. */
+int64_t smi_fbank_num_frames(int64_t nsamples);
+int smi_fbank(const float* wave, int64_t nsamples, float waveform_scale, int32_t standardize, float* out,
+              void* stream);
+
 /* xsim mining ---------------------------------------------------------------
  * Stands in for the similarity search the reference performs as
  * F.normalize(x) @ F.normalize(y).T (tests/integration_tests/test_text_sonar.py:42-53)

@@ -134,6 +134,46 @@ class smi_beam_search_params(C.Structure):
     ]
 
 
+class smi_speech_encoder_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "model_dim", "num_layers", "num_heads", "ffn_inner_dim", "conv_kernel", "num_mel_bins",
+        "pooler_layers", "pooler_heads", "pooler_ffn_dim", "pooler_vocab", "bos_idx", "max_frames")] + [
+        ("ln_eps", C.c_float), ("bn_eps", C.c_float)]
+
+
+_CONF_LAYER_FIELDS = [
+    "ffn1_layer_norm_w", "ffn1_layer_norm_b", "ffn1_inner_w", "ffn1_inner_b", "ffn1_out_w", "ffn1_out_b",
+    "self_attn_layer_norm_w", "self_attn_layer_norm_b",
+    "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "out_w", "out_b",
+    "r_proj_w", "u_bias", "v_bias",
+    "conv_layer_norm_w", "conv_layer_norm_b", "pointwise_conv1_w", "depthwise_conv_w",
+    "batch_norm_w", "batch_norm_b", "batch_norm_mean", "batch_norm_var", "pointwise_conv2_w",
+    "ffn2_layer_norm_w", "ffn2_layer_norm_b", "ffn2_inner_w", "ffn2_inner_b", "ffn2_out_w", "ffn2_out_b",
+    "layer_norm_w", "layer_norm_b",
+]
+_POOL_LAYER_FIELDS = [
+    "self_v_w", "self_v_b", "self_out_w", "self_out_b", "self_attn_layer_norm_w", "self_attn_layer_norm_b",
+    "cross_q_w", "cross_q_b", "cross_k_w", "cross_k_b", "cross_v_w", "cross_v_b", "cross_out_w", "cross_out_b",
+    "cross_layer_norm_w", "cross_layer_norm_b",
+    "ffn_inner_w", "ffn_inner_b", "ffn_out_w", "ffn_out_b", "ffn_layer_norm_w", "ffn_layer_norm_b",
+]
+
+
+class smi_conformer_layer(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in _CONF_LAYER_FIELDS]
+
+
+class smi_pooler_layer(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in _POOL_LAYER_FIELDS]
+
+
+class smi_speech_encoder_weights(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in (
+        "post_extract_layer_norm_w", "post_extract_layer_norm_b", "model_dim_proj_w", "model_dim_proj_b",
+        "layer_norm_w", "layer_norm_b", "pooler_embed", "pooler_projection_out_w")] + [
+        ("layers", C.POINTER(smi_conformer_layer)), ("pooler", C.POINTER(smi_pooler_layer))]
+
+
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -155,6 +195,12 @@ SYMBOLS = {
     "smi_text_decoder_logits": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "smi_text_decoder_generate": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                             C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
+    "smi_speech_encoder_create": (C.c_int, [C.POINTER(smi_speech_encoder_config),
+                                            C.POINTER(smi_speech_encoder_weights), C.POINTER(_vp)]),
+    "smi_speech_encoder_destroy": (None, [_vp]),
+    "smi_speech_encoder_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "smi_fbank_num_frames": (_i64, [_i64]),
+    "smi_fbank": (C.c_int, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "smi_xsim_padded_rows": (_i64, [_i64]),
     "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),

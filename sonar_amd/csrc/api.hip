@@ -419,8 +419,8 @@ int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_
 int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, void* out, int32_t m,
                 int32_t n, int32_t k, int32_t ldo, void* stream) {
   if (!x || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
-  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || (epi & 0xff) > 3 || (epi >> 8) > 2 ||
-      epi < 0 || ldo < n || ((epi >> 8) == 2 && (m % 256 || n % 256)))
+  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || (epi & 0xff) > 6 || (epi >> 8) > 2 ||
+      epi < 0 || ldo < ((epi & 0xff) == 6 ? n / 2 : n) || ((epi >> 8) == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));

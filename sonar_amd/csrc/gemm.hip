@@ -1,19 +1,40 @@
-// Dense projection GEMMs of the SONAR text encoder/decoder layers
-// (q/k/v/out projections and the FFN: reference wiring at
-// sonar/models/sonar_text/factory.py:130-153), fp16 in, fp32 accumulate on
-// v_mfma_f32_32x32x16_f16, with the bias / ReLU / residual epilogues fused.
+// Dense projection GEMMs of the SONAR text encoder/decoder and conformer layers
+// (q/k/v/out projections, FFNs, pointwise convolutions: reference wiring at
+// sonar/models/sonar_text/factory.py:130-153 and, for the conformer, fairseq2's
+// ConformerBlock built by sonar/models/sonar_speech/factory.py:64-71), fp16 in, fp32
+// accumulate on v_mfma_f32_32x32x16_f16, with the epilogues fused.
+#include <cstdlib>
+
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
 
-#include <cstdlib>
-
 namespace smi {
 
-// EPI_BIAS_F16 : out_h[m][n]  = f16(acc + bias[n])
-// EPI_RELU_F16 : out_h[m][n]  = f16(max(acc + bias[n], 0))
-// EPI_RESID_F32: resid[m][n] += acc + bias[n]          (fp32 residual stream)
-// EPI_STORE_F32: out_f[m][n]  = acc (+ bias[n] if bias)  (fp32 logits)
+// EPI_BIAS_F16      : out_h[m][n]  = f16(acc + bias[n])
+// EPI_RELU_F16      : out_h[m][n]  = f16(max(acc + bias[n], 0))
+// EPI_RESID_F32     : resid[m][n] += acc + bias[n]            (fp32 residual stream)
+// EPI_STORE_F32     : out_f[m][n]  = acc + bias[n]            (fp32 logits / split-K slabs)
+// EPI_RESID_HALF_F32: resid[m][n] += 0.5 * (acc + bias[n])    (macaron half-step FFN)
+// EPI_SILU_F16      : out_h[m][n]  = f16(silu(acc + bias[n]))
+// EPI_GLU_F16       : out_h[m][g*32+c] = f16(a * sigmoid(b)), a/b = columns g*64+c / g*64+32+c
+//                     (W rows interleaved in 32-channel groups at pack time), out width N/2
+// bias may be null for every epilogue.
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+template <int EPI>
+__device__ __forceinline__ f32x4 epi_act(f32x4 v) {
+  if constexpr (EPI == EPI_RELU_F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  } else if constexpr (EPI == EPI_SILU_F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+  }
+  return v;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -36,35 +57,56 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
     bias = nullptr;
     out = (char*)out + (size_t)kz * part_stride;
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, wn = wave & 1;
 
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
+  if constexpr (EPI == EPI_GLU_F16) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n = gt_col(n0, ni, q);
-      f32x4 b = {0.f, 0.f, 0.f, 0.f};
-      if (bias) b = *(const f32x4*)(bias + n);
+      f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;
+      if (bias) {
+        ba = *(const f32x4*)(bias + gt_col(n0, 0, q));
+        bg = *(const f32x4*)(bias + gt_col(n0, 1, q));
+      }
+      const int oc = n0 / 2 + wn * 32 + 8 * q + 4 * hi;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         const int m = gt_row(m0, mi);
-        f32x4 v;
+        half4 h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][mi][q * 4 + e] + b[e];
-        if constexpr (EPI == EPI_RESID_F32) {
-          float* p = (float*)out + (size_t)m * ldo + n;
-          f32x4 o = *(f32x4*)p;
-          *(f32x4*)p = o + v;
-        } else if constexpr (EPI == EPI_STORE_F32) {
-          *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
-        } else {
-          if constexpr (EPI == EPI_RELU_F16) {
+        for (int e = 0; e < 4; ++e)
+          h[e] = (f16)((acc.v[0][mi][q * 4 + e] + ba[e]) * sigmoid_f(acc.v[1][mi][q * 4 + e] + bg[e]));
+        *(half4*)((f16*)out + (size_t)m * ldo + oc) = h;
+      }
+    }
+  } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = gt_col(n0, ni, q);
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = *(const f32x4*)(bias + n);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int m = gt_row(m0, mi);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][mi][q * 4 + e] + b[e];
+          if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_HALF_F32) {
+            float* p = (float*)out + (size_t)m * ldo + n;
+            f32x4 o = *(f32x4*)p;
+            if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
+            *(f32x4*)p = o + v;
+          } else if constexpr (EPI == EPI_STORE_F32) {
+            *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+          } else {
+            v = epi_act<EPI>(v);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
+            *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
           }
-          half4 h;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
-          *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
         }
       }
     }
@@ -87,13 +129,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   g2_mainloop<VAR>(acc, X, W, K, m0, n0, smem);
 
   // ---- epilogue: stage the C tile through LDS (free after the main loop) so the
-  // global stores are whole 512-B row segments instead of 8-B pieces 32 rows apart.
+  // global stores are whole row segments instead of 8-B pieces 32 rows apart.
   // Row stride 528 B: 16-B aligned and 2-way-or-better on the LDS banks.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
   constexpr int CS = G2_CSTRIDE;
-  if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
-    // fp32 residual accumulate / fp32 store, two passes of 128 columns (pass p = the waves' ni block)
+  if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
+    // fp32 outputs, two passes of 128 columns (pass p = the waves' ni block)
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       if (p) __syncthreads();
@@ -106,6 +148,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc.v[p][mi][q * 4 + e] + b[e];
+          if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
           *(f32x4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 32 + 8 * q + 4 * hi) * 4) = v;
         }
       }
@@ -116,10 +159,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int row = wave * 32 + it * 2 + hi;
-        if constexpr (EPI == EPI_RESID_F32)
-          old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
-        else
+        if constexpr (EPI == EPI_STORE_F32)
           old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else
+          old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
       }
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
@@ -127,6 +170,32 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
         *(f32x4*)((float*)out + (size_t)(m0 + row) * ldo + gcol) = old[it] + v;
       }
+    }
+  } else if constexpr (EPI == EPI_GLU_F16) {
+    // 128 output channels per tile: channel wc*32 + 8q + 4hi + e from the wave's (a, gate) blocks
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;
+      if (bias) {
+        ba = *(const f32x4*)(bias + g2_col(n0, 0, q));
+        bg = *(const f32x4*)(bias + g2_col(n0, 1, q));
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          h[e] = (f16)((acc.v[0][mi][q * 4 + e] + ba[e]) * sigmoid_f(acc.v[1][mi][q * 4 + e] + bg[e]));
+        *(half4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 32 + 8 * q + 4 * hi) * 2) = h;
+      }
+    }
+    __syncthreads();
+    const int c = lane & 15;  // 16 lanes x 16 B = one 256-B output row
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = wave * 32 + it * 4 + (lane >> 4);
+      const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
+      *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 / 2 + c * 8) = v;
     }
   } else {
 #pragma unroll
@@ -137,13 +206,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         if (bias) b = *(const f32x4*)(bias + g2_col(n0, ni, q));
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][mi][q * 4 + e] + b[e];
+          v = epi_act<EPI>(v);
           half4 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc.v[ni][mi][q * 4 + e] + b[e];
-            if constexpr (EPI == EPI_RELU_F16) v = fmaxf(v, 0.f);
-            h[e] = (f16)v;
-          }
+          for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
           *(half4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 64 + ni * 32 + 8 * q + 4 * hi) * 2) = h;
         }
       }
@@ -183,21 +252,25 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   static const int var = getenv("SMI_GEMM_VAR") ? atoi(getenv("SMI_GEMM_VAR")) : 0;
   if (EPI == EPI_RELU_F16 || EPI == EPI_RESID_F32) {
     switch (var) {
-      case 1: return launch_var256<EPI, 1>(X, W, bias, out, M, N, K, ldo, stream);
-      case 2: return launch_var256<EPI, 2>(X, W, bias, out, M, N, K, ldo, stream);
-      case 3: return launch_var256<EPI, 3>(X, W, bias, out, M, N, K, ldo, stream);
-      case 4: return launch_var256<EPI, 4>(X, W, bias, out, M, N, K, ldo, stream);
-      case 6: return launch_var256<EPI, 6>(X, W, bias, out, M, N, K, ldo, stream);
-      case 7: return launch_var256<EPI, 7>(X, W, bias, out, M, N, K, ldo, stream);
-      case 8: return launch_var256<EPI, 8>(X, W, bias, out, M, N, K, ldo, stream);
-      case 10: return launch_var256<EPI, 10>(X, W, bias, out, M, N, K, ldo, stream);
-      case 11: return launch_var256<EPI, 11>(X, W, bias, out, M, N, K, ldo, stream);
-      case 12: return launch_var256<EPI, 12>(X, W, bias, out, M, N, K, ldo, stream);
-      case 13: return launch_var256<EPI, 13>(X, W, bias, out, M, N, K, ldo, stream);
-      case 14: return launch_var256<EPI, 14>(X, W, bias, out, M, N, K, ldo, stream);
-      case 16: return launch_var256<EPI, 16>(X, W, bias, out, M, N, K, ldo, stream);
-      case 17: return launch_var256<EPI, 17>(X, W, bias, out, M, N, K, ldo, stream);
-      case 18: return launch_var256<EPI, 18>(X, W, bias, out, M, N, K, ldo, stream);
+#define SMI_VAR_CASE(V) \
+  case V:               \
+    return launch_var256<EPI, V>(X, W, bias, out, M, N, K, ldo, stream);
+      SMI_VAR_CASE(1)
+      SMI_VAR_CASE(2)
+      SMI_VAR_CASE(3)
+      SMI_VAR_CASE(4)
+      SMI_VAR_CASE(6)
+      SMI_VAR_CASE(7)
+      SMI_VAR_CASE(8)
+      SMI_VAR_CASE(10)
+      SMI_VAR_CASE(11)
+      SMI_VAR_CASE(12)
+      SMI_VAR_CASE(13)
+      SMI_VAR_CASE(14)
+      SMI_VAR_CASE(16)
+      SMI_VAR_CASE(17)
+      SMI_VAR_CASE(18)
+#undef SMI_VAR_CASE
     }
   }
 #endif
@@ -230,21 +303,20 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
   // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
-  if (use256) {
-    switch (epi) {
-      case EPI_BIAS_F16: return launch_one256<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
-      case EPI_RELU_F16: return launch_one256<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);
-      case EPI_RESID_F32: return launch_one256<EPI_RESID_F32>(X, W, bias, out, M, N, K, ldo, stream);
-      case EPI_STORE_F32: return launch_one256<EPI_STORE_F32>(X, W, bias, out, M, N, K, ldo, stream);
-    }
-    return hipErrorInvalidValue;
-  }
+#define SMI_EPI_CASE(E)                                                     \
+  case E:                                                                   \
+    return use256 ? launch_one256<E>(X, W, bias, out, M, N, K, ldo, stream) \
+                  : launch_one<E>(X, W, bias, out, M, N, K, ldo, stream);
   switch (epi) {
-    case EPI_BIAS_F16: return launch_one<EPI_BIAS_F16>(X, W, bias, out, M, N, K, ldo, stream);
-    case EPI_RELU_F16: return launch_one<EPI_RELU_F16>(X, W, bias, out, M, N, K, ldo, stream);
-    case EPI_RESID_F32: return launch_one<EPI_RESID_F32>(X, W, bias, out, M, N, K, ldo, stream);
-    case EPI_STORE_F32: return launch_one<EPI_STORE_F32>(X, W, bias, out, M, N, K, ldo, stream);
+    SMI_EPI_CASE(EPI_BIAS_F16)
+    SMI_EPI_CASE(EPI_RELU_F16)
+    SMI_EPI_CASE(EPI_RESID_F32)
+    SMI_EPI_CASE(EPI_STORE_F32)
+    SMI_EPI_CASE(EPI_RESID_HALF_F32)
+    SMI_EPI_CASE(EPI_SILU_F16)
+    SMI_EPI_CASE(EPI_GLU_F16)
   }
+#undef SMI_EPI_CASE
   return hipErrorInvalidValue;
 }
 

@@ -8,7 +8,10 @@ namespace smi {
 
 typedef _Float16 f16;
 
-enum GemmEpilogue { EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3 };
+enum GemmEpilogue {
+  EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3,
+  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6
+};
 
 // C = X[M,K] * W[N,K]^T (+bias, epilogue).  M%128==0, N%128==0, K%64==0.
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
@@ -85,5 +88,23 @@ hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, co
                               int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream);
 hipError_t launch_gather_tokens(const int64_t* src, int src_stride, int col, int32_t* tok, int rows,
                                 hipStream_t stream);
+
+// ---- speech path (speech.hip) ----
+hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
+                        const float* mel_w, const int* mel_range, float* out, hipStream_t stream);
+hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t* cu, int max_len, const float* w,
+                           const float* b, float eps, f16* out, int ldo, hipStream_t stream);
+// x = LN1(x) in place; h = f16(w2 ? LN2(x) : x) (h may be null)
+hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
+                      f16* h, int rows, int d, hipStream_t stream);
+hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
+                                   const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
+                                   int heads, hipStream_t stream);
+hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
+                                 const float* shift, f16* y, int n, int max_len, int d, int ktaps,
+                                 hipStream_t stream);
+hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu, f16* ctx, int n, int d, int heads,
+                                 hipStream_t stream);
+hipError_t launch_broadcast_row(const float* row, float* x, int rows, int d, hipStream_t stream);
 
 }  // namespace smi

@@ -1,0 +1,548 @@
+// Device kernels of the SpeechToEmbedding hot path: Kaldi-style log-mel filterbank,
+// frame stacking + LayerNorm, the conformer block's relative-position attention and
+// depthwise convolution, LayerNorm variants, and the attention pooler's single-query
+// cross-attention.  GEMMs (FFNs, projections, pointwise convolutions) run on the shared
+// MFMA tile engines in gemm.hip.
+//
+// Reference: sonar/inference_pipelines/speech.py:283-308,431-474 (fbank options, frame
+// padding to a multiple of 2), sonar/models/sonar_speech/{factory.py:53-152, model.py:59-77},
+// sonar/nn/encoder_pooler.py:70-89; conformer / Wav2Vec2Frontend / RelativePositionSDPA
+// semantics of fairseq2 ~=0.4 as listed in SURVEY a26-a29.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace smi {
+
+// ================================================================== filterbank
+// One workgroup per frame: 400 samples -> remove DC -> pre-emphasis 0.97 -> povey window ->
+// zero-pad to 512 -> radix-2 FFT in LDS -> power -> 80 triangular mel bins -> log.
+constexpr int FB_WIN = 400, FB_SHIFT = 160, FB_NFFT = 512, FB_BINS = 80;
+
+__global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wave, float scale,
+                                                    const float* __restrict__ window,
+                                                    const float* __restrict__ mel_w,  // [80][256]
+                                                    const int* __restrict__ mel_range,  // [80][2]
+                                                    float* __restrict__ out) {
+  __shared__ float re[FB_NFFT], im[FB_NFFT];
+  __shared__ float red[4];
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* src = wave + (size_t)f * FB_SHIFT;
+  // load (two samples per thread, 400 valid)
+  float a0 = tid < FB_WIN ? src[tid] * scale : 0.f;
+  float a1 = tid + 256 < FB_WIN ? src[tid + 256] * scale : 0.f;
+  float s = wave_sum(a0 + a1);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / FB_WIN;
+  if (tid < FB_WIN) re[tid] = a0 - mean;
+  if (tid + 256 < FB_WIN) re[tid + 256] = a1 - mean;
+  __syncthreads();
+  // pre-emphasis + window, bit-reversed scatter for the in-place DIT FFT
+  float y0 = 0.f, y1 = 0.f;
+  if (tid < FB_WIN) y0 = (re[tid] - 0.97f * re[tid == 0 ? 0 : tid - 1]) * window[tid];
+  if (tid + 256 < FB_WIN) y1 = (re[tid + 256] - 0.97f * re[tid + 255]) * window[tid + 256];
+  __syncthreads();
+  {
+    const int r0 = __brev((unsigned)tid) >> 23, r1 = __brev((unsigned)(tid + 256)) >> 23;
+    re[r0] = y0;
+    im[r0] = 0.f;
+    re[r1] = y1;
+    im[r1] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 1; st <= 9; ++st) {
+    const int half = 1 << (st - 1);
+    const int grp = tid >> (st - 1), pos = tid & (half - 1);
+    const int i0 = grp * (half << 1) + pos, i1 = i0 + half;
+    float sn, cs;
+    sincospif(-(float)pos / (float)half, &sn, &cs);
+    const float xr = re[i1], xi = im[i1];
+    const float tr = xr * cs - xi * sn, ti = xr * sn + xi * cs;
+    const float ur = re[i0], ui = im[i0];
+    re[i0] = ur + tr;
+    im[i0] = ui + ti;
+    re[i1] = ur - tr;
+    im[i1] = ui - ti;
+    __syncthreads();
+  }
+  // power spectrum of bins 0..255 (Kaldi's mel banks do not use the Nyquist bin)
+  const float pw = re[tid] * re[tid] + im[tid] * im[tid];
+  __syncthreads();
+  re[tid] = pw;
+  __syncthreads();
+  if (tid < FB_BINS) {
+    const int k0 = mel_range[tid * 2], k1 = mel_range[tid * 2 + 1];
+    float e = 0.f;
+    for (int k = k0; k < k1; ++k) e += mel_w[tid * 256 + k] * re[k];
+    out[(size_t)f * FB_BINS + tid] = __logf(fmaxf(e, 1.1920929e-07f));
+  }
+}
+
+// per-utterance standardisation over time (unbiased std), one workgroup, thread = mel bin
+__global__ __launch_bounds__(128) void fbank_standardize_kernel(float* __restrict__ fb, int frames) {
+  const int b = threadIdx.x;
+  if (b >= FB_BINS || frames < 2) return;
+  float s = 0.f;
+  for (int f = 0; f < frames; ++f) s += fb[(size_t)f * FB_BINS + b];
+  const float mean = s / frames;
+  float q = 0.f;
+  for (int f = 0; f < frames; ++f) {
+    const float d = fb[(size_t)f * FB_BINS + b] - mean;
+    q += d * d;
+  }
+  const float inv = 1.0f / sqrtf(q / (frames - 1));
+  for (int f = 0; f < frames; ++f) fb[(size_t)f * FB_BINS + b] = (fb[(size_t)f * FB_BINS + b] - mean) * inv;
+}
+
+hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
+                        const float* mel_w, const int* mel_range, float* out, hipStream_t stream) {
+  if (nsamples < FB_WIN) return hipSuccess;
+  const int frames = (int)(1 + (nsamples - FB_WIN) / FB_SHIFT);
+  hipLaunchKernelGGL(fbank_kernel, dim3(frames), dim3(256), 0, stream, wave, scale, window, mel_w, mel_range, out);
+  if (standardize)
+    hipLaunchKernelGGL(fbank_standardize_kernel, dim3(1), dim3(128), 0, stream, out, frames);
+  return hipGetLastError();
+}
+
+// =========================================================== frame stacking + LayerNorm(160)
+// out[row(n, j), 0..159] = f16(LN([fb[n, 2j, :], fb[n, 2j+1, :]])), columns 160..191 zero
+// (K padded to a multiple of 64 for the projection GEMM).  One wave per stacked frame.
+__global__ __launch_bounds__(256) void stack_ln_kernel(const float* __restrict__ fb, int t, int nb,
+                                                       const int32_t* __restrict__ cu,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b, float eps,
+                                                       f16* __restrict__ out, int ldo) {
+  const int n = blockIdx.x;
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int start = cu[n], len = cu[n + 1] - start;
+  if (j >= len) return;
+  const int fd = 2 * nb;  // 160
+  const float* src = fb + ((size_t)n * t + 2 * j) * nb;  // 2 consecutive frames are contiguous
+  float v[3];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < fd ? src[c] : 0.f;
+    s += v[k];
+  }
+  const float mean = wave_sum(s) / fd;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < fd ? v[k] - mean : 0.f;
+    q += v[k] * v[k];
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / fd + eps);
+  f16* o = out + (size_t)(start + j) * ldo;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = lane + 64 * k;
+    if (c < ldo) o[c] = c < fd ? (f16)(v[k] * rstd * w[c] + b[c]) : (f16)0.f;
+  }
+}
+
+hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t* cu, int max_len, const float* w,
+                           const float* b, float eps, f16* out, int ldo, hipStream_t stream) {
+  if (2 * nb > 192 || ldo > 192) return hipErrorInvalidValue;
+  dim3 grid(n, (max_len + 3) / 4);
+  hipLaunchKernelGGL(stack_ln_kernel, grid, dim3(256), 0, stream, fb, t, nb, cu, w, b, eps, out, ldo);
+  return hipGetLastError();
+}
+
+// =============================================================== LayerNorm variants (fp32 stream)
+// x = LN1(x) in place (fp32); h = f16(w2 ? LN2(x) : x).  One wave per row.
+template <int NV>
+__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1,
+                                                  const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, float eps,
+                                                  f16* __restrict__ h, int rows) {
+  constexpr int D = NV * 256;
+  constexpr float inv_d = 1.0f / D;
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* xr = x + (size_t)r * D;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  float mean = wave_sum(s) * inv_d, q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[k][i] -= mean;
+      q += v[k][i] * v[k][i];
+    }
+  float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const f32x4 wv = *(const f32x4*)(w1 + k * 256 + lane * 4);
+    const f32x4 bv = *(const f32x4*)(b1 + k * 256 + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] * rstd * wv[i] + bv[i];
+    *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  if (!h) return;
+  if (w2) {
+    mean = wave_sum(s) * inv_d;
+    q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[k][i] -= mean;
+        q += v[k][i] * v[k][i];
+      }
+    rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const f32x4 wv = *(const f32x4*)(w2 + k * 256 + lane * 4);
+      const f32x4 bv = *(const f32x4*)(b2 + k * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] * rstd * wv[i] + bv[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    half4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f16)v[k][i];
+    *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+  }
+}
+
+hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
+                      f16* h, int rows, int d, hipStream_t stream) {
+  if (rows <= 0) return hipErrorInvalidValue;
+  const int blocks = (rows + 3) / 4;
+#define SMI_LN2_CASE(NV)                                                                              \
+  case NV * 256:                                                                                      \
+    hipLaunchKernelGGL(ln2_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
+                       rows);                                                                         \
+    break;
+  switch (d) {
+    SMI_LN2_CASE(1)
+    SMI_LN2_CASE(2)
+    SMI_LN2_CASE(3)
+    SMI_LN2_CASE(4)
+    SMI_LN2_CASE(8)
+    default: return hipErrorInvalidValue;
+  }
+#undef SMI_LN2_CASE
+  return hipGetLastError();
+}
+
+// ========================================================= relative-position self-attention
+// scores[i][j] = ((q_i + u) . k_j + (q_i + v) . rp[i - j]) / 8, softmax over the clip's frames.
+// Same transposed-score / lane-local-softmax structure as attention.hip; the position term of a
+// 32-key block needs rp rows for the 63 relative offsets the (32 queries x 32 keys) block spans:
+// G[rho][i] = rp[rel_lo + rho] . (q_i + v) comes out of 8 more MFMAs, goes through a per-wave LDS
+// pad and is read back at row (ii - jj + 31), column ii -- bank = ii, conflict-free both ways.
+constexpr int RA_QB = 128, RA_KB = 32;
+
+__global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __restrict__ qkv,
+                                                               const int32_t* __restrict__ cu,
+                                                               const f16* __restrict__ rp, int rp_zero,
+                                                               int rp_rows,
+                                                               const float* __restrict__ u_bias,
+                                                               const float* __restrict__ v_bias,
+                                                               f16* __restrict__ ctx, int d, float sl2e) {
+  __shared__ __attribute__((aligned(16))) char lds[RA_KB * 128 + 64 * 64 + 4 * 64 * 32 * 4];
+  char* Ks = lds;                       // [32 keys][128 B], chunk c of key r at slot c ^ ((r>>1)&7)
+  char* Vt = lds + RA_KB * 128;         // [64 dims][64 B], 8-B key granule g of dim r at g ^ ((r>>2)&7)
+  const int n = blockIdx.x, h = blockIdx.y;
+  const int start = cu[n], len = cu[n + 1] - start;
+  const int q0 = blockIdx.z * RA_QB;
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  float* Gs = (float*)(lds + RA_KB * 128 + 64 * 64) + wave * 64 * 32;  // [64 rho][32 queries]
+  const size_t ld = (size_t)3 * d;
+  const f16* qbase = qkv + (size_t)start * ld + h * 64;
+  const f16* kbase = qbase + d;
+  const f16* vbase = qbase + 2 * d;
+  const f16* rph = rp + h * 64;
+
+  const int i0 = q0 + wave * 32;
+  const int qi = i0 + l31;
+  const f16* qptr = qbase + (size_t)min(qi, len - 1) * ld;
+  half8 qu[4], qv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c0 = (ks * 2 + hi) * 8;
+    const half8 q = *(const half8*)(qptr + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qu[ks][e] = (f16)((float)q[e] + u_bias[h * 64 + c0 + e]);
+      qv[ks][e] = (f16)((float)q[e] + v_bias[h * 64 + c0 + e]);
+    }
+  }
+
+  float m = -1e30f, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+
+  for (int j0 = 0; j0 < len; j0 += RA_KB) {
+    __syncthreads();
+    {  // stage K (row-major, swizzled): 32 keys x 8 chunks = 256 chunks, one per thread
+      const int key = tid >> 3, slot = tid & 7;
+      const int chunk = slot ^ ((key >> 1) & 7);
+      const int krow = min(j0 + key, len - 1);
+      *(half8*)(Ks + tid * 16) = *(const half8*)(kbase + (size_t)krow * ld + chunk * 8);
+    }
+    {  // stage V transposed: thread -> key = tid & 31, dim chunk = tid >> 5
+      const int key = tid & 31, dc = tid >> 5;
+      const int vrow = min(j0 + key, len - 1);
+      const half8 v = *(const half8*)(vbase + (size_t)vrow * ld + dc * 8);
+      const int kg = key >> 2, kw = (key & 3) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int dd = dc * 8 + e;
+        *(f16*)(Vt + dd * 64 + ((kg ^ ((dd >> 2) & 7)) << 3) + kw) = v[e];
+      }
+    }
+    __syncthreads();
+
+    // ---- content term: S^T = K . (Q+u)^T ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 kf = *(const half8*)(Ks + l31 * 128 + (((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4));
+      s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], s, 0, 0, 0);
+    }
+    // ---- position term: G[rho][i] = rp[rel_lo + rho] . (q_i + v), rho = 0..63 ----
+    const int rel_lo = i0 - j0 - 31;
+#pragma unroll
+    for (int gb = 0; gb < 2; ++gb) {
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+      const int row = min(max(rel_lo + gb * 32 + l31 + rp_zero, 0), rp_rows - 1);
+      const f16* rrow = rph + (size_t)row * d;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 rf = *(const half8*)(rrow + (ks * 2 + hi) * 8);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf, qv[ks], g, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho = gb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        Gs[rho * 32 + l31] = g[r];
+      }
+    }
+    // (each wave reads back only what it wrote: no workgroup barrier needed, only LDS ordering)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const float bd = Gs[(l31 - jj + 31) * 32 + l31];
+      const float val = (j0 + jj) < len ? (s[r] + bd) * sl2e : -INFINITY;
+      s[r] = val;
+      mx = fmaxf(mx, val);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    float psum = 0.f;
+    half8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+      psum += p;
+      pf[r >> 3][r & 7] = (f16)p;
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int dd = db * 32 + l31;
+      const char* vrow = Vt + dd * 64;
+      const int sw = (dd >> 2) & 7;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int g0 = 4 * u + hi;
+        const half4 a0 = *(const half4*)(vrow + ((g0 ^ sw) << 3));
+        const half4 a1 = *(const half4*)(vrow + (((g0 + 2) ^ sw) << 3));
+        half8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[e] = a0[e];
+          vf[e + 4] = a1[e];
+        }
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
+      }
+    }
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / ltot;
+  if (qi < len) {
+    f16* op = ctx + (size_t)(start + qi) * d + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
+        *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
+      }
+  }
+}
+
+hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
+                                   const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
+                                   int heads, hipStream_t stream) {
+  if (heads <= 0 || d != heads * 64 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
+  const float sl2e = 0.125f * 1.4426950408889634f;
+  dim3 grid(n, heads, (max_len + RA_QB - 1) / RA_QB);
+  hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias,
+                     v_bias, ctx, d, sl2e);
+  return hipGetLastError();
+}
+
+// ============================================= depthwise conv (k taps, 'same') + BatchNorm + SiLU
+// y[t][c] = silu(scale[c] * sum_k w[c][k] x[t + k - (K-1)/2][c] + shift[c]), zero outside the clip.
+// Workgroup = 32 output frames x 256 channels of one clip; thread = channel (coalesced 512-B rows).
+template <int KT>
+__global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restrict__ x,
+                                                             const int32_t* __restrict__ cu,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             f16* __restrict__ y, int d) {
+  constexpr int TT = 32, HALF = (KT - 1) / 2;
+  const int n = blockIdx.x, t0 = blockIdx.y * TT, c = blockIdx.z * 256 + threadIdx.x;
+  const int start = cu[n], len = cu[n + 1] - start;
+  if (t0 >= len) return;
+  float wk[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) wk[k] = w[(size_t)c * KT + k];
+  const float sc = scale[c], sh = shift[c];
+  float win[KT];  // sliding window x[t - HALF .. t + HALF]
+#pragma unroll
+  for (int k = 0; k < KT - 1; ++k) {
+    const int t = t0 - HALF + k;
+    win[k + 1] = (t >= 0 && t < len) ? (float)x[(size_t)(start + t) * d + c] : 0.f;
+  }
+  for (int tt = 0; tt < TT && t0 + tt < len; ++tt) {
+#pragma unroll
+    for (int k = 0; k < KT - 1; ++k) win[k] = win[k + 1];
+    const int t = t0 + tt + HALF;
+    win[KT - 1] = t < len ? (float)x[(size_t)(start + t) * d + c] : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) acc += wk[k] * win[k];
+    const float v = acc * sc + sh;
+    y[(size_t)(start + t0 + tt) * d + c] = (f16)(v / (1.0f + __expf(-v)));
+  }
+}
+
+hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
+                                 const float* shift, f16* y, int n, int max_len, int d, int ktaps,
+                                 hipStream_t stream) {
+  if (d % 256 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
+  dim3 grid(n, (max_len + 31) / 32, d / 256);
+  switch (ktaps) {
+    case 31:
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d);
+      break;
+    case 7:
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<7>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d);
+      break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ================================================== pooler: one query per clip over its frames
+// q: [n][d] (row per clip), kv: [R][2d] (k | v) packed frames; one wave per (clip, head).
+__global__ __launch_bounds__(256) void pool_attention_kernel(const f16* __restrict__ q,
+                                                             const f16* __restrict__ kv,
+                                                             const int32_t* __restrict__ cu,
+                                                             f16* __restrict__ ctx, int n, int d, int heads,
+                                                             float sl2e) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= n * heads) return;
+  const int c = wid / heads, h = wid % heads;
+  const int lane = threadIdx.x & 63;
+  const int start = cu[c], len = cu[c + 1] - start;
+  const f16* qp = q + (size_t)c * d + h * 64;
+  half8 qf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qf[i] = *(const half8*)(qp + i * 8);
+  const size_t ld = (size_t)2 * d;
+  const f16* kb = kv + (size_t)start * ld + h * 64;
+  float m = -1e30f, l = 0.f, o = 0.f;
+  for (int j0 = 0; j0 < len; j0 += 64) {
+    const int j = j0 + lane;
+    float s = -INFINITY;
+    if (j < len) {
+      const f16* kp = kb + (size_t)j * ld;
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const half8 kk = *(const half8*)(kp + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)qf[i][e] * (float)kk[e];
+      }
+      s = acc * sl2e;
+    }
+    const float m_new = fmaxf(m, wave_max(s));
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    const float p = __builtin_amdgcn_exp2f(s - m_new);
+    l = l * alpha + wave_sum(p);
+    o *= alpha;
+    m = m_new;
+    const int cnt = min(64, len - j0);
+    for (int t = 0; t < cnt; ++t) {
+      const float pt = __shfl(p, t, 64);
+      o += pt * (float)kb[(size_t)(j0 + t) * ld + d + lane];
+    }
+  }
+  ctx[(size_t)c * d + h * 64 + lane] = (f16)(len > 0 ? o / l : 0.f);
+}
+
+hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu, f16* ctx, int n, int d, int heads,
+                                 hipStream_t stream) {
+  if (heads <= 0 || d != heads * 64 || n <= 0) return hipErrorInvalidValue;
+  const float sl2e = 0.125f * 1.4426950408889634f;
+  hipLaunchKernelGGL(pool_attention_kernel, dim3((n * heads + 3) / 4), dim3(256), 0, stream, q, kv, cu, ctx, n, d,
+                     heads, sl2e);
+  return hipGetLastError();
+}
+
+// x[r, :] = row[:] for r < rows (pooler query initialisation)
+__global__ void broadcast_row_kernel(const float* __restrict__ row, float* __restrict__ x, int rows, int d) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)rows * d) x[i] = row[i % d];
+}
+
+hipError_t launch_broadcast_row(const float* row, float* x, int rows, int d, hipStream_t stream) {
+  const size_t total = (size_t)rows * d;
+  hipLaunchKernelGGL(broadcast_row_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, row, x, rows, d);
+  return hipGetLastError();
+}
+
+}  // namespace smi

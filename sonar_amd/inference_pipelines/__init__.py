@@ -1,1 +1,2 @@
 from .text import EmbeddingToTextModelPipeline, TextToEmbeddingModelPipeline  # noqa: F401
+from .speech import SpeechToEmbeddingModelPipeline  # noqa: F401,E402

@@ -25,7 +25,7 @@ def _stream():
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
                                    (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
                                    (256, 256, 8192), (1024, 768, 256)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_tn(lib, m, n, k, epi):
     from sonar_amd import _lib
 
@@ -38,10 +38,19 @@ def test_gemm_tn(lib, m, n, k, epi):
     for sel in ([1, 2] if m % 256 == 0 and n % 256 == 0 else [1]):
         use_bias = not (epi == 3 and sel == 1)  # fp32 store also runs without a bias (logits GEMM)
         ref = base + bias if use_bias else base.clone()
-        if epi == 2:
+        ldo = n
+        if epi in (2, 4):
             resid = torch.randn(m, n, device="cuda", generator=g)
             out = resid.clone()
-            ref = ref + resid
+            ref = resid + (ref if epi == 2 else 0.5 * ref)
+        elif epi == 5:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
+            ref = torch.nn.functional.silu(ref)
+        elif epi == 6:   # GLU over 64-column groups [32 values | 32 gates] (rows of W pre-interleaved)
+            ldo = n // 2
+            out = torch.full((m, ldo), float("nan"), device="cuda", dtype=torch.float16)
+            r4 = ref.view(m, n // 64, 2, 32)
+            ref = (r4[:, :, 0] * torch.sigmoid(r4[:, :, 1])).reshape(m, ldo)
         elif epi == 3:
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
         else:
@@ -49,14 +58,14 @@ def test_gemm_tn(lib, m, n, k, epi):
             if epi == 1:
                 ref = torch.relu(ref)
         _lib.check(lib.smi_gemm_tn(epi | (sel << 8), x.data_ptr(), w.data_ptr(), bias.data_ptr() if use_bias else None,
-                                   out.data_ptr(), m, n, k, n, _stream()))
+                                   out.data_ptr(), m, n, k, ldo, _stream()))
         torch.cuda.synchronize()
         got = out.float()
         assert torch.isfinite(got).all()
         err = (got - ref).abs().max().item()
         scale = max(ref.abs().max().item(), 1.0)
         # fp16 output: half-ulp rounding of the result; fp32 outputs: accumulation order only
-        allowed = (2e-3 if epi < 2 else 2e-5) * scale
+        allowed = (2e-3 if epi in (0, 1, 5, 6) else 2e-5) * scale
         assert err <= allowed, (sel, err, scale)
 
 

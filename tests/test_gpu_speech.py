@@ -1,0 +1,110 @@
+"""GPU parity of the SpeechToEmbedding hot path (filterbank, conformer encoder, attention pooler,
+through the C ABI) against the CPU oracle."""
+import wave
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(layers=2, pool=2):
+    from oracle.speech_encoder import OracleSpeechEncoderConfig
+    from sonar_amd.speech_encoder import SonarSpeechEncoderConfig
+
+    o = OracleSpeechEncoderConfig(model_dim=256, num_layers=layers, num_heads=4, ffn_inner_dim=512, conv_kernel=7,
+                                  pooler_layers=pool, pooler_heads=4, pooler_ffn_dim=384, pooler_vocab=64)
+    c = SonarSpeechEncoderConfig(model_dim=256, num_encoder_layers=layers, num_encoder_attn_heads=4, ffn_inner_dim=512,
+                                 depthwise_conv_kernel_size=7, num_decoder_layers=pool, num_decoder_attn_heads=4,
+                                 decoder_ffn_inner_dim=384, max_frames=512)
+    return o, c
+
+
+def _cos_err(a, b):
+    return (1 - F.cosine_similarity(a.float().cpu(), b.float().cpu(), dim=-1)).abs().max().item()
+
+
+@pytest.mark.parametrize("nsamples", [400, 16000, 80640, 33333])
+@pytest.mark.parametrize("standardize", [False, True])
+def test_fbank_vs_oracle(nsamples, standardize):
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import waveform_to_fbank
+
+    if nsamples == 400 and standardize:
+        pytest.skip("a single frame has no std")
+    g = torch.Generator().manual_seed(nsamples)
+    wav = torch.rand(nsamples, generator=g) * 2 - 1
+    wav = wav * 0.3 + 0.2 * torch.sin(torch.arange(nsamples) * 0.05)
+    ref = OS.kaldi_fbank(wav, standardize=standardize)
+    got = waveform_to_fbank(wav.cuda(), standardize=standardize).cpu()
+    assert got.shape == ref.shape == (1 + (nsamples - 400) // 160, 80)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= (3e-3 if standardize else 2e-3)
+
+
+@pytest.mark.parametrize("ragged", [True, False])
+def test_speech_encoder_vs_oracle(ragged):
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import SpeechEncoderEngine
+
+    ocfg, cfg = _cfgs()
+    params = OS.make_synthetic_params(ocfg, seed=99, std=0.06)
+    g = torch.Generator().manual_seed(7)
+    n, t = 5, 300
+    fb = torch.randn(n, t, 80, generator=g)
+    lens = torch.tensor([300, 97, 2, 158, 299]) if ragged else None
+    if ragged:
+        for i, L in enumerate(lens.tolist()):
+            fb[i, L:] = 0
+    _, ref = OS.speech_encoder_forward(params, ocfg, fb, lens)
+    eng = SpeechEncoderEngine(cfg, params, device="cuda:0")
+    emb = eng.forward(fb.cuda(), lens, torch.float32)
+    torch.cuda.synchronize()
+    assert emb.shape == (n, 256) and torch.isfinite(emb).all()
+    assert _cos_err(emb, ref) <= 1e-3, _cos_err(emb, ref)
+    assert (emb.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+    emb16 = eng.forward(fb.cuda(), lens, torch.float16)
+    assert emb16.dtype == torch.float16 and _cos_err(emb16, ref) <= 1e-3
+    # batching invariance: each clip alone gives the same vector (reference: speech pipeline tests)
+    i = 1 if ragged else 0
+    L = int(lens[i]) if ragged else t
+    L -= L % 2
+    one = eng.forward(fb[i:i + 1, :L].cuda(), None, torch.float32)
+    assert _cos_err(one, emb[i:i + 1]) <= 1e-5
+
+
+def test_speech_pipeline_end_to_end(tmp_path):
+    from oracle import speech_encoder as OS
+    from sonar_amd.inference_pipelines import SpeechToEmbeddingModelPipeline
+    from sonar_amd.speech_encoder import SonarSpeechEncoderModel
+
+    ocfg, cfg = _cfgs(layers=1, pool=1)
+    params = OS.make_synthetic_params(ocfg, seed=5, std=0.06)
+    model = SonarSpeechEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    pipe = SpeechToEmbeddingModelPipeline(model, device=torch.device("cuda:0"))
+    g = torch.Generator().manual_seed(3)
+    wavs = [torch.rand(1, 24000, generator=g) * 2 - 1, torch.rand(1, 17777, generator=g) * 2 - 1,
+            torch.rand(1, 24000, generator=g) * 2 - 1]
+    # the third clip also goes through a 16-bit WAV file (tensor-vs-file equality is a reference test:
+    # tests/integration_tests/test_sonar_speech_pipeline_models.py:28-40)
+    pcm = (wavs[2][0] * 32767).round().clamp(-32768, 32767).to(torch.int16)
+    path = tmp_path / "clip.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.numpy().tobytes())
+    wavs[2] = (pcm.float() / 32768.0).unsqueeze(0)
+    out = pipe.predict([wavs[0], wavs[1], str(path)], batch_size=2)
+    out_t = pipe.predict(wavs, batch_size=3)
+    assert out.shape == (3, 256)
+    assert _cos_err(out, out_t) <= 1e-5
+    # oracle on the oracle's own filterbank
+    feats = [OS.kaldi_fbank(w[0]) for w in wavs]
+    for i, f in enumerate(feats):
+        t = f.shape[0] + f.shape[0] % 2
+        fb = torch.zeros(1, t, 80)
+        fb[0, : f.shape[0]] = f
+        _, ref = OS.speech_encoder_forward(params, ocfg, fb, torch.tensor([f.shape[0]]))
+        assert _cos_err(out[i:i + 1], ref) <= 1e-3
