@@ -79,20 +79,39 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
   }
 }
 
-// per-utterance standardisation over time (unbiased std), one workgroup, thread = mel bin
-__global__ __launch_bounds__(128) void fbank_standardize_kernel(float* __restrict__ fb, int frames) {
-  const int b = threadIdx.x;
-  if (b >= FB_BINS || frames < 2) return;
+// per-utterance standardisation over time (unbiased std): one workgroup of 12 x 80 threads,
+// thread (g, b) walks frames g, g+12, ... of mel bin b; partial sums are combined through LDS.
+__global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restrict__ fb, int frames) {
+  __shared__ float part[12][FB_BINS];
+  __shared__ float stat[2][FB_BINS];
+  const int b = threadIdx.x % FB_BINS, g = threadIdx.x / FB_BINS;
+  if (frames < 2) return;
   float s = 0.f;
-  for (int f = 0; f < frames; ++f) s += fb[(size_t)f * FB_BINS + b];
-  const float mean = s / frames;
+  for (int f = g; f < frames; f += 12) s += fb[(size_t)f * FB_BINS + b];
+  part[g][b] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 12; ++i) t += part[i][b];
+    stat[0][b] = t / frames;
+  }
+  __syncthreads();
+  const float mean = stat[0][b];
   float q = 0.f;
-  for (int f = 0; f < frames; ++f) {
+  for (int f = g; f < frames; f += 12) {
     const float d = fb[(size_t)f * FB_BINS + b] - mean;
     q += d * d;
   }
-  const float inv = 1.0f / sqrtf(q / (frames - 1));
-  for (int f = 0; f < frames; ++f) fb[(size_t)f * FB_BINS + b] = (fb[(size_t)f * FB_BINS + b] - mean) * inv;
+  part[g][b] = q;
+  __syncthreads();
+  if (g == 0) {
+    float t = 0.f;
+    for (int i = 0; i < 12; ++i) t += part[i][b];
+    stat[1][b] = 1.0f / sqrtf(t / (frames - 1));
+  }
+  __syncthreads();
+  const float inv = stat[1][b];
+  for (int f = g; f < frames; f += 12) fb[(size_t)f * FB_BINS + b] = (fb[(size_t)f * FB_BINS + b] - mean) * inv;
 }
 
 hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
@@ -101,7 +120,7 @@ hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int st
   const int frames = (int)(1 + (nsamples - FB_WIN) / FB_SHIFT);
   hipLaunchKernelGGL(fbank_kernel, dim3(frames), dim3(256), 0, stream, wave, scale, window, mel_w, mel_range, out);
   if (standardize)
-    hipLaunchKernelGGL(fbank_standardize_kernel, dim3(1), dim3(128), 0, stream, out, frames);
+    hipLaunchKernelGGL(fbank_standardize_kernel, dim3(1), dim3(960), 0, stream, out, frames);
   return hipGetLastError();
 }
 
