@@ -24,8 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BATCH, SEQ = 1024, 128
-D, F, L, H, V = 1024, 8192, 24, 16, 256206
+from tools.synth import BATCH, SEQ, D, F, L, H, V, text_encoder_state_dict  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic flops: per token per layer 8 d^2 + 4 d F + 4 S d
 FLOPS_PER_SENTENCE = SEQ * L * (8 * D * D + 4 * D * F + 4 * SEQ * D)
@@ -34,32 +33,6 @@ FFN1_FLOPS_PER_LAUNCH = 2.0 * BATCH * SEQ * F * D  # one launch = the whole 1310
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
-
-
-def synthetic_state_dict(device, seed=1234):
-    """Random-init weights of the `basic` architecture, generated on the GPU in fp16
-    (Linear/Embedding ~ N(0, 0.02^2), LN weight 1 + N(0, 0.02^2))."""
-    import torch
-
-    g = torch.Generator(device=device).manual_seed(seed)
-
-    def rnd(*shape, dtype=torch.float16, mean=0.0):
-        return (torch.randn(*shape, device=device, generator=g) * 0.02 + mean).to(dtype)
-
-    sd = {"encoder_frontend.embed.weight": rnd(V, D),
-          "layer_norm.weight": rnd(D, dtype=torch.float32, mean=1.0),
-          "layer_norm.bias": rnd(D, dtype=torch.float32)}
-    for i in range(L):
-        p = f"encoder.layers.{i}."
-        for name, shape in (("self_attn.q_proj", (D, D)), ("self_attn.k_proj", (D, D)),
-                            ("self_attn.v_proj", (D, D)), ("self_attn.output_proj", (D, D)),
-                            ("ffn.inner_proj", (F, D)), ("ffn.output_proj", (D, F))):
-            sd[p + name + ".weight"] = rnd(*shape)
-            sd[p + name + ".bias"] = rnd(shape[0], dtype=torch.float32)
-        for name in ("self_attn_layer_norm", "ffn_layer_norm"):
-            sd[p + name + ".weight"] = rnd(D, dtype=torch.float32, mean=1.0)
-            sd[p + name + ".bias"] = rnd(D, dtype=torch.float32)
-    return sd
 
 
 def cpu_baseline(n_sent=96):
@@ -88,6 +61,54 @@ def cpu_baseline(n_sent=96):
             "sample": f"{n_sent} sentences x {SEQ} tokens, full 24-layer fp32 model, torch CPU oracle, 1 timed pass ({dt:.1f} s)"}
 
 
+def decoder_leg(dev, n=256, steps=64):
+    """BASELINE configs[4]: text_sonar_basic_decoder, beam 5, fp16, batch 256, `steps` forced steps."""
+    import torch
+
+    from sonar_amd.text_decoder import TextDecoderEngine, get_text_decoder_config
+    from tools.synth import text_decoder_state_dict
+
+    eng = TextDecoderEngine(get_text_decoder_config("basic"), text_decoder_state_dict(dev), device=dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    emb = torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=g), dim=-1).half() * 0.2
+    eng.generate(emb[:8], [3, 256047], beam_size=5, min_gen_len=4, max_gen_len=(0, 4))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.generate(emb, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"text_sonar_basic_decoder beam 5 fp16, batch {n}, {steps + 1} decode steps (EOS blocked), eng_Latn prompt",
+            "ms": dt * 1e3, "ms_per_step": dt * 1e3 / (steps + 1), "sentences_per_s": n / dt,
+            "tokens_per_s": n * (steps + 1) / dt}
+
+
+def speech_leg(dev, n=64):
+    """BASELINE configs[3]: sonar_speech_encoder_eng, 64 clips x 10 s @ 16 kHz (fbank + conformer + pooler)."""
+    import torch
+
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveform_to_fbank
+    from tools.synth import speech_encoder_state_dict
+
+    eng = SpeechEncoderEngine(get_speech_encoder_config("english"), speech_encoder_state_dict(dev), device=dev)
+    g = torch.Generator(device=dev).manual_seed(4)
+    wavs = torch.rand(n, 160000, device=dev, generator=g) * 2 - 1
+
+    def run():
+        feats = torch.stack([waveform_to_fbank(wavs[i]) for i in range(n)])
+        return eng.forward(feats, None, torch.float16)
+
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"workload": f"sonar_speech_encoder_eng fp16, {n} clips x 10 s @ 16 kHz, GPU fbank + 24 conformer blocks + pooler",
+            "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-xsim", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the decoder (C5) and speech (C4) legs")
     ap.add_argument("--xsim-nx", type=int, default=65536, help="X rows per rank")
     ap.add_argument("--xsim-ny", type=int, default=1 << 20, help="total Y rows (sharded over ranks)")
     ap.add_argument("--cpu-sentences", type=int, default=96)
@@ -123,7 +145,7 @@ def main():
 
     cfg = get_text_encoder_config("basic")
     t0 = time.time()
-    sd = synthetic_state_dict(dev)
+    sd = text_encoder_state_dict(dev)
     model = SonarTextTransformerEncoderModel(cfg, sd, device=dev, dtype=torch.float16, max_tokens_hint=BATCH * SEQ)
     del sd
     torch.cuda.empty_cache()
@@ -174,7 +196,7 @@ def main():
             traffic = json.load(open(tfile)).get("gemm_ffn1_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "kernel": "gemm_tn_kernel<EPI_RELU_F16> (FFN inner projection, M=131072 N=8192 K=1024)",
+    roofline = {"bound": "mfma", "kernel": "gemm_tn256_kernel<EPI_RELU_F16> (FFN inner projection, M=131072 N=8192 K=1024)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None, "traffic": traffic,
                 "avg_launch_ms": ffn1_ms, "launches": ffn1["launches"],
@@ -223,9 +245,24 @@ def main():
               "includes": "row normalisation, Y all-gather (N>1), top-1 mining"}
         del x_local, y_local, yn_all
 
+    # ------------------------------------------------- secondary configs (BASELINE C4 / C5), N = 1 only
+    extra = {}
+    if world == 1 and not args.no_extras:
+        del model
+        torch.cuda.empty_cache()
+        try:
+            extra["decoder"] = decoder_leg(dev)
+        except Exception as e:  # the headline line must survive a failure here
+            extra["decoder"] = {"error": repr(e)}
+        try:
+            extra["speech"] = speech_leg(dev)
+        except Exception as e:
+            extra["speech"] = {"error": repr(e)}
+        model = None
+
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        del model
+        model = None
         torch.cuda.empty_cache()
         cb = cpu_baseline(args.cpu_sentences)
 
@@ -240,7 +277,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cb,
             "encoder_tflops": value * FLOPS_PER_SENTENCE / 1e12,
             "encoder_frac_of_mfma_peak": value * FLOPS_PER_SENTENCE / 1e12 / (MFMA_PEAK_TFLOPS * world),
-            "kernels": kernels, "xsim": xs,
+            "kernels": kernels, "xsim": xs, **extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

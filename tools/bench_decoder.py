@@ -10,19 +10,9 @@ def main():
     cfg = get_text_decoder_config("basic")
     d, f, V = 1024, 8192, cfg.vocab_info.size
     dev = "cuda:0"
+    from tools.synth import text_decoder_state_dict
+    sd = text_decoder_state_dict(dev)
     g = torch.Generator(device=dev).manual_seed(1)
-    rnd = lambda *s, dt=torch.float16, mean=0.0: (torch.randn(*s, device=dev, generator=g) * 0.02 + mean).to(dt)
-    sd = {"decoder_frontend.embed.weight": rnd(V, d), "decoder.layer_norm.weight": rnd(d, dt=torch.float32, mean=1.0),
-          "decoder.layer_norm.bias": rnd(d, dt=torch.float32)}
-    for i in range(24):
-        p = f"decoder.layers.{i}."
-        for att in ("self_attn", "encoder_decoder_attn"):
-            for lin in ("q_proj", "k_proj", "v_proj", "output_proj"):
-                sd[p + f"{att}.{lin}.weight"] = rnd(d, d); sd[p + f"{att}.{lin}.bias"] = rnd(d, dt=torch.float32)
-        sd[p + "ffn.inner_proj.weight"] = rnd(f, d); sd[p + "ffn.inner_proj.bias"] = rnd(f, dt=torch.float32)
-        sd[p + "ffn.output_proj.weight"] = rnd(d, f); sd[p + "ffn.output_proj.bias"] = rnd(d, dt=torch.float32)
-        for ln in ("self_attn_layer_norm", "encoder_decoder_attn_layer_norm", "ffn_layer_norm"):
-            sd[p + ln + ".weight"] = rnd(d, dt=torch.float32, mean=1.0); sd[p + ln + ".bias"] = rnd(d, dt=torch.float32)
     eng = TextDecoderEngine(cfg, sd, device=dev)
     del sd
     emb = torch.nn.functional.normalize(torch.randn(n, d, device=dev, generator=g), dim=-1).half() * 0.2

@@ -10,37 +10,9 @@ def main():
     cfg = get_speech_encoder_config("english")
     d, f = 1024, 4096
     dev = "cuda:0"
+    from tools.synth import speech_encoder_state_dict
+    sd = speech_encoder_state_dict(dev)
     g = torch.Generator(device=dev).manual_seed(1)
-    rnd = lambda *s, dt=torch.float16, mean=0.0, std=0.02: (torch.randn(*s, device=dev, generator=g) * std + mean).to(dt)
-    f32 = torch.float32
-    sd = {"encoder_frontend.post_extract_layer_norm.weight": rnd(160, dt=f32, mean=1.0), "encoder_frontend.post_extract_layer_norm.bias": rnd(160, dt=f32),
-          "encoder_frontend.model_dim_proj.weight": rnd(d, 160), "encoder_frontend.model_dim_proj.bias": rnd(d, dt=f32),
-          "layer_norm.weight": rnd(d, dt=f32, mean=1.0), "layer_norm.bias": rnd(d, dt=f32),
-          "encoder_pooler.decoder_frontend.embed.weight": rnd(1024, d), "encoder_pooler.projection_out.weight": rnd(d, d)}
-    for i in range(24):
-        p = f"encoder.layers.{i}."
-        for ln in ("ffn1_layer_norm", "self_attn_layer_norm", "conv_layer_norm", "ffn2_layer_norm", "layer_norm"):
-            sd[p + ln + ".weight"] = rnd(d, dt=f32, mean=1.0); sd[p + ln + ".bias"] = rnd(d, dt=f32)
-        for ffn in ("ffn1", "ffn2"):
-            sd[p + ffn + ".inner_proj.weight"] = rnd(f, d); sd[p + ffn + ".inner_proj.bias"] = rnd(f, dt=f32)
-            sd[p + ffn + ".output_proj.weight"] = rnd(d, f); sd[p + ffn + ".output_proj.bias"] = rnd(d, dt=f32)
-        for lin in ("q_proj", "k_proj", "v_proj", "output_proj"):
-            sd[p + f"self_attn.{lin}.weight"] = rnd(d, d); sd[p + f"self_attn.{lin}.bias"] = rnd(d, dt=f32)
-        sd[p + "self_attn.sdpa.r_proj.weight"] = rnd(d, d)
-        sd[p + "self_attn.sdpa.u_bias"] = rnd(16, 64, dt=f32); sd[p + "self_attn.sdpa.v_bias"] = rnd(16, 64, dt=f32)
-        sd[p + "conv.pointwise_conv1.weight"] = rnd(2 * d, d, 1); sd[p + "conv.depthwise_conv.weight"] = rnd(d, 1, 31, dt=f32, std=0.1)
-        sd[p + "conv.batch_norm.weight"] = rnd(d, dt=f32, mean=1.0); sd[p + "conv.batch_norm.bias"] = rnd(d, dt=f32)
-        sd[p + "conv.batch_norm.running_mean"] = rnd(d, dt=f32); sd[p + "conv.batch_norm.running_var"] = rnd(d, dt=f32).abs() + 0.5
-        sd[p + "conv.pointwise_conv2.weight"] = rnd(d, d, 1)
-    for i in range(3):
-        p = f"encoder_pooler.decoder.layers.{i}."
-        for att in ("self_attn", "encoder_decoder_attn"):
-            for lin in ("q_proj", "k_proj", "v_proj", "output_proj"):
-                sd[p + f"{att}.{lin}.weight"] = rnd(d, d); sd[p + f"{att}.{lin}.bias"] = rnd(d, dt=f32)
-            sd[p + att + "_layer_norm.weight"] = rnd(d, dt=f32, mean=1.0); sd[p + att + "_layer_norm.bias"] = rnd(d, dt=f32)
-        sd[p + "ffn.inner_proj.weight"] = rnd(f, d); sd[p + "ffn.inner_proj.bias"] = rnd(f, dt=f32)
-        sd[p + "ffn.output_proj.weight"] = rnd(d, f); sd[p + "ffn.output_proj.bias"] = rnd(d, dt=f32)
-        sd[p + "ffn_layer_norm.weight"] = rnd(d, dt=f32, mean=1.0); sd[p + "ffn_layer_norm.bias"] = rnd(d, dt=f32)
     eng = SpeechEncoderEngine(cfg, sd, device=dev)
     del sd
     wavs = torch.rand(n, 160000, device=dev, generator=g) * 2 - 1

@@ -9,13 +9,13 @@ python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/${TAG}_smoke.log 2>&1
 python bench.py --steps 10 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} --output-format csv -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof -o ${TAG} --output-format csv -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 cd $OLDPWD
 python tools/summarize_prof.py $OUT/${TAG}_prof > $OUT/${TAG}_kernel_stats.txt 2>&1
 if [ "$2" == "pmc" ]; then
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --kernel-trace -d $OUT/${TAG}_pmc_$C -o ${TAG} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xsim > /dev/null 2> $OUT/${TAG}_pmc_$C.err
+    rocprofv3 --pmc $C --kernel-trace -d $OUT/${TAG}_pmc_$C -o ${TAG} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-xsim --no-extras > /dev/null 2> $OUT/${TAG}_pmc_$C.err
   done
   cd $OLDPWD
   python tools/summarize_pmc.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE > $OUT/${TAG}_pmc_summary.txt 2>&1
