@@ -1,2 +1,3 @@
-from .text import EmbeddingToTextModelPipeline, TextToEmbeddingModelPipeline  # noqa: F401
-from .speech import SpeechToEmbeddingModelPipeline  # noqa: F401,E402
+from .text import (EmbeddingToTextModelPipeline, TextToEmbeddingModelPipeline,  # noqa: F401
+                   TextToTextModelPipeline)
+from .speech import SpeechToEmbeddingModelPipeline, SpeechToTextModelPipeline  # noqa: F401,E402

@@ -108,3 +108,30 @@ class SpeechToEmbeddingModelPipeline(torch.nn.Module):
         if not results:
             return torch.empty((0, self.model.model_dim), dtype=self.model.dtype, device=self.device)
         return torch.cat(results, dim=0)
+
+
+class SpeechToTextModelPipeline(torch.nn.Module):
+    """sonar/inference_pipelines/speech.py:310-399: audio -> sentence vector (speech engine) -> text
+    (decoder engine, beam search)."""
+
+    def __init__(self, encoder, decoder, tokenizer, device: torch.device = CPU,
+                 fbank_dtype: torch.dtype = torch.float32) -> None:
+        super().__init__()
+        from .text import EmbeddingToTextModelPipeline
+
+        self.s2vec = SpeechToEmbeddingModelPipeline(encoder, device=device, fbank_dtype=fbank_dtype)
+        self.vec2t = EmbeddingToTextModelPipeline(decoder, tokenizer, device=device)
+        self.tokenizer = self.vec2t.tokenizer
+        self.device = self.s2vec.device
+
+    @torch.inference_mode()
+    def predict(self, input: Sequence[Union[str, Path, torch.Tensor]], target_lang: str, batch_size: int = 3,
+                n_parallel: int = 1, pad_idx: int = 0, n_prefetched_batches: int = 2, progress_bar: bool = False,
+                **generator_kwargs) -> List[str]:
+        items = list(input)
+        out: List[str] = []
+        for i in range(0, len(items), batch_size):
+            chunk = items[i:i + batch_size]
+            emb = self.s2vec.predict(chunk, batch_size=len(chunk), pad_idx=pad_idx)
+            out.extend(self.vec2t.predict(emb, target_lang=target_lang, batch_size=len(chunk), **generator_kwargs))
+        return out

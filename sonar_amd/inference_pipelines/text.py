@@ -238,3 +238,35 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
             for i in range(emb.shape[0]):
                 texts.append(decode(toks[i, 0, : int(lens[i, 0])]))
         return texts
+
+
+class TextToTextModelPipeline(torch.nn.Module):
+    """sonar/inference_pipelines/text.py:56-137: text -> sentence vector (encoder engine) -> text
+    (decoder engine, beam search).  `max_seq_len` is clamped to the decoder's positional range as the
+    reference does (text.py:104-107)."""
+
+    def __init__(self, encoder, decoder, tokenizer: Union[str, Path, NllbTokenizer], device: torch.device = CPU,
+                 dtype: Optional[torch.dtype] = None) -> None:
+        super().__init__()
+        self.t2vec = TextToEmbeddingModelPipeline(encoder, tokenizer, device=device, dtype=dtype)
+        self.vec2t = EmbeddingToTextModelPipeline(decoder, self.t2vec.tokenizer, device=device, dtype=dtype)
+        self.tokenizer = self.t2vec.tokenizer
+        self.device = self.t2vec.device
+
+    @torch.inference_mode()
+    def predict(self, input: Union[Path, Sequence[str]], source_lang: str, target_lang: str, batch_size: int = 5,
+                progress_bar: bool = False, **generator_kwargs) -> List[str]:
+        model_max = self.vec2t.model.max_target_seq_len
+        generator_kwargs["max_seq_len"] = min(model_max, generator_kwargs.get("max_seq_len", model_max))
+        if isinstance(input, (str, Path)):
+            with open(Path(input), "r", encoding="utf-8") as fh:
+                input = [line.rstrip("\n") for line in fh]
+        texts = list(input)
+        out: List[str] = []
+        batches: Iterable = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
+        if progress_bar:
+            batches = add_progress_bar(batches, inputs=texts, batch_size=batch_size)
+        for chunk in batches:
+            emb = self.t2vec.predict(chunk, source_lang=source_lang, batch_size=len(chunk))
+            out.extend(self.vec2t.predict(emb, target_lang=target_lang, batch_size=len(chunk), **generator_kwargs))
+        return out

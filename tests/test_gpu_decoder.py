@@ -132,3 +132,56 @@ def test_embedding_to_text_pipeline(setup, tmp_path):
     assert same >= 5
     with pytest.raises(NotImplementedError):
         pipe.predict(emb, target_lang="fra_Latn", sampler=object())
+
+
+def test_text_to_text_and_speech_to_text_chain(setup, tmp_path):
+    """TextToText / SpeechToText pipelines == decode(encode(.)) of the separate pipelines."""
+    import sentencepiece as spm
+
+    from oracle import speech_encoder as OS
+    from oracle import text_encoder as OE
+    from sonar_amd.inference_pipelines import (EmbeddingToTextModelPipeline, SpeechToTextModelPipeline,
+                                               TextToEmbeddingModelPipeline, TextToTextModelPipeline)
+    from sonar_amd.speech_encoder import SonarSpeechEncoderConfig, SonarSpeechEncoderModel
+    from sonar_amd.text_decoder import ConditionalTransformerDecoderModel
+    from sonar_amd.text_encoder import SonarTextEncoderConfig, SonarTextTransformerEncoderModel, VocabularyInfo
+    from sonar_amd.tokenizer import NllbTokenizer
+
+    OD, _, _, _ = setup
+    words = ["hello", "world", "my", "name", "is", "paul", "teacher", "working", "bonjour", "monde"]
+    corpus = tmp_path / "c.txt"
+    g = torch.Generator().manual_seed(0)
+    with open(corpus, "w") as fh:
+        for _ in range(300):
+            n = int(torch.randint(2, 10, (1,), generator=g))
+            fh.write(" ".join(words[int(i)] for i in torch.randint(0, len(words), (n,), generator=g)) + "\n")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "toy"), vocab_size=40,
+                                   model_type="unigram", hard_vocab_limit=False, bos_id=1, eos_id=2,
+                                   unk_id=0, pad_id=-1, minloglevel=2)
+    tok = NllbTokenizer(str(tmp_path / "toy.model"))
+    v = tok.vocab_info.size
+    ocfg, cfg = _cfgs(vocab=v)
+    dec = ConditionalTransformerDecoderModel(cfg, OD.make_synthetic_params(ocfg, seed=77, std=0.09), device="cuda:0")
+    oe = OE.OracleTextEncoderConfig(model_dim=256, num_layers=2, num_heads=4, ffn_inner_dim=512, vocab_size=v)
+    ecfg = SonarTextEncoderConfig(model_dim=256, num_encoder_layers=2, num_encoder_attn_heads=4, ffn_inner_dim=512,
+                                  vocab_info=VocabularyInfo(size=v), _from_fairseq=True)
+    enc = SonarTextTransformerEncoderModel(ecfg, OE.make_synthetic_params(oe, seed=3, std=0.08), device="cuda:0",
+                                           dtype=torch.float16)
+    dev = torch.device("cuda:0")
+    texts = ["hello world", "my name is paul", "bonjour monde"]
+    t2t = TextToTextModelPipeline(enc, dec, tok, device=dev)
+    got = t2t.predict(texts, source_lang="eng_Latn", target_lang="fra_Latn", batch_size=2, max_gen_len=(1, 6))
+    emb = TextToEmbeddingModelPipeline(enc, tok, device=dev).predict(texts, source_lang="eng_Latn")
+    want = EmbeddingToTextModelPipeline(dec, tok, device=dev).predict(emb, target_lang="fra_Latn", max_gen_len=(1, 6))
+    assert got == want and len(got) == 3
+
+    so = OS.OracleSpeechEncoderConfig(model_dim=256, num_layers=1, num_heads=4, ffn_inner_dim=512, conv_kernel=7,
+                                      pooler_layers=1, pooler_heads=4, pooler_ffn_dim=384, pooler_vocab=64)
+    scfg = SonarSpeechEncoderConfig(model_dim=256, num_encoder_layers=1, num_encoder_attn_heads=4, ffn_inner_dim=512,
+                                    depthwise_conv_kernel_size=7, num_decoder_layers=1, num_decoder_attn_heads=4,
+                                    decoder_ffn_inner_dim=384, max_frames=512)
+    senc = SonarSpeechEncoderModel(scfg, OS.make_synthetic_params(so, seed=5, std=0.06), device="cuda:0")
+    wavs = [torch.rand(1, 16000, generator=g) * 2 - 1, torch.rand(1, 20000, generator=g) * 2 - 1]
+    s2t = SpeechToTextModelPipeline(senc, dec, tok, device=dev)
+    out = s2t.predict(wavs, target_lang="eng_Latn", max_gen_len=(1, 5))
+    assert len(out) == 2 and all(isinstance(t, str) for t in out)
