@@ -39,9 +39,12 @@ constexpr int G2_BN = 256;
 constexpr int G2_BK = 32;
 constexpr int G2_THREADS = 512;
 constexpr int G2_SLOT_BYTES = (G2_BM + G2_BN) * G2_BK * 2;  // 32 KiB
-constexpr int G2_LDS_BYTES = 4 * G2_SLOT_BYTES;             // 128 KiB
+#ifndef G2_RING
+#define G2_RING 4  // 5 (all 160 KiB of LDS) measured no faster: buffering is not the limiter
+#endif
+constexpr int G2_LDS_BYTES = G2_RING * G2_SLOT_BYTES;       // 128 KiB (ring of 4) / 160 KiB (5)
 constexpr int G2_CSTRIDE = 528;                            // epilogue C-tile row stride in LDS
-constexpr int G2_KERNEL_LDS_BYTES = G2_BM * G2_CSTRIDE;      // 132 KiB >= ring
+constexpr int G2_KERNEL_LDS_BYTES = G2_LDS_BYTES > G2_BM * G2_CSTRIDE ? G2_LDS_BYTES : G2_BM * G2_CSTRIDE;
 
 struct GemmTile256Acc {
   f32x16 v[2][4];  // [ni][mi]
@@ -56,7 +59,7 @@ struct GemmTile256Acc {
 template <int PART = 3>
 __device__ __forceinline__ void g2_issue(const f16* const (&xg)[2], const f16* const (&wg)[2], int t,
                                          char* smem, int wave, int kt = -1) {
-  char* slot = smem + (t & 3) * G2_SLOT_BYTES + wave * 2048;
+  char* slot = smem + (G2_RING == 4 ? (t & 3) : (t % G2_RING)) * G2_SLOT_BYTES + wave * 2048;
   const int koff = (kt < 0 ? t : kt) * G2_BK;
   if (PART & 1) {
     glds16(xg[0] + koff, slot);
@@ -125,7 +128,9 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
   g2_issue(xg, wg, 0, smem, wave, 0);
   if (nt > 1) g2_issue(xg, wg, 1, smem, wave, 1 * KSTEP);
   if (nt > 2) g2_issue(xg, wg, 2, smem, wave, 2 * KSTEP);
-  if (nt > 2) SMI_WAIT_VMCNT(8);
+  if (G2_RING == 5 && nt > 3) g2_issue(xg, wg, 3, smem, wave, 3 * KSTEP);
+  if (G2_RING == 5 && nt > 3) SMI_WAIT_VMCNT(12);
+  else if (nt > 2) SMI_WAIT_VMCNT(8);
   else if (nt > 1) SMI_WAIT_VMCNT(4);
   else SMI_WAIT_VMCNT(0);
   SMI_BARRIER();            // slice 0 complete for everyone
@@ -133,7 +138,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
 
   for (int t = 0; t < nt; ++t) {
     // ---- read segment: fragments of slice t -> VGPRs, DMA for slice t+3 ----
-    const char* slot = smem + (t & 3) * G2_SLOT_BYTES;
+    const char* slot = smem + (G2_RING == 4 ? (t & 3) : (t % G2_RING)) * G2_SLOT_BYTES;
     half8 fx[2][4], fw[2][2];
     if ((VAR != 4 && VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) || t == 0)
 #pragma unroll
@@ -154,6 +159,18 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       // slice t+3 is issued later, inside the multiply segment: only t+1, t+2 outstanding here
       if (t + 2 < nt) SMI_WAIT_VMCNT(4);
       else SMI_WAIT_VMCNT(0);
+    } else if (G2_RING == 5 && VAR == 0) {
+      // ring of 5: slice t+4 goes into the slot slice t-1 just vacated; t+2..t+4 stay in flight
+      if (t + 4 < nt) {
+        g2_issue(xg, wg, t + 4, smem, wave, (t + 4) * KSTEP);
+        SMI_WAIT_VMCNT(12);
+      } else if (t + 3 < nt) {
+        SMI_WAIT_VMCNT(8);
+      } else if (t + 2 < nt) {
+        SMI_WAIT_VMCNT(4);
+      } else {
+        SMI_WAIT_VMCNT(0);
+      }
     } else if (t + 3 < nt) {
       if (VAR == 7) g2_issue<1>(xg, wg, t + 3, smem, wave);
       else if (VAR == 8 || VAR == 14) g2_issue(xg, wg, t + 3, smem, wave, 0);
