@@ -295,17 +295,32 @@ int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny
                   void* stream);
 
 /* Building blocks (exported for the parity tests and microbenchmarks) ------ */
+/* TILE-MAJOR operand layout (SMI_GEMM_IN_TM / SMI_GEMM_OUT_TM, `tile_major` arguments): a K-major
+ * fp16 matrix A[rows][k] (rows % 256 == 0, k % 32 == 0) stored as 16-KiB blocks, block
+ * (r/256, c/32) at element offset ((r/256)*(k/32) + c/32) * 8192, and inside a block element
+ * (rr = r%256, cc = c%32) at rr*32 + (((cc/8) ^ ((rr>>2)&3)) << 3) + cc%8 -- the LDS image of the
+ * 256x256 tile engine, so one K slice of a tile is one linear 16 KiB read.  The encoder keeps
+ * every GEMM operand (weights, LayerNorm / attention / FFN-inner outputs) in this layout. */
+#define SMI_GEMM_IN_TM (1 << 12)  /* x and w are tile-major (m, n % 256 == 0) */
+#define SMI_GEMM_OUT_TM (1 << 13) /* f16 output tile-major, as the next GEMM's x (needs IN_TM, ldo == n) */
+/* dst <- tile-major(src) (inverse == 0) or dst <- row-major(src) (inverse != 0); f16, device. */
+int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_t k, int32_t inverse,
+                        void* stream);
 /* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi & 0xff: 0 f16 out, 1 f16 ReLU out,
- * 2 fp32 residual accumulate (out += ...), 3 fp32 store (bias may be NULL);
- * epi >> 8 selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0).
+ * 2 fp32 residual accumulate (out += ...), 3 fp32 store, 4 fp32 residual += 0.5 * (...),
+ * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide) (bias may be NULL);
+ * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
+ * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1).
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);
+/* out = f16(LN(x) * w + b); tile_major != 0: out in the tile-major layout ((rows+255)/256*256 rows allocated) */
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out_f16,
-                  int32_t rows, int32_t d, void* stream);
-/* qkv: f16 [t, 3*d] packed rows; cu_seqlens: device int32 [n+1]; ctx: f16 [t, d] */
+                  int32_t rows, int32_t d, int32_t tile_major, void* stream);
+/* qkv: f16 [t, 3*d] packed rows; cu_seqlens: device int32 [n+1]; ctx: f16 [t, d]
+ * (tile_major != 0: tile-major, (t+255)/256*256 rows allocated) */
 int smi_attention(const void* qkv_f16, const int32_t* cu_seqlens, void* ctx_f16, int32_t n,
-                  int32_t max_len, int32_t d, int32_t heads, void* stream);
+                  int32_t max_len, int32_t d, int32_t heads, int32_t tile_major, void* stream);
 
 #ifdef __cplusplus
 }

@@ -91,6 +91,8 @@ struct smi_text_encoder {
   int64_t cu_cap = 0;
   int cu_next = 0;
   int64_t weight_bytes = 0;
+  // every GEMM operand (weights, h, ctx, ffn) in the tile-major layout of common.hpp
+  bool tile_major = false;
   // optional per-launch event timing
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -170,6 +172,16 @@ struct ProfScope {
   }
 };
 
+// w (row-major [rows][K] fp16) -> tile-major, in a fresh buffer
+int to_tile_major(DevBuf& w, int rows, int K) {
+  DevBuf t;
+  HIP_TRY(t.alloc(w.bytes));
+  HIP_TRY(launch_pack_tile_major(w.as<f16>(), t.as<f16>(), rows, K, 0, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  w = std::move(t);
+  return SMI_OK;
+}
+
 int check_cfg(const smi_text_encoder_config& c) {
   if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
     return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must equal num_heads %d * 64", c.model_dim,
@@ -224,6 +236,7 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
   up(w->final_layer_norm_w, d, false, e->lnf_w, "layer_norm.weight");
   up(w->final_layer_norm_b, d, false, e->lnf_b, "layer_norm.bias");
   e->layers.resize(cfg->num_layers);
+  e->tile_major = f % 256 == 0;  // d % 256 == 0 always (check_cfg)
   for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
     const smi_text_encoder_layer& s = w->layers[l];
     Layer& L = e->layers[l];
@@ -260,6 +273,12 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
           rc = fail(he == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "packing qkv: %s",
                     hipGetErrorString(he));
       }
+    }
+    if (rc == SMI_OK && e->tile_major) {
+      rc = to_tile_major(L.w_qkv, 3 * (int)d, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_o, (int)d, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_1, (int)f, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_2, (int)d, (int)f);
     }
   }
   if (rc == SMI_OK && max_tokens_hint > 0) rc = ensure_workspace(e, (max_tokens_hint + 255) / 256 * 256);
@@ -342,23 +361,29 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
                             c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream)); }
+  // x (fp32 residual stream) and qkv stay row-major; h, ctx, ffn and the weights are tile-major
+  const int tm = e->tile_major;
+  const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   for (int l = 0; l < c.num_layers; ++l) {
     Layer& L = e->layers[l];
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream)); }
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
-    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d,
-                           3 * d, stream)); }
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | in_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
+                           d, 3 * d, stream)); }
     { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
-    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream)); }
+    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d, stream)); }
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32 | in_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
+                           stream)); }
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream)); }
+    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
-    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream)); }
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f,
+                           stream)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d, stream)); }
+    HIP_TRY(launch_gemm_tn(EPI_RESID_F32 | in_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
+                           stream)); }
   }
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
@@ -416,33 +441,50 @@ int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_
 }
 
 // -------------------------------------------------------- building blocks
+int smi_pack_tile_major(const void* src, void* dst, int32_t rows, int32_t k, int32_t inverse,
+                        void* stream) {
+  if (!src || !dst || src == dst) return fail(SMI_ERR_INVALID_ARG, "bad argument");
+  if (rows <= 0 || rows % 256 || k <= 0 || k % 32)
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major needs rows %% 256 == 0 and k %% 32 == 0 (rows=%d k=%d)", rows, k);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_pack_tile_major((const f16*)src, (f16*)dst, rows, k, inverse, (hipStream_t)stream));
+  return SMI_OK;
+}
+
 int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, void* out, int32_t m,
                 int32_t n, int32_t k, int32_t ldo, void* stream) {
   if (!x || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
-  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || (epi & 0xff) > 6 || (epi >> 8) > 2 ||
-      epi < 0 || ldo < ((epi & 0xff) == 6 ? n / 2 : n) || ((epi >> 8) == 2 && (m % 256 || n % 256)))
+  const int e = epi & 0xff, sel = (epi >> 8) & 0xf;
+  const bool in_tm = epi & GEMM_IN_TM, out_tm = epi & GEMM_OUT_TM;
+  if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 6 || sel > 2 || m <= 0 || m % 128 ||
+      n <= 0 || n % 128 || k <= 0 || k % 64 || ldo < (e == 6 ? n / 2 : n) || (sel == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
+  if (in_tm && (m % 256 || n % 256 || (e != 0 && e != 2 && e != 3 && !(out_tm && e == 1))))
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major gemm: m=%d n=%d epi=%d", m, n, epi);
+  if (out_tm && (!in_tm || ldo != n || e > 1))
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs, ldo == n, epilogue 0/1");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));
   return SMI_OK;
 }
 
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out, int32_t rows,
-                  int32_t d, void* stream) {
+                  int32_t d, int32_t tile_major, void* stream) {
   if (!x || !w || !b || !out || rows <= 0) return fail(SMI_ERR_INVALID_ARG, "bad argument");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
-  hipError_t e = launch_layernorm(x, w, b, eps, (f16*)out, rows, d, (hipStream_t)stream);
+  hipError_t e = launch_layernorm(x, w, b, eps, (f16*)out, rows, d, (hipStream_t)stream, tile_major != 0);
   if (e == hipErrorInvalidValue) return fail(SMI_ERR_UNSUPPORTED, "layernorm d=%d unsupported", d);
   HIP_TRY(e);
   return SMI_OK;
 }
 
 int smi_attention(const void* qkv, const int32_t* cu, void* ctx, int32_t n, int32_t max_len,
-                  int32_t d, int32_t heads, void* stream) {
+                  int32_t d, int32_t heads, int32_t tile_major, void* stream) {
   if (!qkv || !cu || !ctx) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (heads <= 0 || d != heads * 64) return fail(SMI_ERR_UNSUPPORTED, "head_dim must be 64");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
-  HIP_TRY(launch_attention((const f16*)qkv, cu, (f16*)ctx, n, max_len, d, heads, (hipStream_t)stream));
+  HIP_TRY(launch_attention((const f16*)qkv, cu, (f16*)ctx, n, max_len, d, heads, (hipStream_t)stream,
+                           tile_major != 0));
   return SMI_OK;
 }
 

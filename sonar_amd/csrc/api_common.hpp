@@ -49,6 +49,16 @@ struct DevBuf {
     o.p = nullptr;
     o.bytes = 0;
   }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      bytes = o.bytes;
+      o.p = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
   ~DevBuf() { release(); }
   void release() {
     if (p) (void)hipFree(p);

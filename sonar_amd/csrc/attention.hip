@@ -23,6 +23,9 @@ namespace smi {
 constexpr int AT_QB = 128;  // queries per workgroup
 constexpr int AT_KB = 64;   // keys per K/V tile
 
+// TM: ctx is written in the tile-major GEMM operand layout (common.hpp) -- a wave then stores
+// 2 KiB runs (32 rows x 64 B of one k-block) instead of 8-B pieces one row stride apart.
+template <bool TM>
 __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         f16* __restrict__ ctx, int d, float sl2e) {
@@ -165,17 +168,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
         half4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
-        *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
+        if constexpr (TM)
+          *(half4*)(ctx + tm_offset(start + qi, h * 64 + db * 32 + 8 * q + 4 * hi, d)) = v;
+        else
+          *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
       }
   }
 }
 
 hipError_t launch_attention(const f16* qkv, const int32_t* cu, f16* ctx, int N, int max_len, int d,
-                            int heads, hipStream_t stream) {
+                            int heads, hipStream_t stream, int ctx_tm) {
   if (heads <= 0 || d != heads * 64 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;  // Dh^-0.5 * log2(e)
   dim3 grid(N, heads, (max_len + AT_QB - 1) / AT_QB);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e);
+  if (ctx_tm)
+    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e);
+  else
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e);
   return hipGetLastError();
 }
 

@@ -43,4 +43,16 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// TILE-MAJOR operand layout of a K-major fp16 matrix A[R][K] (R % 256 == 0, K % 32 == 0): block
+// (r/256, k/32) is 16 KiB contiguous and holds the LDS image the 256x256 tile engine wants (row
+// rr = r%256 at rr*64 B, 16-B chunk c = (k%32)/8 at slot c ^ ((rr>>2)&3)).  A K slice of a tile is
+// then ONE linear 16 KiB burst instead of 256 pieces of 64 B (gemm_tile256.hpp).
+constexpr int TM_ROWS = 256;
+constexpr int TM_BLOCK = TM_ROWS * 32;  // elements per block
+// element offset of A[r][k]
+__host__ __device__ __forceinline__ size_t tm_offset(int r, int k, int K) {
+  const int rr = r & 255, c = (k >> 3) & 3;
+  return ((size_t)(r >> 8) * (K >> 5) + (k >> 5)) * TM_BLOCK + rr * 32 + ((c ^ ((rr >> 2) & 3)) << 3) + (k & 7);
+}
+
 }  // namespace smi

@@ -3,8 +3,6 @@
 // sonar/models/sonar_text/factory.py:130-153 and, for the conformer, fairseq2's
 // ConformerBlock built by sonar/models/sonar_speech/factory.py:64-71), fp16 in, fp32
 // accumulate on v_mfma_f32_32x32x16_f16, with the epilogues fused.
-#include <cstdlib>
-
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -35,7 +33,9 @@ __device__ __forceinline__ f32x4 epi_act(f32x4 v) {
   return v;
 }
 
-template <int EPI>
+// LAYOUT: 0 = row-major operands and output; 1 = tile-major X and W (common.hpp), row-major
+// output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N).
+template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
   // the consumer sums the slabs (decode-time GEMMs have too few tiles to fill 256 CUs otherwise)
   const int kz = blockIdx.y;
   const int klen = K / ksplit;
-  gt_mainloop(acc, X, W, K, m0, n0, smem, kz * klen, klen);
+  gt_mainloop<(LAYOUT > 0)>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
   if (kz > 0) {
     bias = nullptr;
     out = (char*)out + (size_t)kz * part_stride;
@@ -105,7 +105,10 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
             half4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
-            *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
+            if constexpr (LAYOUT == 2)
+              *(half4*)((f16*)out + tm_offset(m, n, N)) = h;
+            else
+              *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
           }
         }
       }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
 }
 
 // Same epilogues on the 256x256 ping-pong tile engine (gemm_tile256.hpp).
-template <int EPI, int VAR = 0>
+template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
 
   GemmTile256Acc acc;
-  g2_mainloop<VAR>(acc, X, W, K, m0, n0, smem);
+  g2_mainloop<(LAYOUT > 0), (LAYOUT > 0)>(acc, X, W, K, m0, n0, smem);
 
   // ---- epilogue: stage the C tile through LDS (free after the main loop) so the
   // global stores are whole row segments instead of 8-B pieces 32 rows apart.
@@ -218,103 +221,104 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       }
     }
     __syncthreads();
-    const int c = lane & 31;
+    if constexpr (LAYOUT == 2) {
+      // the tile is 8 tile-major blocks (k-blocks n0/32 .. n0/32+7 of row block m0/256) of 16 KiB;
+      // every wave instruction stores 1 KiB (16 rows x 64 B) linearly
+      f16* blk0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5)) * TM_BLOCK;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = wave * 32 + it * 2 + hi;
-      const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
-      *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
+      for (int it = 0; it < 16; ++it) {
+        const int piece = wave * 16 + it;
+        const int j = piece >> 4, i = piece & 15;
+        const int row = i * 16 + (lane >> 2);
+        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+        const f32x4 v = *(const f32x4*)(smem + row * CS + (j * 32 + chunk * 8) * 2);
+        *(f32x4*)(blk0 + (size_t)j * TM_BLOCK + i * 512 + lane * 8) = v;
+      }
+    } else {
+      const int c = lane & 31;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = wave * 32 + it * 2 + hi;
+        const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
+        *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
+      }
     }
   }
 }
 
-template <int EPI, int VAR>
-static hipError_t launch_var256(const f16* X, const f16* W, const float* bias, void* out, int M,
+template <int EPI, int LAYOUT>
+static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
                                 int N, int K, int ldo, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, VAR>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G2_KERNEL_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int grid = (M / G2_BM) * (N / G2_BN);
-  hipLaunchKernelGGL((gemm_tn256_kernel<EPI, VAR>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
+  hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
                      stream, X, W, bias, out, M, N, K, ldo);
   return hipGetLastError();
 }
 
-template <int EPI>
-static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
-                                int N, int K, int ldo, hipStream_t stream) {
-#ifdef SMI_GEMM_ABLATION
-  // timing ablations of the main loop (wrong results when != 0); see gemm_tile256.hpp
-  static const int var = getenv("SMI_GEMM_VAR") ? atoi(getenv("SMI_GEMM_VAR")) : 0;
-  if (EPI == EPI_RELU_F16 || EPI == EPI_RESID_F32) {
-    switch (var) {
-#define SMI_VAR_CASE(V) \
-  case V:               \
-    return launch_var256<EPI, V>(X, W, bias, out, M, N, K, ldo, stream);
-      SMI_VAR_CASE(1)
-      SMI_VAR_CASE(2)
-      SMI_VAR_CASE(3)
-      SMI_VAR_CASE(4)
-      SMI_VAR_CASE(6)
-      SMI_VAR_CASE(7)
-      SMI_VAR_CASE(8)
-      SMI_VAR_CASE(10)
-      SMI_VAR_CASE(11)
-      SMI_VAR_CASE(12)
-      SMI_VAR_CASE(13)
-      SMI_VAR_CASE(14)
-      SMI_VAR_CASE(16)
-      SMI_VAR_CASE(17)
-      SMI_VAR_CASE(18)
-#undef SMI_VAR_CASE
-    }
-  }
-#endif
-  return launch_var256<EPI, 0>(X, W, bias, out, M, N, K, ldo, stream);
-}
-
-template <int EPI>
+template <int EPI, int LAYOUT = 0>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int grid = (M / GT_BM) * (N / GT_BN);
-  hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(grid, ksplit), dim3(GT_THREADS), GT_LDS_BYTES, stream, X,
-                     W, bias, out, M, N, K, ldo, ksplit, part_stride);
+  hipLaunchKernelGGL((gemm_tn_kernel<EPI, LAYOUT>), dim3(grid, ksplit), dim3(GT_THREADS), GT_LDS_BYTES,
+                     stream, X, W, bias, out, M, N, K, ldo, ksplit, part_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out,
                           int M, int N, int K, int ldo, hipStream_t stream) {
-  // epi_sel = epilogue | (kernel selector << 8): 0 auto, 1 force 128x128, 2 force 256x256
-  const int epi = epi_sel & 0xff, sel = epi_sel >> 8;
+  // epi_sel = epilogue | (engine << 8) | layout flags: engine 0 auto, 1 force 128x128, 2 force
+  // 256x256; GEMM_IN_TM = X and W tile-major, GEMM_OUT_TM = fp16 output tile-major (needs IN_TM)
+  const int epi = epi_sel & 0xff, sel = (epi_sel >> 8) & 0xf;
+  const bool in_tm = epi_sel & GEMM_IN_TM, out_tm = epi_sel & GEMM_OUT_TM;
   if (M % GT_BM || N % GT_BN || K % GT_BK || M <= 0) return hipErrorInvalidValue;
+  if (in_tm && (M % TM_ROWS || N % TM_ROWS)) return hipErrorInvalidValue;
+  if (out_tm && (!in_tm || ldo != N)) return hipErrorInvalidValue;
   const bool can256 = M % G2_BM == 0 && N % G2_BN == 0;
   if (sel == 2 && !can256) return hipErrorInvalidValue;
   // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
   // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
-#define SMI_EPI_CASE(E)                                                     \
-  case E:                                                                   \
-    return use256 ? launch_one256<E>(X, W, bias, out, M, N, K, ldo, stream) \
-                  : launch_one<E>(X, W, bias, out, M, N, K, ldo, stream);
+#define SMI_EPI_CASE(E, L)                                                     \
+  case E:                                                                      \
+    return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \
+                  : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
+  if (out_tm) {  // fp16 outputs that feed the next GEMM
+    switch (epi) {
+      SMI_EPI_CASE(EPI_BIAS_F16, 2)
+      SMI_EPI_CASE(EPI_RELU_F16, 2)
+    }
+    return hipErrorInvalidValue;
+  }
+  if (in_tm) {
+    switch (epi) {
+      SMI_EPI_CASE(EPI_BIAS_F16, 1)
+      SMI_EPI_CASE(EPI_RESID_F32, 1)
+      SMI_EPI_CASE(EPI_STORE_F32, 1)
+    }
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
-    SMI_EPI_CASE(EPI_BIAS_F16)
-    SMI_EPI_CASE(EPI_RELU_F16)
-    SMI_EPI_CASE(EPI_RESID_F32)
-    SMI_EPI_CASE(EPI_STORE_F32)
-    SMI_EPI_CASE(EPI_RESID_HALF_F32)
-    SMI_EPI_CASE(EPI_SILU_F16)
-    SMI_EPI_CASE(EPI_GLU_F16)
+    SMI_EPI_CASE(EPI_BIAS_F16, 0)
+    SMI_EPI_CASE(EPI_RELU_F16, 0)
+    SMI_EPI_CASE(EPI_RESID_F32, 0)
+    SMI_EPI_CASE(EPI_STORE_F32, 0)
+    SMI_EPI_CASE(EPI_RESID_HALF_F32, 0)
+    SMI_EPI_CASE(EPI_SILU_F16, 0)
+    SMI_EPI_CASE(EPI_GLU_F16, 0)
   }
 #undef SMI_EPI_CASE
   return hipErrorInvalidValue;

@@ -68,8 +68,11 @@ __device__ __forceinline__ void gt_compute(GemmTileAcc& acc, const char* stage, 
 }
 
 // K loop for the 128x128 tile at (m0, n0) over columns [k0, k0 + klen) of X: [*, K] and
-// W: [*, K] (row-major, row stride K).  Rows m0..m0+127 of X and n0..n0+127 of W must be
-// readable.  k0 % 64 == 0, klen % 64 == 0 (klen < K: one slice of a split-K GEMM).
+// W: [*, K] (row-major, row stride K; or both in the tile-major layout of common.hpp when TM:
+// the per-lane DMA source address absorbs the layout, the LDS image is the same).  Rows
+// m0..m0+127 of X and n0..n0+127 of W must be readable.  k0 % 64 == 0, klen % 64 == 0
+// (klen < K: one slice of a split-K GEMM).
+template <bool TM = false>
 __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restrict__ X,
                                             const f16* __restrict__ W, int K, int m0, int n0,
                                             char* smem, int k0 = 0, int klen = -1) {
@@ -87,9 +90,15 @@ __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restr
     const int c = wave * 4 + q;
     const int row = c * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    xg[q] = X + (size_t)(m0 + row) * K + k0 + chunk * 8;
-    wg[q] = W + (size_t)(n0 + row) * K + k0 + chunk * 8;
+    if constexpr (TM) {
+      xg[q] = X + tm_offset(m0 + row, k0 + chunk * 8, K);
+      wg[q] = W + tm_offset(n0 + row, k0 + chunk * 8, K);
+    } else {
+      xg[q] = X + (size_t)(m0 + row) * K + k0 + chunk * 8;
+      wg[q] = W + (size_t)(n0 + row) * K + k0 + chunk * 8;
+    }
   }
+  constexpr int kstep = TM ? 2 * TM_BLOCK : GT_BK;  // elements per K tile along the source
 
   // Fragment read offsets: row = w*64 + blk*32 + (lane&31); f(row) = ((lane&31)>>1)&7.
   const int l31 = lane & 31, hi = lane >> 5;
@@ -111,7 +120,7 @@ __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restr
     // barrier; after it tile t is visible to every wave and every wave has
     // finished reading the other stage.
     __syncthreads();
-    if (t + 1 < nt) gt_issue(xg, wg, (t + 1) * GT_BK, smem + ((t + 1) & 1) * GT_STAGE_BYTES, wave);
+    if (t + 1 < nt) gt_issue(xg, wg, (t + 1) * kstep, smem + ((t + 1) & 1) * GT_STAGE_BYTES, wave);
     gt_compute(acc, smem + (t & 1) * GT_STAGE_BYTES, xrow_off, wrow_off, t_sw);
   }
 }

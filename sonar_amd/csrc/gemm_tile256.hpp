@@ -1,23 +1,31 @@
 // 256x256 fp16 MFMA tile engine, 8 waves, 4-slot K=32 LDS ring, ping-pong wave
 // groups.  C[m][n] = sum_k X[m][k] * W[n][k], both operands K-major.
 //
-// Why this shape on MI355X (numbers from profiles/ and MI355X_MICROARCH.md):
-//  * a 128x128 tile pulls 512 KiB through L2 per 33.5 MFLOP: at >1 PFLOP/s that
-//    is >60% of the 34 TB/s aggregate L2 bandwidth; 256x256 halves it;
+// Why this shape on MI355X (measurements in DESIGN.md 3.1 / profiles/):
+//  * a 128x128 tile pulls 512 KiB through L2 per 33.5 MFLOP; 256x256 halves it;
 //  * one workgroup of 8 waves owns the CU (128 KiB LDS): 2 waves per SIMD.  The
 //    waves of a SIMD are put in different GROUPS (waves 0-3 / 4-7) that run the
 //    same loop one barrier interval apart: while one wave of the SIMD issues its
 //    12 ds_read_b128 + 4 global_load_lds for a K slice, its partner runs the 16
-//    MFMAs of the previous slice, so the matrix pipe never waits for LDS;
+//    MFMAs of the previous slice;
 //  * the LDS ring holds 4 K=32 slices; DMA for slice t+3 is issued while slice t
 //    is consumed and is waited for with a COUNTED s_waitcnt vmcnt(8) (never 0 in
-//    steady state), so ~4 barrier intervals (~2k cycles) of L2/HBM latency are
-//    covered.  Barriers are raw s_barrier: __syncthreads() would drain the DMA
-//    queue (vmcnt(0)) every interval.
+//    steady state).  Barriers are raw s_barrier: __syncthreads() would drain the
+//    DMA queue (vmcnt(0)) every interval.  A 5-slot ring (all 160 KiB) measured
+//    no faster: the loop is bound by the operand stream and by power (the shader
+//    clock drops from 2.0 to ~1.6 GHz once the stream runs beside the MFMAs).
+//
+// Operand layouts (per operand, template flags XTM / WTM):
+//  * row-major  A[r][k]: a slice is 256 rows x 64 B, rows K*2 bytes apart;
+//  * TILE-MAJOR: block (r/256, k/32) is 16 KiB contiguous and already holds the LDS image
+//    (row rr at rr*64, 16-B chunk c at slot c ^ ((rr>>2)&3)), so a slice is ONE contiguous
+//    16 KiB burst and every DMA instruction copies 1 KiB linearly.  Measured +26 % on the bare
+//    operand stream and +7 % on the full GEMM versus row-major: 64-B pieces
+//    2-16 KiB apart are a poor DRAM-page / L2-channel pattern.  Every producer in the
+//    encoder (LayerNorm, attention, the FFN-inner epilogue, weight packing) emits it directly.
 //
 // LDS slice layout: X rows [256][64 B] then W rows [256][64 B]; 16-B chunk c of
-// row r sits at slot c ^ ((r>>2)&3) (swizzle applied on the DMA source address,
-// undone by the ds_read address) -> conflict-free ds_read_b128 for the
+// row r sits at slot c ^ ((r>>2)&3) -> conflict-free ds_read_b128 for the
 // 32x32x16 operand fragments.
 //
 // Hazard bookkeeping (intervals are the spans between consecutive barriers;
@@ -39,12 +47,9 @@ constexpr int G2_BN = 256;
 constexpr int G2_BK = 32;
 constexpr int G2_THREADS = 512;
 constexpr int G2_SLOT_BYTES = (G2_BM + G2_BN) * G2_BK * 2;  // 32 KiB
-#ifndef G2_RING
-#define G2_RING 4  // 5 (all 160 KiB of LDS) measured no faster: buffering is not the limiter
-#endif
-constexpr int G2_LDS_BYTES = G2_RING * G2_SLOT_BYTES;       // 128 KiB (ring of 4) / 160 KiB (5)
+constexpr int G2_LDS_BYTES = 4 * G2_SLOT_BYTES;             // 128 KiB
 constexpr int G2_CSTRIDE = 528;                            // epilogue C-tile row stride in LDS
-constexpr int G2_KERNEL_LDS_BYTES = G2_LDS_BYTES > G2_BM * G2_CSTRIDE ? G2_LDS_BYTES : G2_BM * G2_CSTRIDE;
+constexpr int G2_KERNEL_LDS_BYTES = G2_BM * G2_CSTRIDE;      // 132 KiB >= ring
 
 struct GemmTile256Acc {
   f32x16 v[2][4];  // [ni][mi]
@@ -56,32 +61,39 @@ struct GemmTile256Acc {
 #define SMI_LGKM0_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SMI_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int PART = 3>
-__device__ __forceinline__ void g2_issue(const f16* const (&xg)[2], const f16* const (&wg)[2], int t,
-                                         char* smem, int wave, int kt = -1) {
-  char* slot = smem + (G2_RING == 4 ? (t & 3) : (t % G2_RING)) * G2_SLOT_BYTES + wave * 2048;
-  const int koff = (kt < 0 ? t : kt) * G2_BK;
-  if (PART & 1) {
-    glds16(xg[0] + koff, slot);
-    glds16(xg[1] + koff, slot + 1024);
-  }
-  if (PART & 2) {
-    glds16(wg[0] + koff, slot + G2_BM * G2_BK * 2);
-    glds16(wg[1] + koff, slot + G2_BM * G2_BK * 2 + 1024);
+// Per-wave DMA source pointers of the two 1-KiB pieces this wave copies for each operand.
+template <bool TM>
+__device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row0, int wave, int lane,
+                                       const f16* (&ag)[2], int& kstep) {
+  if constexpr (TM) {
+    // block (row0/256, kb) starts at ((row0/256)*(K/32) + kb) * 8192 elements; piece i at i*512
+    const f16* base = A + (size_t)(row0 >> 8) * (K >> 5) * TM_BLOCK;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ag[q] = base + (wave * 2 + q) * 512 + lane * 8;
+    kstep = TM_BLOCK;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = (wave * 2 + q) * 16 + (lane >> 2);
+      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      ag[q] = A + (size_t)(row0 + row) * K + chunk * 8;
+    }
+    kstep = G2_BK;
   }
 }
 
-// X: [*, K] row-major, W: [*, K]; rows m0..m0+255 / n0..n0+255 readable; K % 32 == 0.
-// VAR is a timing-ablation switch (0 = product; others give WRONG results):
-//   1 no in-loop DMA, 2 DMA reads full 128-B lines (wrong rows), 3 no MFMA,
-//   4 no DMA + fragments read once, 6 DMA issued but never waited for,
-//   7 half the DMA, 8 DMA always re-reads slice 0 (cache-hot), 10 DMA issued inside the
-//   multiply segment (CORRECT results), 11 half the fragment reads (ks=1 reuses ks=0),
-//   12 no MFMA + full-line DMA, 13 DMA only (no MFMA, no fragment reads, no barriers),
-//   14 as 13 but cache-hot addresses, 16 as 13 but plain global_load_dwordx4 to VGPRs (no LDS),
-//   17 as 13 with tile-major (contiguous 16 KiB per slice) source addresses, 18 full kernel with
-//   tile-major source addresses (wrong data, right traffic pattern).
-template <int VAR = 0>
+__device__ __forceinline__ void g2_issue(const f16* const (&xg)[2], const f16* const (&wg)[2], int xoff,
+                                         int woff, int t, char* smem, int wave) {
+  char* slot = smem + (t & 3) * G2_SLOT_BYTES + wave * 2048;
+  glds16(xg[0] + xoff, slot);
+  glds16(xg[1] + xoff, slot + 1024);
+  glds16(wg[0] + woff, slot + G2_BM * G2_BK * 2);
+  glds16(wg[1] + woff, slot + G2_BM * G2_BK * 2 + 1024);
+}
+
+// X: [*, K], W: [*, K] (row-major or tile-major per XTM / WTM); rows m0..m0+255 / n0..n0+255
+// readable; K % 32 == 0.
+template <bool XTM = false, bool WTM = false>
 __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __restrict__ X,
                                             const f16* __restrict__ W, int K, int m0, int n0,
                                             char* smem) {
@@ -92,25 +104,9 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
 
   const f16* xg[2];
   const f16* wg[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    int row = (wave * 2 + q) * 16 + (lane >> 2);
-    int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    if constexpr (VAR == 2 || VAR == 12) {
-      row = (wave * 2 + q) * 8 + (lane >> 3);
-      chunk = lane & 7;
-    }
-    xg[q] = X + (size_t)(m0 + row) * K + chunk * 8;
-    wg[q] = W + (size_t)(n0 + row) * K + chunk * 8;
-    if constexpr (VAR == 17 || VAR == 18) {
-      // block (rb, kb) of 256 rows x 32 k is 16 KiB contiguous; slice t advances by 8192 halfs.
-      // (koff = t*32 is added later: scale it to t*8192 by pre-multiplying the base and using
-      // a 256x stride: emulate with pointer arithmetic below)
-      xg[q] = X + (size_t)(m0 / 256) * (size_t)K * 256 + (wave * 2 + q) * 512 + lane * 8;
-      wg[q] = W + (size_t)(n0 / 256) * (size_t)K * 256 + (wave * 2 + q) * 512 + lane * 8;
-    }
-  }
-  constexpr int KSTEP = (VAR == 17 || VAR == 18) ? 256 : 1;  // slice stride multiplier
+  int xstep, wstep;
+  g2_src<XTM>(X, K, m0, wave, lane, xg, xstep);
+  g2_src<WTM>(W, K, n0, wave, lane, wg, wstep);
 
   const int l31 = lane & 31, hi = lane >> 5;
   const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
@@ -125,70 +121,35 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
 
   const int nt = K / G2_BK;
-  g2_issue(xg, wg, 0, smem, wave, 0);
-  if (nt > 1) g2_issue(xg, wg, 1, smem, wave, 1 * KSTEP);
-  if (nt > 2) g2_issue(xg, wg, 2, smem, wave, 2 * KSTEP);
-  if (G2_RING == 5 && nt > 3) g2_issue(xg, wg, 3, smem, wave, 3 * KSTEP);
-  if (G2_RING == 5 && nt > 3) SMI_WAIT_VMCNT(12);
-  else if (nt > 2) SMI_WAIT_VMCNT(8);
+  g2_issue(xg, wg, 0, 0, 0, smem, wave);
+  if (nt > 1) g2_issue(xg, wg, xstep, wstep, 1, smem, wave);
+  if (nt > 2) g2_issue(xg, wg, 2 * xstep, 2 * wstep, 2, smem, wave);
+  if (nt > 2) SMI_WAIT_VMCNT(8);
   else if (nt > 1) SMI_WAIT_VMCNT(4);
   else SMI_WAIT_VMCNT(0);
-  SMI_BARRIER();            // slice 0 complete for everyone
+  SMI_BARRIER();               // slice 0 complete for everyone
   if (wr == 1) SMI_BARRIER();  // group 1 runs one interval behind
 
   for (int t = 0; t < nt; ++t) {
     // ---- read segment: fragments of slice t -> VGPRs, DMA for slice t+3 ----
-    const char* slot = smem + (G2_RING == 4 ? (t & 3) : (t % G2_RING)) * G2_SLOT_BYTES;
+    const char* slot = smem + (t & 3) * G2_SLOT_BYTES;
     half8 fx[2][4], fw[2][2];
-    if ((VAR != 4 && VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) || t == 0)
 #pragma unroll
-    for (int ks = 0; ks < (VAR == 11 ? 1 : 2); ++ks) {
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) fw[ks][ni] = *(const half8*)(slot + ((woff + ni * 2048) ^ (ks << 5)));
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
     }
-    if constexpr (VAR == 11) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fw[1][ni] = fw[0][ni];
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fx[1][mi] = fx[0][mi];
-    }
-    if (VAR == 1 || VAR == 4) {
-    } else if (VAR == 10) {
-      // slice t+3 is issued later, inside the multiply segment: only t+1, t+2 outstanding here
-      if (t + 2 < nt) SMI_WAIT_VMCNT(4);
-      else SMI_WAIT_VMCNT(0);
-    } else if (G2_RING == 5 && VAR == 0) {
-      // ring of 5: slice t+4 goes into the slot slice t-1 just vacated; t+2..t+4 stay in flight
-      if (t + 4 < nt) {
-        g2_issue(xg, wg, t + 4, smem, wave, (t + 4) * KSTEP);
-        SMI_WAIT_VMCNT(12);
-      } else if (t + 3 < nt) {
-        SMI_WAIT_VMCNT(8);
-      } else if (t + 2 < nt) {
-        SMI_WAIT_VMCNT(4);
-      } else {
-        SMI_WAIT_VMCNT(0);
-      }
-    } else if (t + 3 < nt) {
-      if (VAR == 7) g2_issue<1>(xg, wg, t + 3, smem, wave);
-      else if (VAR == 8 || VAR == 14) g2_issue(xg, wg, t + 3, smem, wave, 0);
-      else if (VAR == 16) {
-        const int koff = (t + 3) * G2_BK;
-        half8 a0 = *(const half8*)(xg[0] + koff), a1 = *(const half8*)(xg[1] + koff);
-        half8 a2 = *(const half8*)(wg[0] + koff), a3 = *(const half8*)(wg[1] + koff);
-        asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3));
-      }
-      else g2_issue(xg, wg, t + 3, smem, wave, (t + 3) * KSTEP);
-      if (VAR == 7) SMI_WAIT_VMCNT(4);
-      else if (VAR != 6) SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
+    if (t + 3 < nt) {
+      g2_issue(xg, wg, (t + 3) * xstep, (t + 3) * wstep, t + 3, smem, wave);
+      SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
     } else if (t + 2 < nt) {
       SMI_WAIT_VMCNT(4);
     } else {
       SMI_WAIT_VMCNT(0);
     }
-    if (VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) SMI_LGKM0_BARRIER();
+    SMI_LGKM0_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
     // ---- multiply segment ----
     __builtin_amdgcn_s_setprio(1);
@@ -198,20 +159,10 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
-        {
-          if constexpr (VAR == 3 || VAR == 12 || VAR == 13 || VAR == 14 || VAR == 16 || VAR == 17) {
-            asm volatile("" ::"v"(fw[ks][ni]), "v"(fx[ks][mi]));
-          } else {
-            acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
-          }
-          if constexpr (VAR == 10) {
-            if (ks == 0 && ni == 0 && mi == 3 && t + 3 < nt) g2_issue<1>(xg, wg, t + 3, smem, wave);
-            if (ks == 1 && ni == 0 && mi == 3 && t + 3 < nt) g2_issue<2>(xg, wg, t + 3, smem, wave);
-          }
-        }
+          acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (VAR != 13 && VAR != 14 && VAR != 16 && VAR != 17) SMI_BARRIER();
+    SMI_BARRIER();
   }
   if (wr == 0) SMI_BARRIER();  // balance group 1's extra barrier
 }

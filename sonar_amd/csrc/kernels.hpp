@@ -13,6 +13,10 @@ enum GemmEpilogue {
   EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6
 };
 
+// layout flags OR-ed into epi_sel (tile-major layout: common.hpp tm_offset)
+constexpr int GEMM_IN_TM = 1 << 12;   // X and W are tile-major (M, N % 256 == 0)
+constexpr int GEMM_OUT_TM = 1 << 13;  // fp16 output is tile-major with K = N (needs GEMM_IN_TM, ldo == N)
+
 // C = X[M,K] * W[N,K]^T (+bias, epilogue).  M%128==0, N%128==0, K%64==0.
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
                           int N, int K, int ldo, hipStream_t stream);
@@ -26,8 +30,11 @@ hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu_seqlens, cons
                              int S, int max_len, int d, int64_t vocab, hipStream_t stream);
 
 // h[r,:] = f16(LN(x[r,:]) * w + b)
+// out_tm: h is written tile-major (rows rounded up to 256 must be allocated)
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream);
+                            int rows, int d, hipStream_t stream, int out_tm = 0);
+// dst (tile-major) <- src (row-major [rows][K]), rows % 256 == 0, K % 32 == 0; and the inverse
+hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int inverse, hipStream_t stream);
 
 // Final LN + masked pooling (mean) over each sentence's packed rows.
 // out: [N, d] in fp16 or fp32; encoded (optional): [N, S, d] same dtype, pads zeroed.
@@ -36,8 +43,9 @@ hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float 
                           int S, int d, int pooling, hipStream_t stream);
 
 // Self-attention over packed rows. qkv: [T, 3*d] (q | k | v), ctx: [T, d].  head_dim 64.
+// ctx_tm: ctx is written tile-major.
 hipError_t launch_attention(const f16* qkv, const int32_t* cu_seqlens, f16* ctx, int N, int max_len,
-                            int d, int heads, hipStream_t stream);
+                            int d, int heads, hipStream_t stream, int ctx_tm = 0);
 
 // dst_f16[i] = f16(src_f32[i])
 hipError_t launch_f32_to_f16(const float* src, f16* dst, size_t n, hipStream_t stream);

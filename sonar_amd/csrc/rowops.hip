@@ -96,7 +96,9 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
   }
 }
 
-template <int NV>
+// TM: h in the tile-major GEMM operand layout (common.hpp); 8 lanes then cover one 64-B row piece
+// of a block and the 4 waves of a workgroup (4 consecutive rows) one 256-B run per k-block.
+template <int NV, bool TM>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps,
@@ -112,19 +114,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       half4 o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = (f16)y[k][i];
-      *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+      if constexpr (TM)
+        *(half4*)(h + tm_offset(r, k * 256 + lane * 4, D)) = o;
+      else
+        *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
     }
   }
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream) {
+                            int rows, int d, hipStream_t stream, int out_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
   const int blocks = min((rows + 3) / 4, 256 * 32);
-#define SMI_LN_CASE(NV)                                                                         \
-  case NV * 256:                                                                                \
-    hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, \
-                       h, rows);                                                                \
+#define SMI_LN_CASE(NV)                                                                              \
+  case NV * 256:                                                                                     \
+    if (out_tm)                                                                                      \
+      hipLaunchKernelGGL((layernorm_kernel<NV, true>), dim3(blocks), dim3(256), 0, stream, x, w, b, \
+                         eps, h, rows);                                                              \
+    else                                                                                             \
+      hipLaunchKernelGGL((layernorm_kernel<NV, false>), dim3(blocks), dim3(256), 0, stream, x, w, b, \
+                         eps, h, rows);                                                              \
     break;
   switch (d) {
     SMI_LN_CASE(1)
@@ -229,6 +238,32 @@ hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float 
     default: return hipErrorInvalidValue;
   }
 #undef SMI_LP_CASE
+  return hipGetLastError();
+}
+
+// ------------------------------------------------- row-major <-> tile-major
+// One workgroup per (256-row block, 32-column block): 16 KiB, thread t moves 16-B chunks.
+__global__ __launch_bounds__(256) void pack_tile_major_kernel(const f16* __restrict__ src,
+                                                              f16* __restrict__ dst, int K, int inverse) {
+  const int kb = blockIdx.x, rb = blockIdx.y;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = threadIdx.x + 256 * i;  // (row, chunk)
+    const int rr = id >> 2, c = id & 3;
+    const size_t rm = (size_t)(rb * 256 + rr) * K + kb * 32 + c * 8;
+    const size_t tm = tm_offset(rb * 256 + rr, kb * 32 + c * 8, K);
+    if (inverse)
+      *(half8*)(dst + rm) = *(const half8*)(src + tm);
+    else
+      *(half8*)(dst + tm) = *(const half8*)(src + rm);
+  }
+}
+
+hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int inverse,
+                                  hipStream_t stream) {
+  if (rows <= 0 || rows % TM_ROWS || K <= 0 || K % 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_tile_major_kernel, dim3(K / 32, rows / 256), dim3(256), 0, stream, src, dst, K,
+                     inverse);
   return hipGetLastError();
 }
 

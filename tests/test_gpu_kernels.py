@@ -22,6 +22,84 @@ def _stream():
     return int(torch.cuda.current_stream().cuda_stream)
 
 
+def to_tile_major(a):
+    """Independent (torch index arithmetic) statement of the tile-major layout documented in
+    include/sonar_mi355.h: [rows/256][k/32] blocks of [256 rows][4 slots][8], slot = chunk ^ ((row>>2)&3)."""
+    rows, k = a.shape
+    assert rows % 256 == 0 and k % 32 == 0
+    blocks = a.view(rows // 256, 256, k // 32, 4, 8).permute(0, 2, 1, 3, 4)  # [rb, kb, rr, chunk, 8]
+    rr = torch.arange(256, device=a.device)
+    slot = torch.arange(4, device=a.device)
+    chunk_of_slot = slot[None, :] ^ ((rr[:, None] >> 2) & 3)                 # [rr, slot] -> chunk
+    idx = chunk_of_slot[None, None, :, :, None].expand(rows // 256, k // 32, 256, 4, 8)
+    return torch.gather(blocks, 3, idx).contiguous().view(-1)
+
+
+def from_tile_major(flat, rows, k):
+    blocks = flat.view(rows // 256, k // 32, 256, 4, 8)
+    rr = torch.arange(256, device=flat.device)
+    chunk = torch.arange(4, device=flat.device)
+    slot_of_chunk = chunk[None, :] ^ ((rr[:, None] >> 2) & 3)                # involution
+    idx = slot_of_chunk[None, None, :, :, None].expand(rows // 256, k // 32, 256, 4, 8)
+    return torch.gather(blocks, 3, idx).permute(0, 2, 1, 3, 4).reshape(rows, k).contiguous()
+
+
+@pytest.mark.parametrize("rows,k", [(256, 32), (512, 1024), (768, 8192)])
+def test_pack_tile_major(lib, rows, k):
+    from sonar_amd import _lib
+
+    a = torch.randn(rows, k, device="cuda").half()
+    tm = torch.empty(rows * k, device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_pack_tile_major(a.data_ptr(), tm.data_ptr(), rows, k, 0, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(tm, to_tile_major(a))
+    assert torch.equal(from_tile_major(tm, rows, k), a)
+    back = torch.empty_like(a)
+    _lib.check(lib.smi_pack_tile_major(tm.data_ptr(), back.data_ptr(), rows, k, 1, _stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(back, a)
+    assert lib.smi_pack_tile_major(a.data_ptr(), tm.data_ptr(), rows + 1, k, 0, _stream()) != 0
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (256, 512, 192), (512, 1024, 1024), (256, 256, 8192),
+                                   (1024, 768, 256)])
+@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0)])
+def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
+    """Tile-major operands (and output) on both tile engines against the same fp32 reference."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m * 5 + n * 3 + k + epi + out_tm)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    xt, wt = to_tile_major(x), to_tile_major(w)
+    ref = x.float() @ w.float().T + bias
+    flags = _lib.SMI_GEMM_IN_TM | (_lib.SMI_GEMM_OUT_TM if out_tm else 0)
+    for sel in (1, 2):
+        if epi == 2:
+            resid = torch.randn(m, n, device="cuda", generator=g)
+            out = resid.clone()
+            want = resid + ref
+        elif epi == 3:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
+            want = ref
+        else:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
+            want = torch.relu(ref) if epi == 1 else ref
+        _lib.check(lib.smi_gemm_tn(epi | (sel << 8) | flags, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                   out.data_ptr(), m, n, k, n, _stream()))
+        torch.cuda.synchronize()
+        got = (from_tile_major(out.view(-1), m, n) if out_tm else out).float()
+        assert torch.isfinite(got).all()
+        err = (got - want).abs().max().item()
+        scale = max(want.abs().max().item(), 1.0)
+        assert err <= (2e-3 if epi in (0, 1) else 2e-5) * scale, (sel, err, scale)
+    # unsupported combinations are refused, not mis-computed
+    assert lib.smi_gemm_tn(6 | flags, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n, _stream()) != 0
+    assert lib.smi_gemm_tn(0 | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n,
+                           _stream()) != 0
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
                                    (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
                                    (256, 256, 8192), (1024, 768, 256)])
@@ -70,19 +148,25 @@ def test_gemm_tn(lib, m, n, k, epi):
 
 
 @pytest.mark.parametrize("d", [256, 512, 768, 1024, 2048])
-def test_layernorm(lib, d):
+@pytest.mark.parametrize("tm", [0, 1])
+def test_layernorm(lib, d, tm):
     from sonar_amd import _lib
 
     rows = 517
+    pad = (rows + 255) // 256 * 256
     g = torch.Generator(device="cuda").manual_seed(d)
     x = torch.randn(rows, d, device="cuda", generator=g) * 3 + 0.7
     w = torch.randn(d, device="cuda", generator=g)
     b = torch.randn(d, device="cuda", generator=g)
-    out = torch.empty(rows, d, device="cuda", dtype=torch.float16)
-    _lib.check(lib.smi_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, out.data_ptr(), rows, d, _stream()))
+    out = torch.zeros(pad, d, device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, out.data_ptr(), rows, d, tm,
+                                 _stream()))
     torch.cuda.synchronize()
+    if tm:
+        out = from_tile_major(out.view(-1), pad, d)
     ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-5)
-    assert (out.float() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    assert (out[:rows].float() - ref).abs().max().item() <= 4e-3 * ref.abs().max().item()
+    assert (out[rows:] == 0).all()
 
 
 def _attention_ref(qkv, lens, d, heads):
@@ -105,18 +189,21 @@ def _attention_ref(qkv, lens, d, heads):
 
 @pytest.mark.parametrize("lens,heads", [([128] * 3, 4), ([1, 5, 64, 65, 127, 129, 200, 33], 4),
                                         ([514, 300, 7], 2), ([31, 32, 33, 63], 16)])
-def test_attention(lib, lens, heads):
+@pytest.mark.parametrize("tm", [0, 1])
+def test_attention(lib, lens, heads, tm):
     from sonar_amd import _lib
 
     d = heads * 64
     t = sum(lens)
+    pad = (t + 255) // 256 * 256
     g = torch.Generator(device="cuda").manual_seed(t + heads)
     qkv = (torch.randn(t, 3 * d, device="cuda", generator=g) * 1.5).half()
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
-    ctx = torch.full((t, d), float("nan"), device="cuda", dtype=torch.float16)
-    _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), len(lens), max(lens), d, heads, _stream()))
+    ctx = torch.full((pad, d), float("nan"), device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), len(lens), max(lens), d, heads, tm,
+                                 _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv, lens, d, heads)
-    got = ctx.float()
+    got = (from_tile_major(ctx.view(-1), pad, d) if tm else ctx)[:t].float()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 6e-3, (got - ref).abs().max().item()

@@ -44,14 +44,14 @@ def main():
     x = torch.randn(M, 1024, device="cuda")
     w = torch.randn(1024, device="cuda"); b = torch.randn(1024, device="cuda")
     h = torch.empty(M, 1024, device="cuda", dtype=torch.float16)
-    ms = timeit(lambda: _lib.check(lib.smi_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, h.data_ptr(), M, 1024, st())))
+    ms = timeit(lambda: _lib.check(lib.smi_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5, h.data_ptr(), M, 1024, 0, st())))
     res["layernorm"] = {"ms": ms, "GBs": M * 1024 * 6 / ms / 1e6}
     print(f"layernorm: {ms:.3f} ms {res['layernorm']['GBs']:.0f} GB/s", flush=True)
     # attention
     qkv = (torch.randn(M, 3072, device="cuda")).half()
     cu = torch.arange(0, M + 1, 128, dtype=torch.int32, device="cuda")
     ctx = torch.empty(M, 1024, device="cuda", dtype=torch.float16)
-    ms = timeit(lambda: _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), 1024, 128, 1024, 16, st())))
+    ms = timeit(lambda: _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), 1024, 128, 1024, 16, 0, st())))
     res["attention"] = {"ms": ms, "GBs": M * 4096 * 2 / ms / 1e6, "TF": 4.0 * 128 * 1024 * M / ms / 1e9}
     print(f"attention: {ms:.3f} ms {res['attention']['GBs']:.0f} GB/s {res['attention']['TF']:.0f} TF/s", flush=True)
     del qkv, ctx, x, h
