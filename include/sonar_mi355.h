@@ -317,8 +317,9 @@ int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* 
 /* out = f16(LN(x) * w + b); tile_major != 0: out in the tile-major layout ((rows+255)/256*256 rows allocated) */
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out_f16,
                   int32_t rows, int32_t d, int32_t tile_major, void* stream);
-/* qkv: f16 [t, 3*d] packed rows; cu_seqlens: device int32 [n+1]; ctx: f16 [t, d]
- * (tile_major != 0: tile-major, (t+255)/256*256 rows allocated) */
+/* qkv: f16 [t, 3*d] packed rows; cu_seqlens: device int32 [n+1]; ctx: f16 [t, d];
+ * tile_major bit 0: ctx written tile-major, bit 1: qkv read tile-major (k = 3*d)
+ * ((t+255)/256*256 rows allocated for a tile-major buffer) */
 int smi_attention(const void* qkv_f16, const int32_t* cu_seqlens, void* ctx_f16, int32_t n,
                   int32_t max_len, int32_t d, int32_t heads, int32_t tile_major, void* stream);
 

@@ -361,7 +361,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
                             c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream)); }
-  // x (fp32 residual stream) and qkv stay row-major; h, ctx, ffn and the weights are tile-major
+  // x (fp32 residual stream) stays row-major; h, qkv, ctx, ffn and the weights are tile-major
   const int tm = e->tile_major;
   const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   for (int l = 0; l < c.num_layers; ++l) {
@@ -369,10 +369,10 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
     HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
-    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | in_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
                            d, 3 * d, stream)); }
     { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
-    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm)); }
+    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
     { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
     HIP_TRY(launch_gemm_tn(EPI_RESID_F32 | in_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
                            stream)); }
@@ -484,7 +484,7 @@ int smi_attention(const void* qkv, const int32_t* cu, void* ctx, int32_t n, int3
   if (heads <= 0 || d != heads * 64) return fail(SMI_ERR_UNSUPPORTED, "head_dim must be 64");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_attention((const f16*)qkv, cu, (f16*)ctx, n, max_len, d, heads, (hipStream_t)stream,
-                           tile_major != 0));
+                           tile_major & 3));
   return SMI_OK;
 }
 

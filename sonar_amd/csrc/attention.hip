@@ -25,7 +25,9 @@ constexpr int AT_KB = 64;   // keys per K/V tile
 
 // TM: ctx is written in the tile-major GEMM operand layout (common.hpp) -- a wave then stores
 // 2 KiB runs (32 rows x 64 B of one k-block) instead of 8-B pieces one row stride apart.
-template <bool TM>
+// QTM: qkv is READ tile-major ([T, 3d] as K = 3d blocks, the QKV GEMM's register-direct output):
+// the 64-key x 64-B halves of a K or V tile are then contiguous 4 KiB runs.
+template <bool TM, bool QTM>
 __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         f16* __restrict__ ctx, int d, float sl2e) {
@@ -48,9 +50,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
 
   const int qi = q0 + wave * 32 + l31;
   const f16* qptr = qbase + (size_t)min(qi, len - 1) * ld;
+  const int K3 = 3 * d;
+  // element (row r of this sentence, column c of the [q | k | v] row)
+  auto at = [&](int r, int c) -> const f16* {
+    if constexpr (QTM) return qkv + tm_offset(start + r, c, K3);
+    return qkv + (size_t)(start + r) * ld + c;
+  };
   half8 qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qptr + (ks * 2 + hi) * 8);
+  for (int ks = 0; ks < 4; ++ks) {
+    if constexpr (QTM)
+      qf[ks] = *(const half8*)at(min(qi, len - 1), h * 64 + (ks * 2 + hi) * 8);
+    else
+      qf[ks] = *(const half8*)(qptr + (ks * 2 + hi) * 8);
+  }
 
   float m = -1e30f, lsum = 0.f;
   f32x16 o[2];
@@ -68,7 +81,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
       const int key = c >> 3, slot = c & 7;
       const int chunk = slot ^ ((key >> 1) & 7);
       const int krow = min(kv0 + key, len - 1);
-      *(half8*)(Ks + c * 16) = *(const half8*)(kbase + (size_t)krow * ld + chunk * 8);
+      *(half8*)(Ks + c * 16) = *(const half8*)at(krow, d + h * 64 + chunk * 8);
     }
     // ---- stage V transposed ----
     {
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const int dc = (lane >> 4) + 4 * x;
-        const half8 v = *(const half8*)(vbase + (size_t)vrow * ld + dc * 8);
+        const half8 v = *(const half8*)at(vrow, 2 * d + h * 64 + dc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int dd = dc * 8 + e;
@@ -181,10 +194,13 @@ hipError_t launch_attention(const f16* qkv, const int32_t* cu, f16* ctx, int N, 
   if (heads <= 0 || d != heads * 64 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;  // Dh^-0.5 * log2(e)
   dim3 grid(N, heads, (max_len + AT_QB - 1) / AT_QB);
-  if (ctx_tm)
-    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e);
-  else
-    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e);
+  // ctx_tm: bit 0 = ctx written tile-major, bit 1 = qkv read tile-major
+  switch (ctx_tm & 3) {
+    case 0: hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
+    case 1: hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
+    case 2: hipLaunchKernelGGL((attention_kernel<false, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
+    default: hipLaunchKernelGGL((attention_kernel<true, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
+  }
   return hipGetLastError();
 }
 

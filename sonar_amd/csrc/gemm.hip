@@ -3,6 +3,8 @@
 // sonar/models/sonar_text/factory.py:130-153 and, for the conformer, fairseq2's
 // ConformerBlock built by sonar/models/sonar_speech/factory.py:64-71), fp16 in, fp32
 // accumulate on v_mfma_f32_32x32x16_f16, with the epilogues fused.
+#include <algorithm>
+
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -117,6 +119,21 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
 }
 
 // Same epilogues on the 256x256 ping-pong tile engine (gemm_tile256.hpp).
+#ifdef SMI_GEMM_TRACE
+// development aid (-DSMI_GEMM_TRACE): per-tile phase timestamps (100 MHz wall clock) of thread 0
+// of the first 16 workgroups; read back with smi_debug_gemm_trace()
+__device__ unsigned long long g2_trace_buf[16 * 64 * 8];
+#define G2_TRACE(slot)                                                               \
+  if (threadIdx.x == 0 && blockIdx.x < 16 && trace_i < 64)                           \
+  g2_trace_buf[(blockIdx.x * 64 + trace_i) * 8 + (slot)] = wall_clock64()
+#else
+#define G2_TRACE(slot)
+#endif
+
+// PERSISTENT: the grid is one workgroup per CU (160 KiB of LDS) and every workgroup walks tiles
+// id = round * gridDim + xcd_remap(block).  The pipeline fill of tile i+1 is issued before the
+// epilogue of tile i, and the epilogue leaves through two small staging buffers outside ring slots
+// 0..2 (gemm_tile256.hpp), so the ~2 us fill latency of the 32-slice (K = 1024) tiles is hidden.
 template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -124,126 +141,209 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
                                                                 void* __restrict__ out, int M, int N,
                                                                 int K, int ldo) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tile_m, tile_n;
-  g2_tile_coords(M / G2_BM, N / G2_BN, tile_m, tile_n);
-  const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
-
-  GemmTile256Acc acc;
-  g2_mainloop<(LAYOUT > 0), (LAYOUT > 0)>(acc, X, W, K, m0, n0, smem);
-
-  // ---- epilogue: stage the C tile through LDS (free after the main loop) so the
-  // global stores are whole row segments instead of 8-B pieces 32 rows apart.
-  // Row stride 528 B: 16-B aligned and 2-way-or-better on the LDS banks.
+  constexpr bool TM = LAYOUT > 0;
+  const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn, nt = K / G2_BK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
-  constexpr int CS = G2_CSTRIDE;
-  if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
-    // fp32 outputs, two passes of 128 columns (pass p = the waves' ni block)
+  const int lr_w = wr * 32 + l31;             // staging row this lane writes
+  const int sw_w = g2_stage_swz(lr_w);
+
+  // The bias slice of a tile (256 floats) waits in the second staging buffer: it is fetched with
+  // the pipeline fill of its tile (no exposed latency, no registers held across the K loop) and
+  // read back with ds_reads, which do not touch the vmcnt queue the next tile's fill sits in.
+  float* bias_lds = (float*)g2_stage(smem, 1);
+  const int tid = threadIdx.x;
+  auto fetch_bias = [&](int n0) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (bias && tid < 64) v = *(const f32x4*)(bias + n0 + tid * 4);
+    return v;
+  };
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= ntiles) return;
+  int tile_m, tile_n;
+  g2_tile_coords_of(tile, ntm, ntn, tile_m, tile_n);
+  G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN);
+  g2_prefetch(src, nt, smem);
+  f32x4 bias_next = fetch_bias(tile_n * G2_BN);
+
+#ifdef SMI_GEMM_TRACE
+  int trace_i = 0;
+#endif
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+    G2_TRACE(0);
+    if (tid < 64) *(f32x4*)(bias_lds + tid * 4) = bias_next;
+    GemmTile256Acc acc;
+    g2_begin(acc);
+    G2_TRACE(1);
+    g2_mainloop(acc, src, nt, smem);
+    G2_TRACE(2);
+    if (tile + (int)gridDim.x < ntiles) {  // fill for the next tile, behind this tile's epilogue
+      g2_tile_coords_of(tile + gridDim.x, ntm, ntn, tile_m, tile_n);
+      src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN);
+      g2_prefetch(src, nt, smem);
+      bias_next = fetch_bias(tile_n * G2_BN);
+    }
+    G2_TRACE(3);
+    f32x4 b[2][4];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (p) __syncthreads();
+    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b = *(const f32x4*)(bias + g2_col(n0, p, q));
+      for (int q = 0; q < 4; ++q) b[ni][q] = *(const f32x4*)(bias_lds + wc * 64 + ni * 32 + 8 * q + 4 * hi);
+
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
+      // fp32 outputs: 8 sub-passes (mi block p, ni block) of 64 rows x 128 columns
+      const int c = lane & 31;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+      for (int sp = 0; sp < 8; ++sp) {
+        const int p = sp >> 1, ni = sp & 1;
+        char* st = g2_stage(smem, sp);
+        // residual values of this sub-pass: issued ahead of the LDS round trip
+        const int gcol = n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4;
+        f32x4 old[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = wave * 8 + it * 2 + hi;
+          const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
+          if constexpr (EPI == EPI_STORE_F32)
+            old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+          else
+            old[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc.v[p][mi][q * 4 + e] + b[e];
+          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
           if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
-          *(f32x4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 32 + 8 * q + 4 * hi) * 4) = v;
+          *(f32x4*)(st + lr_w * 512 + (((wc * 8 + 2 * q + hi) ^ sw_w) << 4)) = v;
+        }
+        SMI_LGKM0_BARRIER();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = wave * 8 + it * 2 + hi;
+          const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
+          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          *(f32x4*)((float*)out + (size_t)row * ldo + gcol) = old[it] + v;
         }
       }
-      __syncthreads();
-      const int c = lane & 31;
-      const int gcol = n0 + (c >> 3) * 64 + p * 32 + (c & 7) * 4;
-      f32x4 old[16];
+    } else if constexpr (EPI == EPI_GLU_F16) {
+      // 128 output channels per tile: channel wc*32 + 8q + 4hi + e from the wave's (a, gate) blocks
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = wave * 32 + it * 2 + hi;
-        if constexpr (EPI == EPI_STORE_F32)
-          old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        else
-          old[it] = *(const f32x4*)((const float*)out + (size_t)(m0 + row) * ldo + gcol);
-      }
+      for (int p = 0; p < 4; ++p) {
+        char* st = g2_stage(smem, p);
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = wave * 32 + it * 2 + hi;
-        const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
-        *(f32x4*)((float*)out + (size_t)(m0 + row) * ldo + gcol) = old[it] + v;
-      }
-    }
-  } else if constexpr (EPI == EPI_GLU_F16) {
-    // 128 output channels per tile: channel wc*32 + 8q + 4hi + e from the wave's (a, gate) blocks
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;
-      if (bias) {
-        ba = *(const f32x4*)(bias + g2_col(n0, 0, q));
-        bg = *(const f32x4*)(bias + g2_col(n0, 1, q));
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        half4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          h[e] = (f16)((acc.v[0][mi][q * 4 + e] + ba[e]) * sigmoid_f(acc.v[1][mi][q * 4 + e] + bg[e]));
-        *(half4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 32 + 8 * q + 4 * hi) * 2) = h;
-      }
-    }
-    __syncthreads();
-    const int c = lane & 15;  // 16 lanes x 16 B = one 256-B output row
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = wave * 32 + it * 4 + (lane >> 4);
-      const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
-      *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 / 2 + c * 8) = v;
-    }
-  } else {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b = *(const f32x4*)(bias + g2_col(n0, ni, q));
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][mi][q * 4 + e] + b[e];
-          v = epi_act<EPI>(v);
+        for (int q = 0; q < 4; ++q) {
           half4 h;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
-          *(half4*)(smem + (wr * 128 + mi * 32 + l31) * CS + (wc * 64 + ni * 32 + 8 * q + 4 * hi) * 2) = h;
+          for (int e = 0; e < 4; ++e)
+            h[e] = (f16)((acc.v[0][p][q * 4 + e] + b[0][q][e]) * sigmoid_f(acc.v[1][p][q * 4 + e] + b[1][q][e]));
+          *(half4*)(st + lr_w * 512 + (((wc * 4 + q) ^ sw_w) << 4) + hi * 8) = h;
+        }
+        SMI_LGKM0_BARRIER();
+        const int c = lane & 15;  // 16 lanes x 16 B = one 256-B output row
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int lr = wave * 8 + it * 4 + (lane >> 4);
+          const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
+          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          *(f32x4*)((f16*)out + (size_t)row * ldo + n0 / 2 + c * 8) = v;
+        }
+      }
+    } else if constexpr (LAYOUT == 2) {
+      // fp16 tile-major output straight from the accumulators, no LDS pass, no barriers: a lane
+      // holds 4 consecutive columns (8 B) of row l31 per (ni, q); v_permlane32_swap joins the two
+      // lane halves' 8-B pieces into whole 16-B chunks (lower lanes: chunk 2*pair, upper lanes:
+      // chunk 2*pair+1 of the 32-column k-block wc*2+ni), so a wave instruction stores 64 x 16 B
+      // into one 2 KiB run (32 rows x 64 B of one block) and the two pairs fill it completely.
+      const int sw = (l31 >> 2) & 3;
+      f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
+                   (wr * 128 + l31) * 32;
+      const int slot0 = ((hi ^ sw) << 3), slot1 = (((2 | hi) ^ sw) << 3);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          uint32_t h[4][2];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
+            half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
+            if constexpr (EPI == EPI_RELU_F16) {  // relu after the rounding: same values, packed max
+              const half2v z = {(f16)0.f, (f16)0.f};
+              lo = __builtin_elementwise_max(lo, z);
+              hh = __builtin_elementwise_max(hh, z);
+            }
+            h[q][0] = __builtin_bit_cast(uint32_t, lo);
+            h[q][1] = __builtin_bit_cast(uint32_t, hh);
+          }
+          f16* dst = lane0 + (size_t)ni * TM_BLOCK + p * (32 * 32);
+#pragma unroll
+          for (int pair = 0; pair < 2; ++pair) {
+            // upper half of h[2*pair] <-> lower half of h[2*pair+1]
+            const auto s0 = __builtin_amdgcn_permlane32_swap(h[2 * pair][0], h[2 * pair + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(h[2 * pair][1], h[2 * pair + 1][1], false, false);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
+            *(u32x4*)(dst + (pair ? slot1 : slot0)) = chunk;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        char* st = g2_stage(smem, p);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
+            v = epi_act<EPI>(v);
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
+            *(half4*)(st + lr_w * 512 + (((wc * 8 + ni * 4 + q) ^ sw_w) << 4) + hi * 8) = h;
+          }
+        SMI_LGKM0_BARRIER();
+        const int c = lane & 31;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int lr = wave * 8 + it * 2 + hi;
+          const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
+          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          *(f32x4*)((f16*)out + (size_t)row * ldo + n0 + c * 8) = v;
         }
       }
     }
-    __syncthreads();
-    if constexpr (LAYOUT == 2) {
-      // the tile is 8 tile-major blocks (k-blocks n0/32 .. n0/32+7 of row block m0/256) of 16 KiB;
-      // every wave instruction stores 1 KiB (16 rows x 64 B) linearly
-      f16* blk0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5)) * TM_BLOCK;
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int piece = wave * 16 + it;
-        const int j = piece >> 4, i = piece & 15;
-        const int row = i * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        const f32x4 v = *(const f32x4*)(smem + row * CS + (j * 32 + chunk * 8) * 2);
-        *(f32x4*)(blk0 + (size_t)j * TM_BLOCK + i * 512 + lane * 8) = v;
-      }
-    } else {
-      const int c = lane & 31;
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = wave * 32 + it * 2 + hi;
-        const f32x4 v = *(const f32x4*)(smem + row * CS + c * 16);
-        *(f32x4*)((f16*)out + (size_t)(m0 + row) * ldo + n0 + c * 8) = v;
-      }
-    }
+    // staging reads retired by every wave before the next tile's loop refills slot 3
+    SMI_LGKM0_BARRIER();
+    G2_TRACE(4);
+#ifdef SMI_GEMM_TRACE
+    ++trace_i;
+#endif
   }
+}
+
+#ifdef SMI_GEMM_TRACE
+extern "C" int smi_debug_gemm_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g2_trace_buf), sizeof(g2_trace_buf));
+}
+#endif
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
 }
 
 template <int EPI, int LAYOUT>
@@ -256,7 +356,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int grid = (M / G2_BM) * (N / G2_BN);
+  const int grid = std::min((M / G2_BM) * (N / G2_BN), num_cus());
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
                      stream, X, W, bias, out, M, N, K, ldo);
   return hipGetLastError();

@@ -48,8 +48,7 @@ constexpr int G2_BK = 32;
 constexpr int G2_THREADS = 512;
 constexpr int G2_SLOT_BYTES = (G2_BM + G2_BN) * G2_BK * 2;  // 32 KiB
 constexpr int G2_LDS_BYTES = 4 * G2_SLOT_BYTES;             // 128 KiB
-constexpr int G2_CSTRIDE = 528;                            // epilogue C-tile row stride in LDS
-constexpr int G2_KERNEL_LDS_BYTES = G2_BM * G2_CSTRIDE;      // 132 KiB >= ring
+constexpr int G2_KERNEL_LDS_BYTES = G2_LDS_BYTES + 32 * 1024;  // ring + second epilogue staging buffer = 160 KiB
 
 struct GemmTile256Acc {
   f32x16 v[2][4];  // [ni][mi]
@@ -61,7 +60,14 @@ struct GemmTile256Acc {
 #define SMI_LGKM0_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SMI_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-// Per-wave DMA source pointers of the two 1-KiB pieces this wave copies for each operand.
+// Per-wave DMA source of one tile: pointers of the two 1-KiB pieces this wave copies per operand
+// and slice, and the element step from one K slice to the next.
+struct G2Src {
+  const f16* xg[2];
+  const f16* wg[2];
+  int xstep, wstep;
+};
+
 template <bool TM>
 __device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row0, int wave, int lane,
                                        const f16* (&ag)[2], int& kstep) {
@@ -82,52 +88,64 @@ __device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row
   }
 }
 
-__device__ __forceinline__ void g2_issue(const f16* const (&xg)[2], const f16* const (&wg)[2], int xoff,
-                                         int woff, int t, char* smem, int wave) {
-  char* slot = smem + (t & 3) * G2_SLOT_BYTES + wave * 2048;
-  glds16(xg[0] + xoff, slot);
-  glds16(xg[1] + xoff, slot + 1024);
-  glds16(wg[0] + woff, slot + G2_BM * G2_BK * 2);
-  glds16(wg[1] + woff, slot + G2_BM * G2_BK * 2 + 1024);
-}
-
 // X: [*, K], W: [*, K] (row-major or tile-major per XTM / WTM); rows m0..m0+255 / n0..n0+255
 // readable; K % 32 == 0.
-template <bool XTM = false, bool WTM = false>
-__device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __restrict__ X,
-                                            const f16* __restrict__ W, int K, int m0, int n0,
-                                            char* smem) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;  // wr doubles as the ping-pong group
+template <bool XTM, bool WTM>
+__device__ __forceinline__ G2Src g2_make_src(const f16* __restrict__ X, const f16* __restrict__ W, int K,
+                                             int m0, int n0) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  G2Src s;
+  g2_src<XTM>(X, K, m0, wave, lane, s.xg, s.xstep);
+  g2_src<WTM>(W, K, n0, wave, lane, s.wg, s.wstep);
+  return s;
+}
 
-  const f16* xg[2];
-  const f16* wg[2];
-  int xstep, wstep;
-  g2_src<XTM>(X, K, m0, wave, lane, xg, xstep);
-  g2_src<WTM>(W, K, n0, wave, lane, wg, wstep);
+__device__ __forceinline__ void g2_issue(const G2Src& s, int t, char* smem, int wave) {
+  char* slot = smem + (t & 3) * G2_SLOT_BYTES + wave * 2048;
+  const int xo = t * s.xstep, wo = t * s.wstep;
+  glds16(s.xg[0] + xo, slot);
+  glds16(s.xg[1] + xo, slot + 1024);
+  glds16(s.wg[0] + wo, slot + G2_BM * G2_BK * 2);
+  glds16(s.wg[1] + wo, slot + G2_BM * G2_BK * 2 + 1024);
+}
 
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
-  const int xoff = (wr * 128 + l31) * 64 + t_sw;
-  const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
+// Pipeline fill: DMA for slices 0..2 into ring slots 0..2.  Issued BEFORE the previous tile's
+// epilogue (which stages through slot 3 and the LDS above the ring), so the fill latency of a
+// tile is hidden behind the epilogue of the one before it.
+__device__ __forceinline__ void g2_prefetch(const G2Src& s, int nt, char* smem) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  g2_issue(s, 0, smem, wave);
+  if (nt > 1) g2_issue(s, 1, smem, wave);
+  if (nt > 2) g2_issue(s, 2, smem, wave);
+}
 
+// Tile start: clear the accumulators and retire the pipeline fill issued by g2_prefetch together
+// with the previous epilogue's stores (vmcnt does not tell loads from stores); after this only
+// counted waits.  Separate from the loop so the caller can pin its own early loads (bias) here.
+__device__ __forceinline__ void g2_begin(GemmTile256Acc& acc) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+  SMI_WAIT_VMCNT(0);
+  SMI_BARRIER();  // slices 0..2 complete for everyone
+}
 
-  const int nt = K / G2_BK;
-  g2_issue(xg, wg, 0, 0, 0, smem, wave);
-  if (nt > 1) g2_issue(xg, wg, xstep, wstep, 1, smem, wave);
-  if (nt > 2) g2_issue(xg, wg, 2 * xstep, 2 * wstep, 2, smem, wave);
-  if (nt > 2) SMI_WAIT_VMCNT(8);
-  else if (nt > 1) SMI_WAIT_VMCNT(4);
-  else SMI_WAIT_VMCNT(0);
-  SMI_BARRIER();               // slice 0 complete for everyone
+// K loop of one tile (after g2_begin).
+__device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& src, int nt, char* smem) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // wr doubles as the ping-pong group
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
+  const int xoff = (wr * 128 + l31) * 64 + t_sw;
+  const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
+
   if (wr == 1) SMI_BARRIER();  // group 1 runs one interval behind
 
   for (int t = 0; t < nt; ++t) {
@@ -142,7 +160,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
       for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
     }
     if (t + 3 < nt) {
-      g2_issue(xg, wg, (t + 3) * xstep, (t + 3) * wstep, t + 3, smem, wave);
+      g2_issue(src, t + 3, smem, wave);
       SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
     } else if (t + 2 < nt) {
       SMI_WAIT_VMCNT(4);
@@ -167,6 +185,17 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const f16* __re
   if (wr == 0) SMI_BARRIER();  // balance group 1's extra barrier
 }
 
+// ---- epilogue staging: the C tile leaves through LDS in 4 passes of 64 rows (pass p = the waves'
+// mi block: tile rows wr*128 + p*32 + (0..31)), two 32 KiB buffers used alternately, placed in
+// ring slot 3 and the 32 KiB above the ring so slots 0..2 can already take the next tile's fill.
+// A staging row is 512 B; 16-B chunk c of local row lr sits at c ^ g2_stage_swz(lr): the 8/16-B
+// accumulator writes (32 rows, one chunk), the whole-row reads and the 16-row x 64-B tile-major
+// reads are all bank-conflict free.
+constexpr int G2_STAGE0 = 3 * G2_SLOT_BYTES;         // 96 KiB
+constexpr int G2_STAGE_BYTES = 64 * 512;             // 32 KiB
+__device__ __forceinline__ int g2_stage_swz(int lr) { return ((lr & 3) << 2) | ((lr >> 2) & 3) | (lr & 16); }
+__device__ __forceinline__ char* g2_stage(char* smem, int buf) { return smem + G2_STAGE0 + (buf & 1) * G2_STAGE_BYTES; }
+
 // acc.v[ni][mi][r] is C[m][n] with
 //   m = m0 + wr*128 + mi*32 + (lane&31)
 //   n = n0 + wc*64 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
@@ -181,8 +210,7 @@ __device__ __forceinline__ int g2_col(int n0, int ni, int quad) {
 
 // XCD-aware grouped raster over 256x256 tiles: the ~32 workgroups resident on
 // one XCD (1 per CU) cover a 4(m) x 8(n) super-tile.
-__device__ __forceinline__ void g2_tile_coords(int ntm, int ntn, int& tile_m, int& tile_n) {
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
+__device__ __forceinline__ void g2_tile_coords_of(int id, int ntm, int ntn, int& tile_m, int& tile_n) {
   constexpr int GM = 4;
   const int per_group = GM * ntn;
   const int group = id / per_group;
@@ -191,6 +219,9 @@ __device__ __forceinline__ void g2_tile_coords(int ntm, int ntn, int& tile_m, in
   const int in_group = id - group * per_group;
   tile_m = first_m + in_group % gsz;
   tile_n = in_group / gsz;
+}
+__device__ __forceinline__ void g2_tile_coords(int ntm, int ntn, int& tile_m, int& tile_n) {
+  g2_tile_coords_of(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, tile_m, tile_n);
 }
 
 }  // namespace smi

@@ -43,7 +43,7 @@ hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float 
                           int S, int d, int pooling, hipStream_t stream);
 
 // Self-attention over packed rows. qkv: [T, 3*d] (q | k | v), ctx: [T, d].  head_dim 64.
-// ctx_tm: ctx is written tile-major.
+// ctx_tm bit 0: ctx is written tile-major; bit 1: qkv is read tile-major (K = 3d).
 hipError_t launch_attention(const f16* qkv, const int32_t* cu_seqlens, f16* ctx, int N, int max_len,
                             int d, int heads, hipStream_t stream, int ctx_tm = 0);
 

@@ -79,39 +79,56 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
   }
 }
 
-// per-utterance standardisation over time (unbiased std): one workgroup of 12 x 80 threads,
-// thread (g, b) walks frames g, g+12, ... of mel bin b; partial sums are combined through LDS.
-__global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restrict__ fb, int frames) {
-  __shared__ float part[12][FB_BINS];
+// per-utterance standardisation over time (two-pass mean / unbiased std, as the reference's
+// converter does).  Three short launches over `nblk` workgroups of 12 x 80 threads (thread (g, b)
+// owns frames g, g+12, ... of its workgroup's frame range for mel bin b, loads independent so they
+// overlap); column partials go through a stream-ordered scratch [2][nblk][80] and every workgroup
+// folds the partials it needs itself (nblk <= 256).
+//   pass 0: part0[blk][b] = sum_f x            pass 1: part1[blk][b] = sum_f (x - mean)^2
+//   pass 2: x = (x - mean) / std
+__global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restrict__ fb, int frames, int per_blk,
+                                                                float* __restrict__ part, int nblk, int pass) {
+  __shared__ float red[12][FB_BINS];
   __shared__ float stat[2][FB_BINS];
   const int b = threadIdx.x % FB_BINS, g = threadIdx.x / FB_BINS;
-  if (frames < 2) return;
-  float s = 0.f;
-  for (int f = g; f < frames; f += 12) s += fb[(size_t)f * FB_BINS + b];
-  part[g][b] = s;
-  __syncthreads();
-  if (g == 0) {
+  float* part0 = part;
+  float* part1 = part + (size_t)nblk * FB_BINS;
+  // fold the partials of the earlier passes
+  for (int q = 0; q < pass; ++q) {
+    const float* src = q == 0 ? part0 : part1;
     float t = 0.f;
-    for (int i = 0; i < 12; ++i) t += part[i][b];
-    stat[0][b] = t / frames;
+    for (int i = g; i < nblk; i += 12) t += src[(size_t)i * FB_BINS + b];
+    red[g][b] = t;
+    __syncthreads();
+    if (g == 0) {
+      float v = 0.f;
+      for (int i = 0; i < 12; ++i) v += red[i][b];
+      stat[q][b] = q == 0 ? v / frames : 1.0f / sqrtf(v / (frames - 1));
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const float mean = stat[0][b];
-  float q = 0.f;
-  for (int f = g; f < frames; f += 12) {
+  const int f0 = blockIdx.x * per_blk, f1 = min(frames, f0 + per_blk);
+  const float mean = pass > 0 ? stat[0][b] : 0.f;
+  if (pass == 2) {
+    const float inv = stat[1][b];
+    for (int f = f0 + g; f < f1; f += 12) {
+      float* p = fb + (size_t)f * FB_BINS + b;
+      *p = (*p - mean) * inv;
+    }
+    return;
+  }
+  float acc = 0.f;
+  for (int f = f0 + g; f < f1; f += 12) {
     const float d = fb[(size_t)f * FB_BINS + b] - mean;
-    q += d * d;
+    acc += pass == 0 ? d : d * d;
   }
-  part[g][b] = q;
+  red[g][b] = acc;
   __syncthreads();
   if (g == 0) {
-    float t = 0.f;
-    for (int i = 0; i < 12; ++i) t += part[i][b];
-    stat[1][b] = 1.0f / sqrtf(t / (frames - 1));
+    float v = 0.f;
+    for (int i = 0; i < 12; ++i) v += red[i][b];
+    (pass == 0 ? part0 : part1)[(size_t)blockIdx.x * FB_BINS + b] = v;
   }
-  __syncthreads();
-  const float inv = stat[1][b];
-  for (int f = g; f < frames; f += 12) fb[(size_t)f * FB_BINS + b] = (fb[(size_t)f * FB_BINS + b] - mean) * inv;
 }
 
 hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
@@ -119,8 +136,19 @@ hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int st
   if (nsamples < FB_WIN) return hipSuccess;
   const int frames = (int)(1 + (nsamples - FB_WIN) / FB_SHIFT);
   hipLaunchKernelGGL(fbank_kernel, dim3(frames), dim3(256), 0, stream, wave, scale, window, mel_w, mel_range, out);
-  if (standardize)
-    hipLaunchKernelGGL(fbank_standardize_kernel, dim3(1), dim3(960), 0, stream, out, frames);
+  if (standardize && frames >= 2) {
+    int per_blk = 48;
+    if ((frames + per_blk - 1) / per_blk > 256) per_blk = ((frames + 255) / 256 + 11) / 12 * 12;
+    const int nblk = (frames + per_blk - 1) / per_blk;
+    float* part = nullptr;
+    hipError_t e = hipMallocAsync((void**)&part, (size_t)2 * nblk * FB_BINS * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    for (int pass = 0; pass < 3; ++pass)
+      hipLaunchKernelGGL(fbank_standardize_kernel, dim3(nblk), dim3(960), 0, stream, out, frames, per_blk, part, nblk,
+                         pass);
+    e = hipFreeAsync(part, stream);
+    if (e != hipSuccess) return e;
+  }
   return hipGetLastError();
 }
 

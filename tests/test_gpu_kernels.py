@@ -189,7 +189,7 @@ def _attention_ref(qkv, lens, d, heads):
 
 @pytest.mark.parametrize("lens,heads", [([128] * 3, 4), ([1, 5, 64, 65, 127, 129, 200, 33], 4),
                                         ([514, 300, 7], 2), ([31, 32, 33, 63], 16)])
-@pytest.mark.parametrize("tm", [0, 1])
+@pytest.mark.parametrize("tm", [0, 1, 2, 3])
 def test_attention(lib, lens, heads, tm):
     from sonar_amd import _lib
 
@@ -200,10 +200,13 @@ def test_attention(lib, lens, heads, tm):
     qkv = (torch.randn(t, 3 * d, device="cuda", generator=g) * 1.5).half()
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
     ctx = torch.full((pad, d), float("nan"), device="cuda", dtype=torch.float16)
-    _lib.check(lib.smi_attention(qkv.data_ptr(), cu.data_ptr(), ctx.data_ptr(), len(lens), max(lens), d, heads, tm,
+    qkv_in = qkv
+    if tm & 2:   # qkv handed over tile-major (K = 3d), rows padded to 256
+        qkv_in = to_tile_major(torch.cat([qkv, torch.zeros(pad - t, 3 * d, device="cuda", dtype=torch.float16)]))
+    _lib.check(lib.smi_attention(qkv_in.data_ptr(), cu.data_ptr(), ctx.data_ptr(), len(lens), max(lens), d, heads, tm,
                                  _stream()))
     torch.cuda.synchronize()
     ref = _attention_ref(qkv, lens, d, heads)
-    got = (from_tile_major(ctx.view(-1), pad, d) if tm else ctx)[:t].float()
+    got = (from_tile_major(ctx.view(-1), pad, d) if tm & 1 else ctx)[:t].float()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 6e-3, (got - ref).abs().max().item()
