@@ -28,15 +28,19 @@ def main():
     st = lambda: int(torch.cuda.current_stream().cuda_stream)
     res = {}
     M = 131072
-    for (n, k, epi) in [(3072, 1024, 0), (1024, 1024, 2), (8192, 1024, 1), (1024, 8192, 2)]:
+    tmf, otm = _lib.SMI_GEMM_IN_TM, _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM
+    # the layouts only change addresses, so the same random buffers serve as row-major or tile-major operands
+    for (n, k, epi) in [(3072, 1024, 0), (1024, 1024, 2), (8192, 1024, 1), (1024, 8192, 2),
+                        (3072, 1024, 0 | otm), (1024, 1024, 2 | tmf), (8192, 1024, 1 | otm), (1024, 8192, 2 | tmf)]:
         x = (torch.randn(M, k, device="cuda") * 0.5).half()
         w = (torch.randn(n, k, device="cuda") * 0.03).half()
         b = torch.randn(n, device="cuda")
-        out = torch.zeros(M, n, device="cuda", dtype=torch.float32 if epi == 2 else torch.float16)
+        out = torch.zeros(M, n, device="cuda", dtype=torch.float32 if (epi & 0xff) == 2 else torch.float16)
         ms = timeit(lambda: _lib.check(lib.smi_gemm_tn(epi, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, n, k, n, st())))
         tf = 2.0 * M * n * k / ms / 1e9
-        res[f"gemm_{n}x{k}_epi{epi}"] = {"ms": ms, "TF": tf}
-        print(f"gemm M={M} N={n} K={k} epi={epi}: {ms:.3f} ms  {tf:.0f} TF/s", flush=True)
+        tag = "tm" if epi & tmf else "rm"
+        res[f"gemm_{n}x{k}_epi{epi & 0xff}_{tag}"] = {"ms": ms, "TF": tf}
+        print(f"gemm {tag} M={M} N={n} K={k} epi={epi & 0xff}: {ms:.3f} ms  {tf:.0f} TF/s", flush=True)
         del x, w, b, out
     if len(sys.argv) > 1 and sys.argv[1] == "gemm":
         return
