@@ -294,6 +294,22 @@ int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny
                   int32_t k, int64_t y_index_offset, int32_t* idx, float* score, void* workspace,
                   void* stream);
 
+/* Host input path ------------------------------------------------------------
+ * Replaces the fairseq2n C++ DataPipeline stages between the tokenizer and the model,
+ * sonar/inference_pipelines/text.py:226-247 (`.map(truncate)`, `.dynamic_bucket(...)`,
+ * `Collater(pad_value)`), fused with the NLLB id assembly of the token encoder
+ * ([prefix] piece+1 ... [suffix]).  Pure host code (threads), writes into the caller's
+ * (pinned) staging buffer.  SentencePiece segmentation itself is done by the caller with the
+ * sentencepiece library's multi-threaded batch encode, as `pieces` (flat int32) + `piece_offsets`. */
+int smi_host_token_lengths(const int64_t* piece_offsets, int64_t n, int32_t n_prefix, int32_t n_suffix,
+                           int32_t max_seq_len, int32_t* out_lens, int64_t* n_truncated);
+int smi_host_dynamic_bucket(const int32_t* lens, int64_t n, int64_t threshold, int32_t max_num,
+                            int32_t min_num, int64_t* bounds, int64_t* n_buckets, int64_t* n_open);
+int smi_host_collate_nllb(const int32_t* pieces, const int64_t* piece_offsets, const int32_t* lens,
+                          int64_t first, int64_t n, const int64_t* prefix, int32_t n_prefix,
+                          const int64_t* suffix, int32_t n_suffix, int32_t piece_shift, int64_t pad_value,
+                          int64_t* out_ids, int32_t row_stride, int32_t num_threads);
+
 /* Building blocks (exported for the parity tests and microbenchmarks) ------ */
 /* TILE-MAJOR operand layout (SMI_GEMM_IN_TM / SMI_GEMM_OUT_TM, `tile_major` arguments): a K-major
  * fp16 matrix A[rows][k] (rows % 256 == 0, k % 32 == 0) stored as 16-KiB blocks, block

@@ -207,6 +207,9 @@ SYMBOLS = {
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "smi_host_token_lengths": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, C.POINTER(_i64)]),
+    "smi_host_dynamic_bucket": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "smi_host_collate_nllb": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32]),
     "smi_pack_tile_major": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "smi_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

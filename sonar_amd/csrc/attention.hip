@@ -44,12 +44,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const size_t ld = (size_t)3 * d;
-  const f16* qbase = qkv + (size_t)start * ld + h * 64;
-  const f16* kbase = qbase + d;
-  const f16* vbase = qbase + 2 * d;
 
   const int qi = q0 + wave * 32 + l31;
-  const f16* qptr = qbase + (size_t)min(qi, len - 1) * ld;
   const int K3 = 3 * d;
   // element (row r of this sentence, column c of the [q | k | v] row)
   auto at = [&](int r, int c) -> const f16* {
@@ -58,12 +54,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
   };
   half8 qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    if constexpr (QTM)
-      qf[ks] = *(const half8*)at(min(qi, len - 1), h * 64 + (ks * 2 + hi) * 8);
-    else
-      qf[ks] = *(const half8*)(qptr + (ks * 2 + hi) * 8);
-  }
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)at(min(qi, len - 1), h * 64 + (ks * 2 + hi) * 8);
 
   float m = -1e30f, lsum = 0.f;
   f32x16 o[2];

@@ -16,7 +16,7 @@ from typing import Iterable, Iterator, List, Optional, Sequence, Union
 import torch
 
 from ..text_encoder import SonarTextTransformerEncoderModel, load_sonar_text_encoder
-from ..tokenizer import NllbTokenizer
+from ..tokenizer import NllbEncoder, NllbTokenizer
 from .utils import add_progress_bar, extract_sequence_batch
 
 CPU = torch.device("cpu")
@@ -122,6 +122,9 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
         self.model = encoder.eval()
         self.device = getattr(encoder, "device", device)
         self.dtype = dtype
+        # "native": sonar_amd.host_input (C++ host threads); "python": the per-sentence restatement
+        # of the reference pipeline below (any tokenizer object with create_encoder())
+        self.host_input = "native"
 
     @torch.inference_mode()
     def predict(self, input: Union[Path, Sequence[str]], source_lang: str,
@@ -168,7 +171,17 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
         pad_idx = self.tokenizer.vocab_info.pad_idx
         dev = self.device
 
+        stats = {"n_truncated": 0}
+        native = self.host_input == "native" and isinstance(tokenizer_encoder, NllbEncoder)
+
         def upstream():
+            if native:  # C++ host path: batch SentencePiece + threaded assembly/bucketing/collation
+                from ..host_input import iter_text_batches
+
+                yield from iter_text_batches(texts, order, tokenizer_encoder, max_seq_len=max_seq_len,
+                                             batch_size=batch_size, batch_max_tokens=batch_max_tokens,
+                                             pad_idx=pad_idx, device=torch.device(dev), stats=stats)
+                return
             toks = (truncate(tokenizer_encoder(texts[i])) for i in order)
             for bucket in dynamic_bucket(toks, batch_max_tokens or 2**31, batch_size or 20_000):
                 yield extract_sequence_batch(collate(bucket, pad_idx), dev)
@@ -183,6 +196,7 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
                 out = self.model(batch)
                 results.append(out.sentence_embeddings.to(target_device or self.device))
 
+        n_truncated += stats["n_truncated"]
         if n_truncated:
             warnings.warn(f"For {n_truncated} input tensors for SONAR text encoder, "
                           f"the length was truncated to {max_seq_len} elements.")

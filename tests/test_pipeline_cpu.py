@@ -161,3 +161,71 @@ def test_checkpoint_conversion_layouts():
     assert convert_sonar_text_encoder_checkpoint(m)["encoder_frontend.embed.weight"] is emb
     with pytest.raises(ValueError):
         convert_sonar_text_encoder_checkpoint({"weights": {}})
+
+
+def test_native_host_path_equals_python_path(spm_model):
+    """The C++ host input path (sonar_amd/host_input.py + smi_host_*) must produce the same batches
+    -- shapes, padding masks, ids, order, truncation count -- as the per-sentence restatement."""
+    tok = NllbTokenizer(spm_model)
+    words = ["hello", "world", "my", "name", "is", "paul", "teacher", "bonjour", "monde", "fox", "jumps"]
+    g = torch.Generator().manual_seed(3)
+    texts = [" ".join(words[int(i)] for i in torch.randint(0, len(words), (int(torch.randint(1, 14, (1,), generator=g)),),
+                                                           generator=g)) for _ in range(137)]
+    texts[5] = ""          # empty sentence: [lang, eos] only
+    for kw in (dict(batch_size=8), dict(batch_size=None, batch_max_tokens=40), dict(batch_size=16, batch_max_tokens=64),
+               dict(batch_size=1000), dict(batch_size=8, max_seq_len=9)):
+        got = {}
+        for mode in ("native", "python"):
+            stub = _StubEncoder()
+            pipe = TextToEmbeddingModelPipeline(stub, tok, device=torch.device("cpu"))
+            pipe.host_input = mode
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                out = pipe.predict(texts, source_lang="fra_Latn", **kw)
+            got[mode] = (out, stub.batches, sorted(str(x.message) for x in w))
+        assert torch.equal(got["native"][0], got["python"][0]), kw
+        assert got["native"][1] == got["python"][1], kw
+        assert got["native"][2] == got["python"][2], kw
+    # the native path crosses its tokenisation-chunk boundary with an open bucket
+    from sonar_amd.host_input import iter_text_batches
+
+    enc = tok.create_encoder(lang="eng_Latn")
+    a = list(iter_text_batches(texts, range(len(texts)), enc, max_seq_len=16, batch_size=7, batch_max_tokens=None,
+                               pad_idx=0, device=torch.device("cpu"), chunk=10))
+    b = list(iter_text_batches(texts, range(len(texts)), enc, max_seq_len=16, batch_size=7, batch_max_tokens=None,
+                               pad_idx=0, device=torch.device("cpu"), chunk=10_000))
+    assert len(a) == len(b) == (len(texts) + 6) // 7
+    for x, y in zip(a, b):
+        assert torch.equal(x.seqs, y.seqs) and (x.padding_mask is None) == (y.padding_mask is None)
+
+
+def test_host_abi_functions():
+    import ctypes as C
+
+    import numpy as np
+
+    from sonar_amd import _lib
+
+    lib = _lib.load()
+    off = np.array([0, 3, 3, 10], dtype=np.int64)          # piece counts 3, 0, 7
+    lens = np.zeros(3, dtype=np.int32)
+    cut = C.c_int64(-1)
+    assert lib.smi_host_token_lengths(off.ctypes.data, 3, 1, 1, 6, lens.ctypes.data, C.byref(cut)) == 0
+    assert lens.tolist() == [5, 2, 6] and cut.value == 1
+    pieces = np.arange(100, 110, dtype=np.int32)
+    out = np.full((3, 7), -7, dtype=np.int64)
+    pre, suf = np.array([900], dtype=np.int64), np.array([3], dtype=np.int64)
+    assert lib.smi_host_collate_nllb(pieces.ctypes.data, off.ctypes.data, lens.ctypes.data, 0, 3, pre.ctypes.data, 1,
+                                     suf.ctypes.data, 1, 1, 0, out.ctypes.data, 7, 4) == 0
+    assert out.tolist() == [[900, 101, 102, 103, 3, 0, 0], [900, 3, 0, 0, 0, 0, 0],
+                            [900, 104, 105, 106, 107, 108, 0]]  # third row truncated to 6: its EOS is lost
+    # row_stride smaller than a sequence is refused
+    assert lib.smi_host_collate_nllb(pieces.ctypes.data, off.ctypes.data, lens.ctypes.data, 0, 3, pre.ctypes.data, 1,
+                                     suf.ctypes.data, 1, 1, 0, out.ctypes.data, 5, 1) != 0
+    bl = np.array([3, 4, 5, 1, 2, 9], dtype=np.int32)
+    bounds = np.zeros(7, dtype=np.int64)
+    nb, nopen = C.c_int64(0), C.c_int64(0)
+    assert lib.smi_host_dynamic_bucket(bl.ctypes.data, 6, 7, 100, 1, bounds.ctypes.data, C.byref(nb), C.byref(nopen)) == 0
+    assert bounds[:nb.value + 1].tolist() == [0, 2, 5, 6] and nopen.value == 0
+    assert lib.smi_host_dynamic_bucket(bl.ctypes.data, 6, 2**31, 4, 1, bounds.ctypes.data, C.byref(nb), C.byref(nopen)) == 0
+    assert bounds[:nb.value + 1].tolist() == [0, 4] and nopen.value == 2
