@@ -294,6 +294,37 @@ int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny
                   int32_t k, int64_t y_index_offset, int32_t* idx, float* score, void* workspace,
                   void* stream);
 
+/* Embedding heads: BLASER / MuTox ---------------------------------------------
+ * A small MLP over (features of) sentence embeddings.  Replaces
+ *   BlaserModel.forward = F.normalize -> featurize_input -> mlp   sonar/models/blaser/model.py:82-125
+ *   MutoxClassifier.forward = model_all (+ sigmoid)               sonar/models/mutox/model.py:18-24,
+ *                                                                 sonar/models/mutox/factory.py:15-38
+ * Hidden layers need in % 64 == 0 and out % 128 == 0 (MFMA GEMM tiles); the output layer has 1..8 units. */
+typedef struct smi_mlp_head smi_mlp_head; /* opaque */
+typedef struct smi_mlp_head_config {
+  int32_t input_dim;  /* feature width: 6*d (COMET), 4*d (QE), d (MuTox) */
+  int32_t n_layers;   /* Linear layers including the output layer, 1..8 */
+  int32_t hidden_act; /* 0 ReLU, 1 tanh */
+  int32_t out_act;    /* 0 none, 1 tanh (BLASER output_act), 2 sigmoid (MuTox output_prob) */
+} smi_mlp_head_config;
+typedef struct smi_mlp_head_layer {
+  smi_tensor w; /* [out_dim, in_dim], nn.Linear layout */
+  smi_tensor b; /* [out_dim] */
+  int32_t out_dim;
+  int32_t reserved;
+} smi_mlp_head_layer;
+int smi_mlp_head_create(const smi_mlp_head_config* cfg, const smi_mlp_head_layer* layers, smi_mlp_head** out);
+void smi_mlp_head_destroy(smi_mlp_head* head);
+/* features: form 0 f16(src); 1 QE [src, mt, src*mt, |mt-src|]; 2 COMET [ref, mt, src*mt, ref*mt,
+ * |mt-src|, |mt-ref|] (model.py:95-125), inputs L2-normalised first when norm_emb (model.py:89-93).
+ * src/mt/ref: device [rows, d] of `dtype`; out: device f16 [(rows+127)/128*128, blocks*d], pad rows zeroed. */
+int smi_head_featurize(int32_t form, const void* src, const void* mt, const void* ref, int32_t dtype, int32_t rows,
+                       int32_t d, int32_t norm_emb, void* out_f16, void* stream);
+/* x: device f16 [(rows+127)/128*128, input_dim]; out: device fp32 [rows, out_dim];
+ * out_act -1 = the configured one, else 0 / 1 / 2 as above. */
+int smi_mlp_head_forward(smi_mlp_head* head, const void* x_f16, int32_t rows, int32_t out_act, float* out,
+                         void* stream);
+
 /* Host input path ------------------------------------------------------------
  * Replaces the fairseq2n C++ DataPipeline stages between the tokenizer and the model,
  * sonar/inference_pipelines/text.py:226-247 (`.map(truncate)`, `.dynamic_bucket(...)`,
@@ -324,7 +355,7 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
                         void* stream);
 /* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi & 0xff: 0 f16 out, 1 f16 ReLU out,
  * 2 fp32 residual accumulate (out += ...), 3 fp32 store, 4 fp32 residual += 0.5 * (...),
- * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide) (bias may be NULL);
+ * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out (bias may be NULL);
  * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
  * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1).
  * m%128==0, n%128==0, k%64==0. */

@@ -175,6 +175,14 @@ class smi_speech_encoder_weights(C.Structure):
         ("layers", C.POINTER(smi_conformer_layer)), ("pooler", C.POINTER(smi_pooler_layer))]
 
 
+class smi_mlp_head_config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("input_dim", "n_layers", "hidden_act", "out_act")]
+
+
+class smi_mlp_head_layer(C.Structure):
+    _fields_ = [("w", smi_tensor), ("b", smi_tensor), ("out_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
@@ -207,6 +215,10 @@ SYMBOLS = {
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "smi_mlp_head_create": (C.c_int, [C.POINTER(smi_mlp_head_config), C.POINTER(smi_mlp_head_layer), C.POINTER(_vp)]),
+    "smi_mlp_head_destroy": (None, [_vp]),
+    "smi_head_featurize": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "smi_mlp_head_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "smi_host_token_lengths": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, C.POINTER(_i64)]),
     "smi_host_dynamic_bucket": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "smi_host_collate_nllb": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32]),

@@ -17,11 +17,14 @@ namespace smi {
 // EPI_STORE_F32     : out_f[m][n]  = acc + bias[n]            (fp32 logits / split-K slabs)
 // EPI_RESID_HALF_F32: resid[m][n] += 0.5 * (acc + bias[n])    (macaron half-step FFN)
 // EPI_SILU_F16      : out_h[m][n]  = f16(silu(acc + bias[n]))
+// EPI_TANH_F16      : out_h[m][n]  = f16(tanh(acc + bias[n]))
 // EPI_GLU_F16       : out_h[m][g*32+c] = f16(a * sigmoid(b)), a/b = columns g*64+c / g*64+32+c
 //                     (W rows interleaved in 32-channel groups at pack time), out width N/2
 // bias may be null for every epilogue.
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// tanh(v) = 1 - 2 / (exp(2v) + 1); exact limits at +-inf (exp -> inf gives 1, exp -> 0 gives -1)
+__device__ __forceinline__ float tanh_f(float v) { return 1.0f - 2.0f / (__expf(2.0f * v) + 1.0f); }
 
 template <int EPI>
 __device__ __forceinline__ f32x4 epi_act(f32x4 v) {
@@ -31,6 +34,9 @@ __device__ __forceinline__ f32x4 epi_act(f32x4 v) {
   } else if constexpr (EPI == EPI_SILU_F16) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+  } else if constexpr (EPI == EPI_TANH_F16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tanh_f(v[e]);
   }
   return v;
 }
@@ -419,6 +425,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     SMI_EPI_CASE(EPI_RESID_HALF_F32, 0)
     SMI_EPI_CASE(EPI_SILU_F16, 0)
     SMI_EPI_CASE(EPI_GLU_F16, 0)
+    SMI_EPI_CASE(EPI_TANH_F16, 0)
   }
 #undef SMI_EPI_CASE
   return hipErrorInvalidValue;

@@ -10,7 +10,7 @@ typedef _Float16 f16;
 
 enum GemmEpilogue {
   EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3,
-  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6
+  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6, EPI_TANH_F16 = 7
 };
 
 // layout flags OR-ed into epi_sel (tile-major layout: common.hpp tm_offset)
@@ -96,6 +96,16 @@ hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, co
                               int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream);
 hipError_t launch_gather_tokens(const int64_t* src, int src_stride, int col, int32_t* tok, int rows,
                                 hipStream_t stream);
+
+// ---- embedding heads: BLASER / MuTox MLPs (heads.hip) ----
+// form 0: out = f16(x) (src only); 1 QE: [src, mt, src*mt, |mt-src|]; 2 COMET:
+// [ref, mt, src*mt, ref*mt, |mt-src|, |mt-ref|]; inputs optionally L2-normalised first (F.normalize).
+// out: [rows rounded up to 128][blocks * d] fp16, padding rows zero.
+hipError_t launch_head_featurize(int form, const void* src, const void* mt, const void* ref, int in_is_f32,
+                                 int rows, int d, int norm, f16* out, hipStream_t stream);
+// out[r][o] = act(h[r,:] . w[o,:] + b[o]) for o < out_dim (<= 8); act 0 none, 1 tanh, 2 sigmoid
+hipError_t launch_head_output(const f16* h, int ldh, const float* w, const float* b, int rows, int K, int out_dim,
+                              int act, float* out, hipStream_t stream);
 
 // ---- speech path (speech.hip) ----
 hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
