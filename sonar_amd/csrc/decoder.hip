@@ -131,8 +131,10 @@ hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t
 
 // -------------------------------------------------- single-query (decode) attention
 // One wave per (row, head).  kv: [pos][rows_pad][3d] (q|k|v), anc: [rows][anc_stride].
-// QK^T: lane j owns position j (128-B contiguous K row per lane); softmax across lanes;
-// PV: lane owns one of the 64 head dims, positions are broadcast with readlane-style shuffles.
+// Lane (pg = lane>>3, c = lane&7) owns the 8 head dims c*8..c*8+7 of the positions j0 + 8*it + pg:
+// every load instruction fetches 8 whole 128-B K (or V) rows as 16 B per lane, a score is joined
+// across the 8 lanes of its position by 3 xor-shuffles, the softmax statistics across the 8 position
+// groups by 3 more, and the probabilities never leave the lanes that multiply them into V.
 __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restrict__ kv,
                                                             const int32_t* __restrict__ anc,
                                                             int anc_stride, f16* __restrict__ ctx,
@@ -141,48 +143,76 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= rows * heads) return;
   const int r = wid / heads, h = wid % heads;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, pg = lane >> 3, c = lane & 7;
   const size_t ld = (size_t)3 * d;
   const size_t slab = (size_t)rows_pad * ld;
-  const f16* qp = kv + (size_t)pos * slab + (size_t)r * ld + h * 64;
-  half8 q[8];
+  const half8 qh = *(const half8*)(kv + (size_t)pos * slab + (size_t)r * ld + h * 64 + c * 8);
+  float q[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) q[i] = *(const half8*)(qp + i * 8);
+  for (int e = 0; e < 8; ++e) q[e] = (float)qh[e] * sl2e;
 
   const int32_t* ar = anc + (size_t)r * anc_stride;
-  float m = -1e30f, l = 0.f, o = 0.f;  // o: this lane's head-dim accumulator
+  const f16* kbase = kv + d + h * 64 + c * 8;
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
   for (int j0 = 0; j0 <= pos; j0 += 64) {
-    const int j = j0 + lane;
-    float s = -INFINITY;
-    int src = 0;
-    if (j <= pos) {
-      src = j == pos ? r : ar[j];
-      const f16* kp = kv + (size_t)j * slab + (size_t)src * ld + d + h * 64;
+    float s[8];
+    const f16* row[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int j = j0 + it * 8 + pg;
+      const bool valid = j <= pos;
+      const int src = valid ? (j == pos ? r : ar[j]) : 0;
+      row[it] = kbase + (size_t)(valid ? j : 0) * slab + (size_t)src * ld;
+      const half8 kk = *(const half8*)row[it];
       float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const half8 kk = *(const half8*)(kp + i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += (float)q[i][e] * (float)kk[e];
-      }
-      s = acc * sl2e;
+      for (int e = 0; e < 8; ++e) acc += q[e] * (float)kk[e];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      s[it] = valid ? acc : -INFINITY;
     }
-    const float mx = wave_max(s);
+    float mx = s[0];
+#pragma unroll
+    for (int it = 1; it < 8; ++it) mx = fmaxf(mx, s[it]);
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    const float p = __builtin_amdgcn_exp2f(s - m_new);  // 0 for masked lanes
-    l = l * alpha + wave_sum(p);
-    o *= alpha;
+    float ps = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      s[it] = __builtin_amdgcn_exp2f(s[it] - m_new);  // 0 for masked positions
+      ps += s[it];
+    }
+    ps += __shfl_xor(ps, 8, 64);
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * alpha + ps;
     m = m_new;
-    const int cnt = min(64, pos + 1 - j0);
-    for (int t = 0; t < cnt; ++t) {
-      const float pt = __shfl(p, t, 64);
-      const int st = __shfl(src, t, 64);
-      const f16* vp = kv + (size_t)(j0 + t) * slab + (size_t)st * ld + 2 * d + h * 64;
-      o += pt * (float)vp[lane];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= alpha;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const half8 vv = *(const half8*)(row[it] + d);  // the V row follows the K row at +d
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += s[it] * (float)vv[e];
     }
   }
-  ctx[(size_t)r * d + h * 64 + lane] = (f16)(o / l);
+  half8 out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = o[e];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    out[e] = (f16)(v / l);
+  }
+  if (pg == 0) *(half8*)(ctx + (size_t)r * d + h * 64 + c * 8) = out;
 }
 
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
@@ -194,202 +224,168 @@ hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_strid
   return hipGetLastError();
 }
 
-// ----------------------------------------------------- vocabulary scan (per row, per chunk)
-// For logits[row][c0 .. c0+4096): chunk max, sum exp(x - max) and the top-K2 entries by
-// value among tokens that may be generated (PAD excluded; EOS excluded when blocked).
-constexpr int VS_CHUNK = 4096;
+// candidate ordering shared by the selection and the beam step: value desc, token asc
 constexpr int VS_K2MAX = 16;
 
 __device__ __forceinline__ bool cand_better(float a, int ia, float b, int ib) {
   return a > b || (a == b && ia < ib);
 }
 
-__global__ __launch_bounds__(256) void vocab_scan_kernel(const float* __restrict__ logits, int ldl,
-                                                         int vocab, int k2, float inv_temp,
-                                                         int pad_idx, int eos_idx, int unk_idx,
-                                                         float unk_penalty, int block_eos,
-                                                         float* __restrict__ pmax,
-                                                         float* __restrict__ psum,
-                                                         float* __restrict__ pval,
-                                                         int* __restrict__ pidx, int nchunks) {
-  __shared__ float s_red[4];
-  const int row = blockIdx.y, chunk = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int c0 = chunk * VS_CHUNK;
-  const float* lp = logits + (size_t)row * ldl + c0;
-  float v[16];
-  int id[16];
-  float tmax = -INFINITY;
+// ------------------------------------------------- vocabulary select (per row, tile statistics)
+// The logits GEMM leaves, per row and 256-column tile, the tile maximum and sum exp(v - max)
+// (GemmTileStats).  One workgroup per row then
+//  1. folds the tile statistics into the row's softmax normaliser (pmax, psum), and
+//  2. finds the top-k2 candidates WITHOUT reading the whole logits row: the k2 best tiles by maximum
+//     (ties: lower tile first) among tiles >= 1 contain every candidate that can reach the top-k2 --
+//     each of them holds an element >= the k2-th best tile maximum, and an element of a later tile
+//     loses every value tie against them (lower token wins).  Tile 0 is always read too: it holds the
+//     tokens the generation masks touch (PAD, UNK penalty, blocked EOS), so its raw maximum says
+//     nothing.  Thread t owns column t of every selected tile; k2 rounds of a workgroup-wide arg-max
+//     over sortable (value desc, token asc) keys produce the exact ordered list.
+constexpr int VSEL_SLOTS = VS_K2MAX + 1;
+
+__device__ __forceinline__ unsigned long long cand_key(float v, int idx) {
+  unsigned u = __float_as_uint(v);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)idx);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int off = k * 1024 + tid * 4;
-    f32x4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    if (c0 + off + 3 < vocab) {
-      x = *(const f32x4*)(lp + off);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c0 + off + e < vocab) x[e] = lp[off + e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[k * 4 + e] = x[e] * inv_temp;
-      id[k * 4 + e] = c0 + off + e;
-      tmax = fmaxf(tmax, v[k * 4 + e]);
-    }
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(k, o, 64);
+    k = other > k ? other : k;
   }
-  // chunk max / sum-exp over ALL vocabulary entries (softmax normaliser)
-  float wm = wave_max(tmax);
-  if (lane == 0) s_red[wv] = wm;
+  return k;
+}
+
+__global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restrict__ logits, int ldl, int vocab,
+                                                           const float* __restrict__ tile_max,
+                                                           const float* __restrict__ tile_sum, int ntiles, int k2,
+                                                           float inv_temp, int pad_idx, int eos_idx, int unk_idx,
+                                                           float unk_penalty, int block_eos,
+                                                           float* __restrict__ pmax, float* __restrict__ psum,
+                                                           float* __restrict__ pval, int* __restrict__ pidx) {
+  __shared__ float s_f[4];
+  __shared__ unsigned long long s_k[4];
+  __shared__ int s_sel[VSEL_SLOTS];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* tm = tile_max + (size_t)row * ntiles;
+  const float* ts = tile_sum + (size_t)row * ntiles;
+  constexpr int TPT = 8;  // tiles per thread: up to 2048 tiles = 524288 tokens
+  float m[TPT], sm[TPT];
+  float lm = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) {
+    const int t = tid + 256 * j;
+    m[j] = t < ntiles ? tm[t] : -INFINITY;
+    sm[j] = t < ntiles ? ts[t] : 0.f;
+    lm = fmaxf(lm, m[j]);
+  }
+  // ---- 1. softmax normaliser of the row
+  lm = wave_max(lm);
+  if (lane == 0) s_f[wv] = lm;
   __syncthreads();
-  const float cmax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float M = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
   float se = 0.f;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) se += (v[k] == -INFINITY) ? 0.f : __expf(v[k] - cmax);
+  for (int j = 0; j < TPT; ++j)
+    if (m[j] != -INFINITY) se += sm[j] * __expf(m[j] - M);
   se = wave_sum(se);
   __syncthreads();
-  if (lane == 0) s_red[wv] = se;
+  if (lane == 0) s_f[wv] = se;
   __syncthreads();
   if (tid == 0) {
-    pmax[(size_t)row * nchunks + chunk] = cmax;
-    psum[(size_t)row * nchunks + chunk] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    pmax[row] = M;
+    psum[row] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
   }
-  // candidates: apply the generation masks (they act on log-probs AFTER the softmax)
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (id[k] == pad_idx || (block_eos && id[k] == eos_idx) || id[k] >= vocab) v[k] = -INFINITY;
-    else if (id[k] == unk_idx) v[k] -= unk_penalty;
-  }
-  // Top-k2 of the chunk.  Fast path: per wave, the k2-th largest LANE maximum is a lower
-  // bound of the k2-th largest element, so only entries >= that threshold can be in the
-  // top-k2; the few survivors of the 4 waves are compacted into LDS as sortable 64-bit keys
-  // (value desc, token asc) and ranked by wave 0.  Slow exact path if the survivor list
-  // overflows (massive ties).
-  constexpr int CAP = 128;
-  __shared__ unsigned long long surv[CAP];
-  __shared__ int surv_n;
-  __shared__ float w_val[4 * VS_K2MAX];
-  __shared__ int w_idx[4 * VS_K2MAX];
   if (k2 == 0) return;
-  if (tid == 0) surv_n = 0;
-  float lmax = v[0];
-#pragma unroll
-  for (int k = 1; k < 16; ++k) lmax = fmaxf(lmax, v[k]);
-  float thr = -INFINITY;
-  {
-    float t = lmax;
-    for (int round = 0; round < k2; ++round) {
-      const float mval = wave_max(t);
-      thr = mval;
-      if (mval == -INFINITY) break;
-      const unsigned long long owners = __ballot(t == mval);
-      if (lane == __ffsll((long long)owners) - 1) t = -INFINITY;
-    }
+  // ---- 2a. the k2 best tiles among tiles >= 1 (value desc, tile asc), plus tile 0
+  if (tid == 0) {
+    s_sel[0] = 0;
+    m[0] = -INFINITY;  // tile 0 is taken unconditionally
   }
-  __syncthreads();  // surv_n = 0 visible
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (v[k] >= thr && v[k] != -INFINITY) {
-      const int slot = atomicAdd(&surv_n, 1);
-      if (slot < CAP) {
-        unsigned u = __float_as_uint(v[k]);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-        surv[slot] = ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)id[k]);
-      }
-    }
-  }
-  __syncthreads();
-  const int ns = surv_n;
-  if (ns <= CAP) {
-    if (wv == 0) {
-      unsigned long long k0 = lane < ns ? surv[lane] : 0ull;
-      unsigned long long k1 = lane + 64 < ns ? surv[lane + 64] : 0ull;
-      for (int round = 0; round < k2; ++round) {
-        unsigned long long best = k0 > k1 ? k0 : k1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const unsigned long long other = __shfl_xor(best, o, 64);
-          best = other > best ? other : best;
-        }
-        if (lane == 0) {
-          float val = -INFINITY;
-          int idx = 0x7fffffff;
-          if (best != 0ull) {
-            unsigned u = (unsigned)(best >> 32);
-            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-            val = __uint_as_float(u);
-            idx = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
-          }
-          pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = val;
-          pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = idx;
-        }
-        if (k0 == best) k0 = 0ull;
-        if (k1 == best) k1 = 0ull;
-      }
-    }
-    return;
-  }
-  // ---- slow exact path: every wave extracts the k2 best of its 1024 entries ...
+  int nsel = 1;
   for (int round = 0; round < k2; ++round) {
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
+    unsigned long long best = 0ull;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (cand_better(v[k], id[k], bv, bi)) {
-        bv = v[k];
-        bi = id[k];
+    for (int j = 0; j < TPT; ++j)
+      if (m[j] != -INFINITY) {
+        const unsigned long long k = cand_key(m[j], tid + 256 * j);
+        best = k > best ? k : best;
       }
+    best = wave_max_u64(best);
+    __syncthreads();
+    if (lane == 0) s_k[wv] = best;
+    __syncthreads();
+    unsigned long long b = s_k[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(bv, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (cand_better(ov, oi, bv, bi)) {
-        bv = ov;
-        bi = oi;
-      }
-    }
-    if (lane == 0) {
-      w_val[wv * VS_K2MAX + round] = bv;
-      w_idx[wv * VS_K2MAX + round] = bi;
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (id[k] == bi) v[k] = -INFINITY;  // taken
+    for (int w = 1; w < 4; ++w) b = s_k[w] > b ? s_k[w] : b;
+    if (b == 0ull) break;  // fewer than k2 tiles
+    const int t = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
+    if (tid == 0) s_sel[nsel] = t;
+    ++nsel;
+    if ((t & 255) == tid) m[t >> 8] = -INFINITY;
   }
   __syncthreads();
-  // ... and wave 0 merges the 4 x k2 lists (one candidate per lane)
-  if (wv == 0) {
-    const int src = (lane / k2) * VS_K2MAX + (lane % k2);
-    float cv = lane < 4 * k2 ? w_val[src] : -INFINITY;
-    const int ci = lane < 4 * k2 ? w_idx[src] : 0x7fffffff;
-    for (int round = 0; round < k2; ++round) {
-      float bv = cv;
-      int bi = ci;
+  // ---- 2b. thread t owns column t of every selected tile
+  float v[VSEL_SLOTS];
+  int id[VSEL_SLOTS];
+  const float* lp = logits + (size_t)row * ldl;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (cand_better(ov, oi, bv, bi)) {
-          bv = ov;
-          bi = oi;
-        }
+  for (int j = 0; j < VSEL_SLOTS; ++j) {
+    v[j] = -INFINITY;
+    id[j] = 0x7fffffff;
+    if (j < nsel) {
+      const int tok = s_sel[j] * 256 + tid;
+      id[j] = tok;
+      if (tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
+        v[j] = lp[tok] * inv_temp;
+        if (tok == unk_idx) v[j] -= unk_penalty;
       }
-      if (lane == 0) {
-        pval[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bv;
-        pidx[((size_t)row * nchunks + chunk) * VS_K2MAX + round] = bi;
-      }
-      if (ci == bi) cv = -INFINITY;
     }
+  }
+  // ---- 2c. ordered top-k2 by k2 workgroup-wide arg-max rounds
+  for (int round = 0; round < k2; ++round) {
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < VSEL_SLOTS; ++j)
+      if (v[j] != -INFINITY) {
+        const unsigned long long k = cand_key(v[j], id[j]);
+        best = k > best ? k : best;
+      }
+    best = wave_max_u64(best);
+    __syncthreads();
+    if (lane == 0) s_k[wv] = best;
+    __syncthreads();
+    unsigned long long b = s_k[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = s_k[w] > b ? s_k[w] : b;
+    float val = -INFINITY;
+    int idx = 0x7fffffff;
+    if (b != 0ull) {
+      unsigned u = (unsigned)(b >> 32);
+      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+      val = __uint_as_float(u);
+      idx = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
+    }
+    if (tid == 0) {
+      pval[(size_t)row * VS_K2MAX + round] = val;
+      pidx[(size_t)row * VS_K2MAX + round] = idx;
+    }
+#pragma unroll
+    for (int j = 0; j < VSEL_SLOTS; ++j)
+      if (id[j] == idx) v[j] = -INFINITY;
   }
 }
 
-hipError_t launch_vocab_scan(const float* logits, int ldl, int rows, int vocab, int k2, float inv_temp,
-                             int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int block_eos,
-                             float* pmax, float* psum, float* pval, int* pidx, hipStream_t stream) {
-  const int nchunks = (vocab + VS_CHUNK - 1) / VS_CHUNK;
-  hipLaunchKernelGGL(vocab_scan_kernel, dim3(nchunks, rows), dim3(256), 0, stream, logits, ldl, vocab,
-                     k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval,
-                     pidx, nchunks);
+hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
+                               const float* tile_sum, int ntiles, int k2, float inv_temp, int pad_idx, int eos_idx,
+                               int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
+                               int* pidx, hipStream_t stream) {
+  if (rows <= 0 || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, vocab, tile_max, tile_sum,
+                     ntiles, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
   return hipGetLastError();
 }
 

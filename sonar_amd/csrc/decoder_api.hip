@@ -32,6 +32,7 @@ struct smi_text_decoder {
   DevBuf tok, cum, parent, new_tok, new_cum, nactive, done, ndone, fin_count, fin_len, fin_score, fin_tok;
   DevBuf anc[2], hist[2];
   DevBuf pmax, psum, pval, pidx;
+  DevBuf tile_max, tile_sum;  // logits-GEMM tile statistics [rows_pad][vocab_pad / 256]
   DevBuf zero_cc;
   int64_t weight_bytes = 0;
   int kv_positions = 0;  // positions per layer in the current kv allocation
@@ -78,7 +79,7 @@ int compute_cross_constants(smi_text_decoder* D, const void* emb, int emb_dtype,
 
 // one decoder step at position `pos` for `rows` rows (rows_pad GEMM rows); logits -> D->logits
 int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_pad, int pos,
-                 const int32_t* anc, int anc_stride, hipStream_t stream) {
+                 const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f) {
   const smi_text_decoder_config& c = D->cfg;
   const int d = c.model_dim, f = c.ffn_inner_dim;
   float* x = D->x.as<float>();
@@ -112,8 +113,11 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
   }
   HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,
                                D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+  // beam search (stats_scale = 1 / temperature > 0): the GEMM also leaves per-tile softmax
+  // statistics, so the candidate selection never re-reads the 1 MB logits rows
+  GemmTileStats st{D->tile_max.as<float>(), D->tile_sum.as<float>(), stats_scale, (int)c.vocab_size};
   HIP_TRY(launch_gemm_tn(EPI_STORE_F32, h, D->embed.as<f16>(), nullptr, D->logits.p, rows_pad, (int)D->vocab_pad, d,
-                         (int)D->vocab_pad, stream));
+                         (int)D->vocab_pad, stream, stats_scale > 0.f ? &st : nullptr));
   return SMI_OK;
 }
 
@@ -278,7 +282,6 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   const int rows_pad = (int)round_up(rows, 256), n_pad = (int)round_up(n, 256);
   const int stride = c.max_seq_len + 1;
   const int k2 = 2 * beam;
-  const int nchunks = (int)((c.vocab_size + kVocabScanChunk - 1) / kVocabScanChunk);
   if (int rc = ensure_step_workspace(D, rows_pad, max_len)) return rc;
   HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
   HIP_TRY(D->cum.reserve((size_t)rows * 4));
@@ -296,32 +299,34 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
     HIP_TRY(D->anc[i].reserve((size_t)rows_pad * stride * 4));
     HIP_TRY(D->hist[i].reserve((size_t)rows_pad * stride * 4));
   }
-  HIP_TRY(D->pmax.reserve((size_t)rows * nchunks * 4));
-  HIP_TRY(D->psum.reserve((size_t)rows * nchunks * 4));
-  HIP_TRY(D->pval.reserve((size_t)rows * nchunks * kVocabScanK2Max * 4));
-  HIP_TRY(D->pidx.reserve((size_t)rows * nchunks * kVocabScanK2Max * 4));
+  const int ntiles = (int)(D->vocab_pad / 256);
+  HIP_TRY(D->pmax.reserve((size_t)rows * 4));
+  HIP_TRY(D->psum.reserve((size_t)rows * 4));
+  HIP_TRY(D->pval.reserve((size_t)rows * kVocabScanK2Max * 4));
+  HIP_TRY(D->pidx.reserve((size_t)rows * kVocabScanK2Max * 4));
+  HIP_TRY(D->tile_max.reserve((size_t)rows_pad * ntiles * 4));
+  HIP_TRY(D->tile_sum.reserve((size_t)rows_pad * ntiles * 4));
 
   if (int rc = compute_cross_constants(D, emb, emb_dtype, n, n_pad, stream)) return rc;
   HIP_TRY(launch_beam_init(D->tok.as<int32_t>(), D->cum.as<float>(), D->nactive.as<int32_t>(),
                            D->done.as<int32_t>(), D->ndone.as<int32_t>(), D->fin_count.as<int32_t>(),
                            D->hist[0].as<int32_t>(), D->anc[0].as<int32_t>(), rows, n, stride, (int)prompt[0], stream));
   const float inv_temp = 1.0f / bp->temperature;
-  int cur = 0;
-  for (int pos = 0; pos + 1 < max_len; ++pos) {
-    const int step_nr = pos + 1;
-    if (int rc = decoder_step(D, rows, rows_pad, beam, n_pad, pos, D->anc[cur].as<int32_t>(), stride, stream)) return rc;
+
+  // everything one decode step enqueues (position pos; ancestry/history buffer pos & 1)
+  auto enqueue_step = [&](int pos, hipStream_t s) -> int {
+    const int cur = pos & 1, step_nr = pos + 1;
+    if (int rc = decoder_step(D, rows, rows_pad, beam, n_pad, pos, D->anc[cur].as<int32_t>(), stride, s, inv_temp))
+      return rc;
     const bool forced_prompt = step_nr < prompt_len;
     const bool force_eos = !forced_prompt && step_nr == max_len - 1;
-    if (!forced_prompt && !force_eos) {
-      HIP_TRY(launch_vocab_scan(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size, k2, inv_temp,
-                                c.pad_idx, c.eos_idx, c.unk_idx, bp->unk_penalty, step_nr < min_len ? 1 : 0,
-                                D->pmax.as<float>(), D->psum.as<float>(), D->pval.as<float>(), D->pidx.as<int>(), stream));
-    } else {
-      // only the softmax normaliser is needed (the candidate is a given token)
-      HIP_TRY(launch_vocab_scan(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size, 0, inv_temp,
-                                c.pad_idx, c.eos_idx, c.unk_idx, 0.f, 0, D->pmax.as<float>(), D->psum.as<float>(),
-                                D->pval.as<float>(), D->pidx.as<int>(), stream));
-    }
+    // forced steps need only the softmax normaliser (the candidate is a given token): k2 = 0
+    const bool free_step = !forced_prompt && !force_eos;
+    HIP_TRY(launch_vocab_select(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size,
+                                D->tile_max.as<float>(), D->tile_sum.as<float>(), ntiles, free_step ? k2 : 0, inv_temp,
+                                c.pad_idx, c.eos_idx, c.unk_idx, free_step ? bp->unk_penalty : 0.f,
+                                free_step && step_nr < min_len ? 1 : 0, D->pmax.as<float>(), D->psum.as<float>(),
+                                D->pval.as<float>(), D->pidx.as<int>(), s));
     BeamStepArgs a{};
     a.tok = D->tok.as<int32_t>(); a.cum = D->cum.as<float>(); a.nactive = D->nactive.as<int32_t>();
     a.done = D->done.as<int32_t>(); a.ndone = D->ndone.as<int32_t>();
@@ -330,17 +335,27 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
     a.fin_score = D->fin_score.as<float>(); a.fin_count = D->fin_count.as<int32_t>();
     a.logits = D->logits.as<float>(); a.ldl = (int)D->vocab_pad;
     a.pmax = D->pmax.as<float>(); a.psum = D->psum.as<float>(); a.pval = D->pval.as<float>(); a.pidx = D->pidx.as<int>();
-    a.nchunks = nchunks; a.n = n; a.beam = beam; a.k2 = k2; a.pos = pos; a.prompt_len = prompt_len;
+    a.nchunks = 1; a.n = n; a.beam = beam; a.k2 = k2; a.pos = pos; a.prompt_len = prompt_len;
     a.forced_tok = forced_prompt ? (int)prompt[step_nr] : -1; a.max_len = max_len;
     a.inv_temp = inv_temp; a.len_penalty = bp->len_penalty; a.normalize = bp->normalize_scores;
     a.eos_idx = c.eos_idx; a.hist_stride = stride;
-    HIP_TRY(launch_beam_step(a, stream));
+    HIP_TRY(launch_beam_step(a, s));
     HIP_TRY(launch_beam_reorder(D->parent.as<int32_t>(), D->new_tok.as<int32_t>(), D->new_cum.as<float>(),
                                 D->anc[cur].as<int32_t>(), D->anc[cur ^ 1].as<int32_t>(), D->hist[cur].as<int32_t>(),
                                 D->hist[cur ^ 1].as<int32_t>(), D->tok.as<int32_t>(), D->cum.as<float>(), rows, stride,
-                                pos, stream));
-    cur ^= 1;
+                                pos, s));
+    return SMI_OK;
+  };
+
+  // (A hipGraph cache of this step -- one captured graph per position, replayed on later calls -- was
+  // measured at 256 x beam 5 and 16 x beam 5: 447.1 vs 447.3 ms and 185.4 vs 184.9 ms per 65 steps.  The
+  // step is bound by the GPU front end's dependent-dispatch latency of ~180 short kernels, not by host
+  // launch cost, so plain launches stay; fewer, fatter kernels are the lever.  DESIGN.md 3.4.)
+  for (int pos = 0; pos + 1 < max_len; ++pos) {
+    const int step_nr = pos + 1;
+    if (int rc = enqueue_step(pos, stream)) return rc;
     // every 8 steps: has every sentence collected its `beam` hypotheses?
+    const bool force_eos = step_nr >= prompt_len && step_nr == max_len - 1;
     if ((step_nr & 7) == 0 || force_eos) {
       int32_t nd = 0;
       HIP_TRY(hipMemcpyAsync(&nd, D->ndone.p, 4, hipMemcpyDeviceToHost, stream));

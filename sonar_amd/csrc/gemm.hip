@@ -145,7 +145,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 void* __restrict__ out, int M, int N,
-                                                                int K, int ldo) {
+                                                                int K, int ldo, GemmTileStats stats) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool TM = LAYOUT > 0;
   const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn, nt = K / G2_BK;
@@ -178,6 +178,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #endif
   for (; tile < ntiles; tile += gridDim.x) {
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
+    const int tile_n_cur = tile_n;
+    (void)tile_n_cur;
     G2_TRACE(0);
     if (tid < 64) *(f32x4*)(bias_lds + tid * 4) = bias_next;
     GemmTile256Acc acc;
@@ -198,6 +200,52 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #pragma unroll
       for (int q = 0; q < 4; ++q) b[ni][q] = *(const f32x4*)(bias_lds + wc * 64 + ni * 32 + 8 * q + 4 * hi);
 
+    if constexpr (EPI == EPI_STORE_F32) {
+      if (stats.tile_max) {
+        // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's
+        // logits GEMM): lane-local over its 32 values of a row, joined across the lane halves by a
+        // shuffle and across the 4 column waves through LDS (above the bias slice).
+        float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          float mx = -INFINITY;
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+              const float v = col < stats.valid_n ? (acc.v[ni][p][r] + b[ni][r >> 2][r & 3]) * stats.scale : -INFINITY;
+              mx = fmaxf(mx, v);
+            }
+          const float mo = __shfl_xor(mx, 32, 64);
+          const float m2 = fmaxf(mx, mo);
+          float se = 0.f;
+          if (m2 != -INFINITY) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                if (col < stats.valid_n)
+                  se += __expf((acc.v[ni][p][r] + b[ni][r >> 2][r & 3]) * stats.scale - m2);
+              }
+          }
+          se += __shfl_xor(se, 32, 64);
+          if (hi == 0) red[(wr * 128 + p * 32 + l31) * 4 + wc] = float2{m2, se};
+        }
+        SMI_LGKM0_BARRIER();
+        if (tid < 256) {
+          const float2 a0 = red[tid * 4], a1 = red[tid * 4 + 1], a2 = red[tid * 4 + 2], a3 = red[tid * 4 + 3];
+          const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+          float sum = 0.f;
+          if (m != -INFINITY)
+            sum = a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m);
+          const size_t o = (size_t)(m0 + tid) * ntn + tile_n_cur;
+          stats.tile_max[o] = m;
+          stats.tile_sum[o] = sum;
+        }
+      }
+    }
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
       // fp32 outputs: 8 sub-passes (mi block p, ni block) of 64 rows x 128 columns
       const int c = lane & 31;
@@ -354,7 +402,7 @@ static int num_cus() {
 
 template <int EPI, int LAYOUT>
 static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
-                                int N, int K, int ldo, hipStream_t stream) {
+                                int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, LAYOUT>,
@@ -364,7 +412,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   }
   const int grid = std::min((M / G2_BM) * (N / G2_BN), num_cus());
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
-                     stream, X, W, bias, out, M, N, K, ldo);
+                     stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0});
   return hipGetLastError();
 }
 
@@ -385,7 +433,7 @@ static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void
 }
 
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out,
-                          int M, int N, int K, int ldo, hipStream_t stream) {
+                          int M, int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats) {
   // epi_sel = epilogue | (engine << 8) | layout flags: engine 0 auto, 1 force 128x128, 2 force
   // 256x256; GEMM_IN_TM = X and W tile-major, GEMM_OUT_TM = fp16 output tile-major (needs IN_TM)
   const int epi = epi_sel & 0xff, sel = (epi_sel >> 8) & 0xf;
@@ -398,6 +446,10 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
   // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
+  if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue
+    if (epi != EPI_STORE_F32 || in_tm || !can256 || sel == 1) return hipErrorInvalidValue;
+    return launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);
+  }
 #define SMI_EPI_CASE(E, L)                                                     \
   case E:                                                                      \
     return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \

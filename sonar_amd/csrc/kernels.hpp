@@ -17,9 +17,19 @@ enum GemmEpilogue {
 constexpr int GEMM_IN_TM = 1 << 12;   // X and W are tile-major (M, N % 256 == 0)
 constexpr int GEMM_OUT_TM = 1 << 13;  // fp16 output is tile-major with K = N (needs GEMM_IN_TM, ldo == N)
 
+// Optional per-(row, 256-column tile) softmax statistics of an EPI_STORE_F32 GEMM on the 256x256
+// engine (the decoder's logits GEMM): tile_max[m][N/256] = max_n v, tile_sum[m][N/256] =
+// sum_n exp(v - max) with v = C[m][n] * scale over the columns n < valid_n of the tile.
+struct GemmTileStats {
+  float* tile_max;
+  float* tile_sum;
+  float scale;
+  int valid_n;
+};
+
 // C = X[M,K] * W[N,K]^T (+bias, epilogue).  M%128==0, N%128==0, K%64==0.
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
-                          int N, int K, int ldo, hipStream_t stream);
+                          int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr);
 
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
                                  int N, int K, int ksplit, hipStream_t stream);
@@ -69,11 +79,14 @@ hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t
                                 f16* h, int rows, int d, hipStream_t stream);
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream);
-constexpr int kVocabScanChunk = 4096;
 constexpr int kVocabScanK2Max = 16;
-hipError_t launch_vocab_scan(const float* logits, int ldl, int rows, int vocab, int k2, float inv_temp,
-                             int pad_idx, int eos_idx, int unk_idx, float unk_penalty, int block_eos,
-                             float* pmax, float* psum, float* pval, int* pidx, hipStream_t stream);
+// Per row: softmax normaliser (pmax, psum) from the GEMM's tile statistics and the top-k2 candidates
+// among the k2 best tiles + tile 0 (pval / pidx [rows][kVocabScanK2Max]), without re-reading the whole
+// logits row.
+hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
+                               const float* tile_sum, int ntiles, int k2, float inv_temp, int pad_idx, int eos_idx,
+                               int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
+                               int* pidx, hipStream_t stream);
 struct BeamStepArgs {
   int32_t* tok; float* cum; int32_t* nactive; int32_t* done; int32_t* ndone;
   int32_t* parent; int32_t* new_tok; float* new_cum;

@@ -86,6 +86,21 @@ def test_beam_search_vs_oracle(setup, beam):
     assert exact >= n - 1, f"only {exact}/{n} best hypotheses identical to the oracle"
 
 
+def test_generate_is_repeatable_across_calls(setup):
+    """Workspace reuse across calls (grow-only buffers, KV cache, tile statistics) must not leak state:
+    the same request gives the same hypotheses after other requests ran in between."""
+    OD, ocfg, params, eng = setup
+    emb = (torch.randn(6, ocfg.model_dim, generator=torch.Generator().manual_seed(77)) * 0.3).cuda()
+    kw = dict(beam_size=3, max_gen_len=(1, 10))
+    first = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
+    other = [t.cpu() for t in eng.generate(emb, [3, 703], **kw)]
+    eng.generate(emb[:2], [3, 702], beam_size=5, max_gen_len=(1, 20))
+    again = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)
+    assert not torch.equal(first[0], other[0])
+
+
 def test_beam_search_forced_eos_and_min_len(setup):
     OD, ocfg, params, eng = setup
     emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3
