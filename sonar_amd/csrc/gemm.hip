@@ -194,11 +194,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       bias_next = fetch_bias(tile_n * G2_BN);
     }
     G2_TRACE(3);
+    constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32;
+    // bias of the lane's columns (fp16-output epilogues; the fp32 ones add it at read-out time)
     f32x4 b[2][4];
+    if constexpr (!F32_OUT) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[ni][q] = *(const f32x4*)(bias_lds + wc * 64 + ni * 32 + 8 * q + 4 * hi);
+        for (int q = 0; q < 4; ++q) b[ni][q] = *(const f32x4*)(bias_lds + wc * 64 + ni * 32 + 8 * q + 4 * hi);
+    }
 
     if constexpr (EPI == EPI_STORE_F32) {
       if (stats.tile_max) {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-              const float v = col < stats.valid_n ? (acc.v[ni][p][r] + b[ni][r >> 2][r & 3]) * stats.scale : -INFINITY;
+              const float v = col < stats.valid_n ? (acc.v[ni][p][r] + bias_lds[col - n0]) * stats.scale : -INFINITY;
               mx = fmaxf(mx, v);
             }
           const float mo = __shfl_xor(mx, 32, 64);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
               for (int r = 0; r < 16; ++r) {
                 const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
                 if (col < stats.valid_n)
-                  se += __expf((acc.v[ni][p][r] + b[ni][r >> 2][r & 3]) * stats.scale - m2);
+                  se += __expf((acc.v[ni][p][r] + bias_lds[col - n0]) * stats.scale - m2);
               }
           }
           se += __shfl_xor(se, 32, 64);
@@ -247,29 +251,45 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       }
     }
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
-      // fp32 outputs: 8 sub-passes (mi block p, ni block) of 64 rows x 128 columns
+      // fp32 outputs: 8 sub-passes (mi block p, ni block) of 64 rows x 128 columns.  The residual
+      // values of sub-pass sp+1 are requested before the barrier of sub-pass sp (the barrier's memory
+      // clobber would otherwise pin every load behind it and expose one HBM latency per sub-pass).
       const int c = lane & 31;
+      // what the read-out adds to the staged accumulators: the old residual values (RESID) and the
+      // bias of the lane's 4 read-out columns (same columns for every row)
+      f32x4 bro[2];
 #pragma unroll
-      for (int sp = 0; sp < 8; ++sp) {
+      for (int ni = 0; ni < 2; ++ni) {
+        bro[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bro[ni] = *(const f32x4*)(bias + n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4);
+        if constexpr (EPI == EPI_RESID_HALF_F32) bro[ni] = bro[ni] * 0.5f;
+      }
+      auto load_old = [&](int sp, f32x4 (&o)[4]) {
         const int p = sp >> 1, ni = sp & 1;
-        char* st = g2_stage(smem, sp);
-        // residual values of this sub-pass: issued ahead of the LDS round trip
         const int gcol = n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4;
-        f32x4 old[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           if constexpr (EPI == EPI_STORE_F32)
-            old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            o[it] = bro[ni];
           else
-            old[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol);
+            o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol) + bro[ni];
         }
+      };
+      f32x4 old[2][4];
+      load_old(0, old[0]);
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        const int p = sp >> 1, ni = sp & 1;
+        char* st = g2_stage(smem, sp);
+        const int gcol = n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4;
+        if (sp + 1 < 8) load_old(sp + 1, old[(sp + 1) & 1]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
+          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e];
           if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
           *(f32x4*)(st + lr_w * 512 + (((wc * 8 + 2 * q + hi) ^ sw_w) << 4)) = v;
         }
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
-          *(f32x4*)((float*)out + (size_t)row * ldo + gcol) = old[it] + v;
+          *(f32x4*)((float*)out + (size_t)row * ldo + gcol) = old[sp & 1][it] + v;
         }
       }
     } else if constexpr (EPI == EPI_GLU_F16) {
