@@ -71,7 +71,8 @@ def decoder_leg(dev, n=256, steps=64):
     eng = TextDecoderEngine(get_text_decoder_config("basic"), text_decoder_state_dict(dev), device=dev)
     g = torch.Generator(device=dev).manual_seed(7)
     emb = torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=g), dim=-1).half() * 0.2
-    eng.generate(emb[:8], [3, 256047], beam_size=5, min_gen_len=4, max_gen_len=(0, 4))
+    # untimed warm-up with the same shapes: the first call allocates the KV cache / logits workspace
+    eng.generate(emb, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.generate(emb, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
