@@ -374,9 +374,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qu[ks], s, 0, 0, 0);
     }
     // ---- position term: G[rho][i] = rp[rel_lo + rho] . (q_i + v), rho = 0..63 ----
+    // rel_lo drops by 32 per key block, so rows 32..63 of this block are rows 0..31 of the previous
+    // one: the pad is two 32-row halves used alternately, and only the first key block computes both.
     const int rel_lo = i0 - j0 - 31;
+    const int kb = j0 / RA_KB;
+    float* Gnew = Gs + (kb & 1) * 32 * 32;        // rho 0..31 of this block
+    float* Gold = Gs + ((kb + 1) & 1) * 32 * 32;  // rho 32..63 = the previous block's rho 0..31
 #pragma unroll
     for (int gb = 0; gb < 2; ++gb) {
+      if (gb == 1 && kb > 0) break;
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
@@ -387,10 +393,11 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
         const half8 rf = *(const half8*)(rrow + (ks * 2 + hi) * 8);
         g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf, qv[ks], g, 0, 0, 0);
       }
+      float* Gw = gb ? Gold : Gnew;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int rho = gb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        Gs[rho * 32 + l31] = g[r];
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        Gw[rho * 32 + l31] = g[r];
       }
     }
     // (each wave reads back only what it wrote: no workgroup barrier needed, only LDS ordering)
@@ -399,7 +406,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float bd = Gs[(l31 - jj + 31) * 32 + l31];
+      const int rho = l31 - jj + 31;  // 0..62
+      const float bd = (rho < 32 ? Gnew : Gold)[(rho & 31) * 32 + l31];
       const float val = (j0 + jj) < len ? (s[r] + bd) * sl2e : -INFINITY;
       s[r] = val;
       mx = fmaxf(mx, val);
