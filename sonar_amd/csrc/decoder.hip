@@ -260,8 +260,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restrict__ logits, int ldl, int vocab,
                                                            const float* __restrict__ tile_max,
-                                                           const float* __restrict__ tile_sum, int ntiles, int k2,
-                                                           float inv_temp, int pad_idx, int eos_idx, int unk_idx,
+                                                           const float* __restrict__ tile_sum, int ntiles,
+                                                           int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx, int unk_idx,
                                                            float unk_penalty, int block_eos,
                                                            float* __restrict__ pmax, float* __restrict__ psum,
                                                            float* __restrict__ pval, int* __restrict__ pidx) {
@@ -269,16 +269,16 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
   __shared__ unsigned long long s_k[4];
   __shared__ int s_sel[VSEL_SLOTS];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float* tm = tile_max + (size_t)row * ntiles;
-  const float* ts = tile_sum + (size_t)row * ntiles;
+  const float* tm = tile_max + row;  // [tile][stat_rows]
+  const float* ts = tile_sum + row;
   constexpr int TPT = 8;  // tiles per thread: up to 2048 tiles = 524288 tokens
   float m[TPT], sm[TPT];
   float lm = -INFINITY;
 #pragma unroll
   for (int j = 0; j < TPT; ++j) {
     const int t = tid + 256 * j;
-    m[j] = t < ntiles ? tm[t] : -INFINITY;
-    sm[j] = t < ntiles ? ts[t] : 0.f;
+    m[j] = t < ntiles ? tm[(size_t)t * stat_rows] : -INFINITY;
+    sm[j] = t < ntiles ? ts[(size_t)t * stat_rows] : 0.f;
     lm = fmaxf(lm, m[j]);
   }
   // ---- 1. softmax normaliser of the row
@@ -379,13 +379,13 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
 }
 
 hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
-                               const float* tile_sum, int ntiles, int k2, float inv_temp, int pad_idx, int eos_idx,
+                               const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream) {
-  if (rows <= 0 || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
+  if (rows <= 0 || stat_rows < rows || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, vocab, tile_max, tile_sum,
-                     ntiles, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
+                     ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
   return hipGetLastError();
 }
 

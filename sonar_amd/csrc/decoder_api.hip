@@ -323,7 +323,7 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
     // forced steps need only the softmax normaliser (the candidate is a given token): k2 = 0
     const bool free_step = !forced_prompt && !force_eos;
     HIP_TRY(launch_vocab_select(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size,
-                                D->tile_max.as<float>(), D->tile_sum.as<float>(), ntiles, free_step ? k2 : 0, inv_temp,
+                                D->tile_max.as<float>(), D->tile_sum.as<float>(), ntiles, rows_pad, free_step ? k2 : 0, inv_temp,
                                 c.pad_idx, c.eos_idx, c.unk_idx, free_step ? bp->unk_penalty : 0.f,
                                 free_step && step_nr < min_len ? 1 : 0, D->pmax.as<float>(), D->psum.as<float>(),
                                 D->pval.as<float>(), D->pidx.as<int>(), s));

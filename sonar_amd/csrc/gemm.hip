@@ -206,46 +206,48 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 
     if constexpr (EPI == EPI_STORE_F32) {
       if (stats.tile_max) {
-        // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's
-        // logits GEMM): lane-local over its 32 values of a row, joined across the lane halves by a
-        // shuffle and across the 4 column waves through LDS (above the bias slice).
+        // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's logits
+        // GEMM, no bias): branch-free and lane-local over the lane's 32 values of a row in the log2
+        // domain (t = v * scale * log2 e, one v_exp_f32 per element), joined across the lane halves by
+        // a shuffle and across the 4 column waves through LDS (above the bias slice).
         float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
+        const float sc2 = stats.scale * 1.4426950408889634f;
+        const bool full = n0 + G2_BN <= stats.valid_n;  // every tile but the last one
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+          float t[2][16];
           float mx = -INFINITY;
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-              const float v = col < stats.valid_n ? (acc.v[ni][p][r] + bias_lds[col - n0]) * stats.scale : -INFINITY;
+              float v = acc.v[ni][p][r] * sc2;
+              if (!full) {
+                const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                v = col < stats.valid_n ? v : -INFINITY;
+              }
+              t[ni][r] = v;
               mx = fmaxf(mx, v);
             }
-          const float mo = __shfl_xor(mx, 32, 64);
-          const float m2 = fmaxf(mx, mo);
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float ms = mx == -INFINITY ? 0.f : mx;
           float se = 0.f;
-          if (m2 != -INFINITY) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-                if (col < stats.valid_n)
-                  se += __expf((acc.v[ni][p][r] + bias_lds[col - n0]) * stats.scale - m2);
-              }
-          }
+            for (int r = 0; r < 16; ++r) se += __builtin_amdgcn_exp2f(t[ni][r] - ms);
           se += __shfl_xor(se, 32, 64);
-          if (hi == 0) red[(wr * 128 + p * 32 + l31) * 4 + wc] = float2{m2, se};
+          if (hi == 0) red[(wr * 128 + p * 32 + l31) * 4 + wc] = float2{mx, se};
         }
         SMI_LGKM0_BARRIER();
         if (tid < 256) {
           const float2 a0 = red[tid * 4], a1 = red[tid * 4 + 1], a2 = red[tid * 4 + 2], a3 = red[tid * 4 + 3];
           const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
-          float sum = 0.f;
-          if (m != -INFINITY)
-            sum = a0.y * __expf(a0.x - m) + a1.y * __expf(a1.x - m) + a2.y * __expf(a2.x - m) + a3.y * __expf(a3.x - m);
-          const size_t o = (size_t)(m0 + tid) * ntn + tile_n_cur;
-          stats.tile_max[o] = m;
+          const float ms = m == -INFINITY ? 0.f : m;
+          const float sum = a0.y * __builtin_amdgcn_exp2f(a0.x - ms) + a1.y * __builtin_amdgcn_exp2f(a1.x - ms) +
+                            a2.y * __builtin_amdgcn_exp2f(a2.x - ms) + a3.y * __builtin_amdgcn_exp2f(a3.x - ms);
+          const size_t o = (size_t)tile_n_cur * M + m0 + tid;  // [tile][row]: 1 KiB coalesced per tile
+          stats.tile_max[o] = m * 0.6931471805599453f;         // back to natural units
           stats.tile_sum[o] = sum;
         }
       }
@@ -466,8 +468,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
   // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
-  if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue
-    if (epi != EPI_STORE_F32 || in_tm || !can256 || sel == 1) return hipErrorInvalidValue;
+  if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
+    if (epi != EPI_STORE_F32 || in_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
     return launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);
   }
 #define SMI_EPI_CASE(E, L)                                                     \

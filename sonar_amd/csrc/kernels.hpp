@@ -18,8 +18,9 @@ constexpr int GEMM_IN_TM = 1 << 12;   // X and W are tile-major (M, N % 256 == 0
 constexpr int GEMM_OUT_TM = 1 << 13;  // fp16 output is tile-major with K = N (needs GEMM_IN_TM, ldo == N)
 
 // Optional per-(row, 256-column tile) softmax statistics of an EPI_STORE_F32 GEMM on the 256x256
-// engine (the decoder's logits GEMM): tile_max[m][N/256] = max_n v, tile_sum[m][N/256] =
-// sum_n exp(v - max) with v = C[m][n] * scale over the columns n < valid_n of the tile.
+// engine (the decoder's logits GEMM): tile_max[N/256][M] = max_n v, tile_sum[N/256][M] =
+// sum_n exp(v - max) with v = C[m][n] * scale over the columns n < valid_n of the tile
+// (tile-major so that a tile's 256 rows are one coalesced 1 KiB store).
 struct GemmTileStats {
   float* tile_max;
   float* tile_sum;
@@ -84,7 +85,7 @@ constexpr int kVocabScanK2Max = 16;
 // among the k2 best tiles + tile 0 (pval / pidx [rows][kVocabScanK2Max]), without re-reading the whole
 // logits row.
 hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
-                               const float* tile_sum, int ntiles, int k2, float inv_temp, int pad_idx, int eos_idx,
+                               const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream);
 struct BeamStepArgs {
