@@ -172,16 +172,6 @@ struct ProfScope {
   }
 };
 
-// w (row-major [rows][K] fp16) -> tile-major, in a fresh buffer
-int to_tile_major(DevBuf& w, int rows, int K) {
-  DevBuf t;
-  HIP_TRY(t.alloc(w.bytes));
-  HIP_TRY(launch_pack_tile_major(w.as<f16>(), t.as<f16>(), rows, K, 0, nullptr));
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  w = std::move(t);
-  return SMI_OK;
-}
-
 int check_cfg(const smi_text_encoder_config& c) {
   if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
     return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must equal num_heads %d * 64", c.model_dim,
@@ -459,10 +449,10 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
   if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 7 || sel > 2 || m <= 0 || m % 128 ||
       n <= 0 || n % 128 || k <= 0 || k % 64 || ldo < (e == 6 ? n / 2 : n) || (sel == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
-  if (in_tm && (m % 256 || n % 256 || (e != 0 && e != 2 && e != 3 && !(out_tm && e == 1))))
+  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5) : (e != 0 && e != 2 && e != 3 && e != 4))))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major gemm: m=%d n=%d epi=%d", m, n, epi);
-  if (out_tm && (!in_tm || ldo != n || e > 1))
-    return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs, ldo == n, epilogue 0/1");
+  if (out_tm && (!in_tm || ldo != n))
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));
   return SMI_OK;

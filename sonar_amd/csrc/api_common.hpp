@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <utility>
 
 #include "../../include/sonar_mi355.h"
 #include "kernels.hpp"
@@ -84,5 +85,15 @@ struct DevBuf {
 // `pad_numel` (>= numel) zero-pads the destination.
 int upload(const smi_tensor& t, int64_t expect_numel, bool want_f16, DevBuf& dst, const char* name,
            int64_t pad_numel = 0);
+
+// w (row-major [rows][K] fp16 on the device) -> tile-major (common.hpp), in a fresh buffer
+inline int to_tile_major(DevBuf& w, int rows, int K) {
+  DevBuf t;
+  HIP_TRY(t.alloc(w.bytes));
+  HIP_TRY(launch_pack_tile_major(w.as<f16>(), t.as<f16>(), rows, K, 0, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  w = std::move(t);
+  return SMI_OK;
+}
 
 }  // namespace smi_host

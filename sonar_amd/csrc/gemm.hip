@@ -347,12 +347,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
-            half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
-            if constexpr (EPI == EPI_RELU_F16) {  // relu after the rounding: same values, packed max
-              const half2v z = {(f16)0.f, (f16)0.f};
-              lo = __builtin_elementwise_max(lo, z);
-              hh = __builtin_elementwise_max(hh, z);
-            }
+            v = epi_act<EPI>(v);
+            const half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
             h[q][0] = __builtin_bit_cast(uint32_t, lo);
             h[q][1] = __builtin_bit_cast(uint32_t, hh);
           }
@@ -480,6 +476,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     switch (epi) {
       SMI_EPI_CASE(EPI_BIAS_F16, 2)
       SMI_EPI_CASE(EPI_RELU_F16, 2)
+      SMI_EPI_CASE(EPI_SILU_F16, 2)
     }
     return hipErrorInvalidValue;
   }
@@ -488,6 +485,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       SMI_EPI_CASE(EPI_BIAS_F16, 1)
       SMI_EPI_CASE(EPI_RESID_F32, 1)
       SMI_EPI_CASE(EPI_STORE_F32, 1)
+      SMI_EPI_CASE(EPI_RESID_HALF_F32, 1)
     }
     return hipErrorInvalidValue;
   }

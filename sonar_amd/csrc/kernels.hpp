@@ -128,7 +128,7 @@ hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t*
                            const float* b, float eps, f16* out, int ldo, hipStream_t stream);
 // x = LN1(x) in place; h = f16(w2 ? LN2(x) : x) (h may be null)
 hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream);
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm = 0);
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
                                    int heads, hipStream_t stream);

@@ -202,7 +202,7 @@ hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t*
 
 // =============================================================== LayerNorm variants (fp32 stream)
 // x = LN1(x) in place (fp32); h = f16(w2 ? LN2(x) : x).  One wave per row.
-template <int NV>
+template <int NV, bool TM>
 __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const float* __restrict__ w1,
                                                   const float* __restrict__ b1,
                                                   const float* __restrict__ w2,
@@ -265,18 +265,25 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const f
     half4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (f16)v[k][i];
-    *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+    if constexpr (TM)
+      *(half4*)(h + tm_offset(r, k * 256 + lane * 4, D)) = o;  // tile-major GEMM operand (common.hpp)
+    else
+      *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
   }
 }
 
 hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream) {
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
   const int blocks = (rows + 3) / 4;
-#define SMI_LN2_CASE(NV)                                                                              \
-  case NV * 256:                                                                                      \
-    hipLaunchKernelGGL(ln2_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
-                       rows);                                                                         \
+#define SMI_LN2_CASE(NV)                                                                                       \
+  case NV * 256:                                                                                               \
+    if (out_tm)                                                                                                \
+      hipLaunchKernelGGL((ln2_kernel<NV, true>), dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
+                         rows);                                                                                \
+    else                                                                                                       \
+      hipLaunchKernelGGL((ln2_kernel<NV, false>), dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
+                         rows);                                                                                \
     break;
   switch (d) {
     SMI_LN2_CASE(1)

@@ -116,6 +116,7 @@ int ensure_fbank_consts() {
 struct smi_speech_encoder {
   smi_speech_encoder_config cfg;
   int kpad = 0;  // stacked feature dim padded to a multiple of 64
+  int ffn_tile_major = 0;  // macaron FFN operands (LN output, hidden, weights) in the tile-major layout
   DevBuf pe_ln_w, pe_ln_b, proj_w, proj_b, ln_w, ln_b, pool_q0, pool_out_w, rel_table;
   std::vector<ConfLayer> layers;
   std::vector<PoolLayer> pooler;
@@ -229,6 +230,7 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     if (he != hipSuccess) rc = fail(he == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "rel table: %s", hipGetErrorString(he));
   }
   E->layers.resize(c.num_layers);
+  E->ffn_tile_major = f % 256 == 0;  // d % 256 == 0 is checked above
   for (int l = 0; l < c.num_layers && rc == SMI_OK; ++l) {
     const smi_conformer_layer& s = w->layers[l];
     ConfLayer& L = E->layers[l];
@@ -257,6 +259,12 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     up(s.ffn2_out_b, d, false, L.ffn2_b2, "ffn2.output_proj.bias");
     up(s.layer_norm_w, d, false, L.ln_w, "layer_norm.weight");
     up(s.layer_norm_b, d, false, L.ln_b, "layer_norm.bias");
+    if (rc == SMI_OK && E->ffn_tile_major) {
+      rc = to_tile_major(L.ffn1_w1, (int)f, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.ffn1_w2, (int)d, (int)f);
+      if (rc == SMI_OK) rc = to_tile_major(L.ffn2_w1, (int)f, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.ffn2_w2, (int)d, (int)f);
+    }
     if (rc == SMI_OK) {
       const smi_tensor ws[3] = {s.q_w, s.k_w, s.v_w}, bs[3] = {s.q_b, s.k_b, s.v_b};
       rc = pack_fused(ws, bs, 3, d, d, L.w_qkv, L.b_qkv, "self_attn.qkv");
@@ -403,12 +411,18 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   const int64_t P = c.max_frames + 192;
   const f16* pe_slice = E->rel_table.as<f16>() + (size_t)((P - 1) - (tm - 1)) * d;
 
-  HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream));
+  // The two macaron FFNs (4 of the block's 8 GEMMs, 2/3 of its FLOPs) run on tile-major operands
+  // (common.hpp): their LayerNorm input, the SiLU hidden activation and the weights.
+  const int tmf = E->ffn_tile_major;
+  const int ffn_in = tmf ? GEMM_IN_TM : 0, ffn_io = tmf ? GEMM_IN_TM | GEMM_OUT_TM : 0;
+  HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream,
+                           tmf));
   for (int l = 0; l < c.num_layers; ++l) {
     ConfLayer& L = E->layers[l];
     // x += 0.5 * FFN1(LN(x))
-    HIP_TRY(launch_gemm_tn(EPI_SILU_F16, h, L.ffn1_w1.as<f16>(), L.ffn1_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d, stream));
+    HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn1_w1.as<f16>(), L.ffn1_b1.as<float>(), big, R, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32 | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
+                           stream));
     // x += RelPosMHA(LN(x))
     HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
@@ -423,14 +437,16 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
                                   E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream));
     HIP_TRY(launch_gemm_tn(EPI_RESID_F32, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
     // x += 0.5 * FFN2(LN(x))
-    HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream));
-    HIP_TRY(launch_gemm_tn(EPI_SILU_F16, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d, stream));
+    HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf));
+    HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32 | ffn_in, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d,
+                           stream));
     // x = LN_block(x); h = next block's ffn1 LN, or the model-level LayerNorm after the last block
     const bool last = l + 1 == c.num_layers;
     const float* w2 = last ? E->ln_w.as<float>() : E->layers[l + 1].ffn1_ln_w.as<float>();
     const float* b2 = last ? E->ln_b.as<float>() : E->layers[l + 1].ffn1_ln_b.as<float>();
-    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream));
+    // (the last block's h is the encoder output the pooler reads row-major)
+    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream, last ? 0 : tmf));
   }
   // ---- attention pooler: h now holds the encoder output (fp16) ----
   float* xq = E->xq.as<float>();
