@@ -150,9 +150,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   constexpr bool TM = LAYOUT > 0;
   const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn, nt = K / G2_BK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
-  const int lr_w = wr * 32 + l31;             // staging row this lane writes
-  const int sw_w = g2_stage_swz(lr_w);
+  // accumulator layout (gemm_tile256.hpp): lane -> row l15 of a 16-row block, 4 consecutive columns
+  // at 4*kg of a 16-column block
+  const int l15 = lane & 15, kg = lane >> 4, wr = wave >> 2, wc = wave & 3;
+  const int hi = lane >> 5;  // read-out row parity of the staged epilogues
 
   // The bias slice of a tile (256 floats) waits in the second staging buffer: it is fetched with
   // the pipeline fill of its tile (no exposed latency, no registers held across the K loop) and
@@ -196,48 +197,48 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     G2_TRACE(3);
     constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32;
     // bias of the lane's columns (fp16-output epilogues; the fp32 ones add it at read-out time)
-    f32x4 b[2][4];
+    f32x4 b[4];
     if constexpr (!F32_OUT) {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[ni][q] = *(const f32x4*)(bias_lds + wc * 64 + ni * 32 + 8 * q + 4 * hi);
+      for (int ni = 0; ni < 4; ++ni) b[ni] = *(const f32x4*)(bias_lds + wc * 64 + ni * 16 + 4 * kg);
     }
+    // staged epilogues: pass p holds tile rows wr*128 + p*32 + (0..31) of both row groups =
+    // accumulator blocks mi = 2p, 2p+1; a lane writes staging row lr_w(mi)
+    auto lr_w = [&](int mi) { return wr * 32 + (mi & 1) * 16 + l15; };
 
     if constexpr (EPI == EPI_STORE_F32) {
       if (stats.tile_max) {
         // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's logits
-        // GEMM, no bias): branch-free and lane-local over the lane's 32 values of a row in the log2
-        // domain (t = v * scale * log2 e, one v_exp_f32 per element), joined across the lane halves by
-        // a shuffle and across the 4 column waves through LDS (above the bias slice).
+        // GEMM, no bias): branch-free and lane-local over the lane's 16 values of a row in the log2
+        // domain (t = v * scale * log2 e, one v_exp_f32 per element), joined across the 4 lane groups
+        // by two shuffles and across the 4 column waves through LDS (above the bias slice).
         float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
         const float sc2 = stats.scale * 1.4426950408889634f;
         const bool full = n0 + G2_BN <= stats.valid_n;  // every tile but the last one
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          float t[2][16];
+        for (int mi = 0; mi < 8; ++mi) {
+          float t[4][4];
           float mx = -INFINITY;
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              float v = acc.v[ni][p][r] * sc2;
-              if (!full) {
-                const int col = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-                v = col < stats.valid_n ? v : -INFINITY;
-              }
+            for (int r = 0; r < 4; ++r) {
+              float v = acc.v[ni][mi][r] * sc2;
+              if (!full) v = (n0 + wc * 64 + ni * 16 + 4 * kg + r) < stats.valid_n ? v : -INFINITY;
               t[ni][r] = v;
               mx = fmaxf(mx, v);
             }
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
           const float ms = mx == -INFINITY ? 0.f : mx;
           float se = 0.f;
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) se += __builtin_amdgcn_exp2f(t[ni][r] - ms);
+            for (int r = 0; r < 4; ++r) se += __builtin_amdgcn_exp2f(t[ni][r] - ms);
+          se += __shfl_xor(se, 16, 64);
           se += __shfl_xor(se, 32, 64);
-          if (hi == 0) red[(wr * 128 + p * 32 + l31) * 4 + wc] = float2{mx, se};
+          if (kg == 0) red[(wr * 128 + mi * 16 + l15) * 4 + wc] = float2{mx, se};
         }
         SMI_LGKM0_BARRIER();
         if (tid < 256) {
@@ -252,49 +253,53 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
       }
     }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32) {
-      // fp32 outputs: 8 sub-passes (mi block p, ni block) of 64 rows x 128 columns.  The residual
-      // values of sub-pass sp+1 are requested before the barrier of sub-pass sp (the barrier's memory
-      // clobber would otherwise pin every load behind it and expose one HBM latency per sub-pass).
+    if constexpr (F32_OUT) {
+      // fp32 outputs: 8 sub-passes (row pass p, column half nh) of 64 rows x 128 columns (the waves'
+      // blocks ni = 2nh, 2nh+1).  The residual values of sub-pass sp+1 are requested before the barrier
+      // of sub-pass sp (the barrier's memory clobber would otherwise pin every load behind it and
+      // expose one HBM latency per sub-pass).
       const int c = lane & 31;
       // what the read-out adds to the staged accumulators: the old residual values (RESID) and the
       // bias of the lane's 4 read-out columns (same columns for every row)
       f32x4 bro[2];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        bro[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bro[ni] = *(const f32x4*)(bias + n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4);
-        if constexpr (EPI == EPI_RESID_HALF_F32) bro[ni] = bro[ni] * 0.5f;
+      for (int nh = 0; nh < 2; ++nh) {
+        bro[nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (bias) bro[nh] = *(const f32x4*)(bias + n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4);
+        if constexpr (EPI == EPI_RESID_HALF_F32) bro[nh] = bro[nh] * 0.5f;
       }
       auto load_old = [&](int sp, f32x4 (&o)[4]) {
-        const int p = sp >> 1, ni = sp & 1;
-        const int gcol = n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4;
+        const int p = sp >> 1, nh = sp & 1;
+        const int gcol = n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           if constexpr (EPI == EPI_STORE_F32)
-            o[it] = bro[ni];
+            o[it] = bro[nh];
           else
-            o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol) + bro[ni];
+            o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol) + bro[nh];
         }
       };
       f32x4 old[2][4];
       load_old(0, old[0]);
 #pragma unroll
       for (int sp = 0; sp < 8; ++sp) {
-        const int p = sp >> 1, ni = sp & 1;
+        const int p = sp >> 1, nh = sp & 1;
         char* st = g2_stage(smem, sp);
-        const int gcol = n0 + (c >> 3) * 64 + ni * 32 + (c & 7) * 4;
+        const int gcol = n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4;
         if (sp + 1 < 8) load_old(sp + 1, old[(sp + 1) & 1]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 v;
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e];
-          if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
-          *(f32x4*)(st + lr_w * 512 + (((wc * 8 + 2 * q + hi) ^ sw_w) << 4)) = v;
-        }
+          for (int nl = 0; nl < 2; ++nl) {
+            const int mi = 2 * p + mh, ni = 2 * nh + nl;
+            f32x4 v = acc.v[ni][mi];
+            if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
+            const int lr = lr_w(mi);
+            // 16-B chunk (4 floats) of the 128 staged columns: wc*8 + nl*4 + kg
+            *(f32x4*)(st + lr * 512 + (((wc * 8 + nl * 4 + kg) ^ g2_stage_swz(lr)) << 4)) = v;
+          }
         SMI_LGKM0_BARRIER();
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -305,18 +310,24 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
       }
     } else if constexpr (EPI == EPI_GLU_F16) {
-      // 128 output channels per tile: channel wc*32 + 8q + 4hi + e from the wave's (a, gate) blocks
+      // 128 output channels per tile; a wave's 64 columns are [32 values | 32 gates] (W rows interleaved
+      // in 32-channel groups at pack time): channel wc*32 + nl*16 + 4kg + r from blocks ni = nl, nl + 2
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         char* st = g2_stage(smem, p);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          half4 h;
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            h[e] = (f16)((acc.v[0][p][q * 4 + e] + b[0][q][e]) * sigmoid_f(acc.v[1][p][q * 4 + e] + b[1][q][e]));
-          *(half4*)(st + lr_w * 512 + (((wc * 4 + q) ^ sw_w) << 4) + hi * 8) = h;
-        }
+          for (int nl = 0; nl < 2; ++nl) {
+            const int mi = 2 * p + mh;
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              h[e] = (f16)((acc.v[nl][mi][e] + b[nl][e]) * sigmoid_f(acc.v[nl + 2][mi][e] + b[nl + 2][e]));
+            const int lr = lr_w(mi);
+            // 16-B chunk (8 channels) of the 128 staged channels: wc*4 + nl*2 + (kg>>1), half kg&1
+            *(half4*)(st + lr * 512 + (((wc * 4 + nl * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
+          }
         SMI_LGKM0_BARRIER();
         const int c = lane & 15;  // 16 lanes x 16 B = one 256-B output row
 #pragma unroll
@@ -328,40 +339,35 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
       }
     } else if constexpr (LAYOUT == 2) {
-      // fp16 tile-major output straight from the accumulators, no LDS pass, no barriers: a lane
-      // holds 4 consecutive columns (8 B) of row l31 per (ni, q); v_permlane32_swap joins the two
-      // lane halves' 8-B pieces into whole 16-B chunks (lower lanes: chunk 2*pair, upper lanes:
-      // chunk 2*pair+1 of the 32-column k-block wc*2+ni), so a wave instruction stores 64 x 16 B
-      // into one 2 KiB run (32 rows x 64 B of one block) and the two pairs fill it completely.
-      const int sw = (l31 >> 2) & 3;
+      // fp16 tile-major output straight from the accumulators, no LDS pass, no barriers.  A lane holds
+      // 4 consecutive columns (8 B) of row l15 per 16-column block; a 32-column k-block is the block
+      // pair A = 2j, B = 2j+1.  v_permlane16_swap moves lane group 1's piece of A against group 0's
+      // piece of B (and 3 against 2), after which every lane holds a whole 16-B chunk: group kg owns
+      // chunk (kg&1)*2 + (kg>>1) of the k-block.  A wave instruction then stores 16 rows x 64 B = one
+      // dense, contiguous 1 KiB run of a tile-major block.
+      const int cidx = (kg & 1) * 2 + (kg >> 1);
+      const int sw = (l15 >> 2) & 3;
       f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
-                   (wr * 128 + l31) * 32;
-      const int slot0 = ((hi ^ sw) << 3), slot1 = (((2 | hi) ^ sw) << 3);
+                   (wr * 128 + l15) * 32 + ((cidx ^ sw) << 3);
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          uint32_t h[4][2];
+        for (int j = 0; j < 2; ++j) {
+          uint32_t h[2][2];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
+          for (int nl = 0; nl < 2; ++nl) {
+            f32x4 v = acc.v[2 * j + nl][mi] + b[2 * j + nl];
             v = epi_act<EPI>(v);
             const half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
-            h[q][0] = __builtin_bit_cast(uint32_t, lo);
-            h[q][1] = __builtin_bit_cast(uint32_t, hh);
+            h[nl][0] = __builtin_bit_cast(uint32_t, lo);
+            h[nl][1] = __builtin_bit_cast(uint32_t, hh);
           }
-          f16* dst = lane0 + (size_t)ni * TM_BLOCK + p * (32 * 32);
-#pragma unroll
-          for (int pair = 0; pair < 2; ++pair) {
-            // upper half of h[2*pair] <-> lower half of h[2*pair+1]
-            const auto s0 = __builtin_amdgcn_permlane32_swap(h[2 * pair][0], h[2 * pair + 1][0], false, false);
-            const auto s1 = __builtin_amdgcn_permlane32_swap(h[2 * pair][1], h[2 * pair + 1][1], false, false);
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-            *(u32x4*)(dst + (pair ? slot1 : slot0)) = chunk;
-          }
+          // rows 16..31 / 48..63 of h[0] <-> rows 0..15 / 32..47 of h[1]
+          const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
+          *(u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = chunk;
         }
       }
     } else {
@@ -369,17 +375,18 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       for (int p = 0; p < 4; ++p) {
         char* st = g2_stage(smem, p);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][p][q * 4 + e] + b[ni][q][e];
+          for (int ni = 0; ni < 4; ++ni) {
+            const int mi = 2 * p + mh;
+            f32x4 v = acc.v[ni][mi] + b[ni];
             v = epi_act<EPI>(v);
             half4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
-            *(half4*)(st + lr_w * 512 + (((wc * 8 + ni * 4 + q) ^ sw_w) << 4) + hi * 8) = h;
+            const int lr = lr_w(mi);
+            // 16-B chunk (8 columns) of the 256 staged columns: wc*8 + ni*2 + (kg>>1), half kg&1
+            *(half4*)(st + lr * 512 + (((wc * 8 + ni * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
           }
         SMI_LGKM0_BARRIER();
         const int c = lane & 31;

@@ -1,12 +1,18 @@
 // 256x256 fp16 MFMA tile engine, 8 waves, 4-slot K=32 LDS ring, ping-pong wave
 // groups.  C[m][n] = sum_k X[m][k] * W[n][k], both operands K-major.
 //
+// MFMA shape: v_mfma_f32_16x16x32_f16 (one instruction spans the whole K=32 slice of a 16x16 block).
+// The chip is power-limited on real data, and tools/micro/mfma_power.hip (no memory traffic, 8 waves/CU,
+// 128 accumulator registers) measures 2038 TFLOP/s for 16x16x32 against 1732 for 32x32x16 on uniform
+// random operands (both 2478 on zeros): same peak rate, ~18 % less energy per flop.  Same 12 ds_read_b128
+// per wave and slice, same 128 accumulator registers; a lane's accumulators are still 4-wide runs along n.
+//
 // Why this shape on MI355X (measurements in DESIGN.md 3.1 / profiles/):
 //  * a 128x128 tile pulls 512 KiB through L2 per 33.5 MFLOP; 256x256 halves it;
 //  * one workgroup of 8 waves owns the CU (128 KiB LDS): 2 waves per SIMD.  The
 //    waves of a SIMD are put in different GROUPS (waves 0-3 / 4-7) that run the
 //    same loop one barrier interval apart: while one wave of the SIMD issues its
-//    12 ds_read_b128 + 4 global_load_lds for a K slice, its partner runs the 16
+//    12 ds_read_b128 + 4 global_load_lds for a K slice, its partner runs the 32
 //    MFMAs of the previous slice;
 //  * the LDS ring holds 4 K=32 slices; DMA for slice t+3 is issued while slice t
 //    is consumed and is waited for with a COUNTED s_waitcnt vmcnt(8) (never 0 in
@@ -26,7 +32,7 @@
 //
 // LDS slice layout: X rows [256][64 B] then W rows [256][64 B]; 16-B chunk c of
 // row r sits at slot c ^ ((r>>2)&3) -> conflict-free ds_read_b128 for the
-// 32x32x16 operand fragments.
+// 16x16x32 operand fragments (lane -> row l&15, chunk l>>4).
 //
 // Hazard bookkeeping (intervals are the spans between consecutive barriers;
 // group 0 reads slice t in interval 2t and multiplies it in 2t+1, group 1 one
@@ -51,7 +57,7 @@ constexpr int G2_LDS_BYTES = 4 * G2_SLOT_BYTES;             // 128 KiB
 constexpr int G2_KERNEL_LDS_BYTES = G2_LDS_BYTES + 32 * 1024;  // ring + second epilogue staging buffer = 160 KiB
 
 struct GemmTile256Acc {
-  f32x16 v[2][4];  // [ni][mi]
+  f32x4 v[4][8];  // [ni][mi]: 16x16 blocks of the wave's 64(n) x 128(m) tile
 };
 
 #define SMI_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -125,11 +131,9 @@ __device__ __forceinline__ void g2_prefetch(const G2Src& s, int nt, char* smem) 
 // counted waits.  Separate from the loop so the caller can pin its own early loads (bias) here.
 __device__ __forceinline__ void g2_begin(GemmTile256Acc& acc) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+    for (int j = 0; j < 8; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   SMI_WAIT_VMCNT(0);
   SMI_BARRIER();  // slices 0..2 complete for everyone
 }
@@ -141,24 +145,22 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& sr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;  // wr doubles as the ping-pong group
 
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
-  const int xoff = (wr * 128 + l31) * 64 + t_sw;
-  const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
+  // fragment of a 16-row block: lane -> row l&15, 16-B chunk l>>4 (the 8 k values of its MFMA slot)
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int t_sw = (kg ^ ((l15 >> 2) & 3)) << 4;
+  const int xoff = (wr * 128 + l15) * 64 + t_sw;
+  const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l15) * 64 + t_sw;
 
   if (wr == 1) SMI_BARRIER();  // group 1 runs one interval behind
 
   for (int t = 0; t < nt; ++t) {
     // ---- read segment: fragments of slice t -> VGPRs, DMA for slice t+3 ----
     const char* slot = smem + (t & 3) * G2_SLOT_BYTES;
-    half8 fx[2][4], fw[2][2];
+    half8 fx[8], fw[4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const half8*)(slot + woff + ni * 1024);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) fw[ks][ni] = *(const half8*)(slot + ((woff + ni * 2048) ^ (ks << 5)));
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
-    }
+    for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
     if (t + 3 < nt) {
       g2_issue(src, t + 3, smem, wave);
       SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
@@ -169,15 +171,13 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& sr
     }
     SMI_LGKM0_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
-    // ---- multiply segment ----
+    // ---- multiply segment: W is the MFMA A operand, X the B operand ----
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
+      for (int mi = 0; mi < 8; ++mi)
+        acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], acc.v[ni][mi], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     SMI_BARRIER();
@@ -197,15 +197,15 @@ __device__ __forceinline__ int g2_stage_swz(int lr) { return ((lr & 3) << 2) | (
 __device__ __forceinline__ char* g2_stage(char* smem, int buf) { return smem + G2_STAGE0 + (buf & 1) * G2_STAGE_BYTES; }
 
 // acc.v[ni][mi][r] is C[m][n] with
-//   m = m0 + wr*128 + mi*32 + (lane&31)
-//   n = n0 + wc*64 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+//   m = m0 + wr*128 + mi*16 + (lane&15)
+//   n = n0 + wc*64 + ni*16 + 4*(lane>>4) + r
 __device__ __forceinline__ int g2_row(int m0, int mi) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  return m0 + (wave >> 2) * 128 + mi * 32 + (lane & 31);
+  return m0 + (wave >> 2) * 128 + mi * 16 + (lane & 15);
 }
-__device__ __forceinline__ int g2_col(int n0, int ni, int quad) {
+__device__ __forceinline__ int g2_col(int n0, int ni) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  return n0 + (wave & 3) * 64 + ni * 32 + 8 * quad + 4 * (lane >> 5);
+  return n0 + (wave & 3) * 64 + ni * 16 + 4 * (lane >> 4);
 }
 
 // XCD-aware grouped raster over 256x256 tiles: the ~32 workgroups resident on

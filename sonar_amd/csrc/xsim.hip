@@ -184,7 +184,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     const int xoff = (wr * 128 + l31) * 64 + t_sw;
     const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
 
-    GemmTile256Acc acc;
+    struct { f32x16 v[2][4]; } acc;  // 32x32x16 blocks [ni][mi] (this kernel's own MFMA shape)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
