@@ -143,16 +143,18 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
   const int m0 = tile_m * G2_BM;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
+  // 16x16x32 MFMA blocks (gemm_tile256.hpp): lane -> row l15 of a 16-row block, 4 consecutive
+  // columns at 4*kg of a 16-column block
+  const int l15 = lane & 15, kg = lane >> 4, wr = wave >> 2, wc = wave & 3;
 
   const int t_begin = chunk * tiles_per_chunk;
   const int ntiles = min(nty, t_begin + tiles_per_chunk) - t_begin;
   const int nt = d / G2_BK;
   const int S = max(ntiles, 0) * nt;
 
-  TopK<K> best[4];
+  TopK<K> best[8];  // one running list per accumulator row block
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) best[mi].init();
+  for (int mi = 0; mi < 8; ++mi) best[mi].init();
 
   if (S > 0) {
     // DMA stream state: slice s = (tile s / nt, k = s % nt)
@@ -180,17 +182,15 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
         yg[1] += (size_t)G2_BN * d;
       }
     };
-    const int t_sw = (hi ^ ((l31 >> 2) & 3)) << 4;
-    const int xoff = (wr * 128 + l31) * 64 + t_sw;
-    const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l31) * 64 + t_sw;
+    const int t_sw = (kg ^ ((l15 >> 2) & 3)) << 4;
+    const int xoff = (wr * 128 + l15) * 64 + t_sw;
+    const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l15) * 64 + t_sw;
 
-    struct { f32x16 v[2][4]; } acc;  // 32x32x16 blocks [ni][mi] (this kernel's own MFMA shape)
+    GemmTile256Acc acc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+      for (int j = 0; j < 8; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     issue();
     if (S > 1) issue();
@@ -204,14 +204,11 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     int k = 0, n0 = t_begin * G2_BN;
     for (int s = 0; s < S; ++s) {
       const char* slot = smem + (s & 3) * G2_SLOT_BYTES;
-      half8 fx[2][4], fw[2][2];
+      half8 fx[8], fw[4];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const half8*)(slot + woff + ni * 1024);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) fw[ks][ni] = *(const half8*)(slot + ((woff + ni * 2048) ^ (ks << 5)));
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fx[ks][mi] = *(const half8*)(slot + ((xoff + mi * 2048) ^ (ks << 5)));
-      }
+      for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
       if (s + 3 < S) {
         issue();
         SMI_WAIT_VMCNT(8);
@@ -224,34 +221,33 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi)
-            acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][ni], fx[ks][mi], acc.v[ni][mi], 0, 0, 0);
+        for (int mi = 0; mi < 8; ++mi)
+          acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], acc.v[ni][mi], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       SMI_BARRIER();
       if (++k == nt) {  // y tile finished: fold the 128x64 scores of this wave into the top-k
         k = 0;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < 8; ++mi) {
+          float vmax = -INFINITY;
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            float vmax = acc.v[ni][mi][0];
+          for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 1; r < 16; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
-            if (vmax >= best[mi].s[K - 1]) {
+            for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
+          if (vmax >= best[mi].s[K - 1]) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wc * 64 + ni * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wc * 64 + ni * 16 + 4 * kg + r;
                 if (n < ny) best[mi].push(acc.v[ni][mi][r], n);
               }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc.v[ni][mi][r] = 0.f;
           }
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc.v[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         n0 += G2_BN;
       }
@@ -259,18 +255,35 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     if (wr == 0) SMI_BARRIER();
   }
 
-  // merge the 8 lists of every x row (2 lane halves x 4 n-waves) through LDS
+  // a row's candidates sit in the 4 lane groups (kg) of 4 column waves: join the lane groups with
+  // xor-shuffles (both partners end with the merged list), then the 4 waves through LDS
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+      float os[K];
+      int oi[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        os[j] = __shfl_xor(best[mi].s[j], step, 64);
+        oi[j] = __shfl_xor(best[mi].i[j], step, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < K; ++j) best[mi].push(os[j], oi[j]);
+    }
+  }
   __syncthreads();
-  float* ls = (float*)smem;  // [256 rows][8][K]
-  int* li = (int*)(smem + 256 * 8 * K * 4);
+  float* ls = (float*)smem;  // [256 rows][4 waves][K]
+  int* li = (int*)(smem + 256 * 4 * K * 4);
+  if (kg == 0) {
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int row = wr * 128 + mi * 32 + l31;
-    const int slot = wc * 2 + hi;
+    for (int mi = 0; mi < 8; ++mi) {
+      const int row = wr * 128 + mi * 16 + l15;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      ls[(row * 8 + slot) * K + j] = best[mi].s[j];
-      li[(row * 8 + slot) * K + j] = best[mi].i[j];
+      for (int j = 0; j < K; ++j) {
+        ls[(row * 4 + wc) * K + j] = best[mi].s[j];
+        li[(row * 4 + wc) * K + j] = best[mi].i[j];
+      }
     }
   }
   __syncthreads();
@@ -278,7 +291,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     const int row = threadIdx.x;
     TopK<K> t;
     t.init();
-    for (int c = 0; c < 8 * K; ++c) t.push(ls[row * 8 * K + c], li[row * 8 * K + c]);
+    for (int c = 0; c < 4 * K; ++c) t.push(ls[row * 4 * K + c], li[row * 4 * K + c]);
     const size_t o = ((size_t)chunk * nx_pad + m0 + row) * K;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
