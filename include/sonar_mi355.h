@@ -345,7 +345,8 @@ int smi_host_collate_nllb(const int32_t* pieces, const int64_t* piece_offsets, c
 /* TILE-MAJOR operand layout (SMI_GEMM_IN_TM / SMI_GEMM_OUT_TM, `tile_major` arguments): a K-major
  * fp16 matrix A[rows][k] (rows % 256 == 0, k % 32 == 0) stored as 16-KiB blocks, block
  * (r/256, c/32) at element offset ((r/256)*(k/32) + c/32) * 8192, and inside a block element
- * (rr = r%256, cc = c%32) at rr*32 + (((cc/8) ^ ((rr>>2)&3)) << 3) + cc%8 -- the LDS image of the
+ * (rr = r%256, cc = c%32) at rr*32 + (((cc/8) ^ s(rr)) << 3) + cc%8 with s(rr) = q ^ ((q&1)<<1),
+ * q = (rr>>2)&3 (i.e. 0,3,2,1 for q = 0..3: the bank swizzle of the 16x16x32 fragment reads) -- the LDS image of the
  * 256x256 tile engine, so one K slice of a tile is one linear 16 KiB read.  The encoder keeps
  * every GEMM operand (weights, LayerNorm / attention / FFN-inner outputs) in this layout. */
 #define SMI_GEMM_IN_TM (1 << 12)  /* x and w are tile-major (m, n % 256 == 0) */

@@ -45,14 +45,23 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 
 // TILE-MAJOR operand layout of a K-major fp16 matrix A[R][K] (R % 256 == 0, K % 32 == 0): block
 // (r/256, k/32) is 16 KiB contiguous and holds the LDS image the 256x256 tile engine wants (row
-// rr = r%256 at rr*64 B, 16-B chunk c = (k%32)/8 at slot c ^ ((rr>>2)&3)).  A K slice of a tile is
+// rr = r%256 at rr*64 B, 16-B chunk c = (k%32)/8 at slot c ^ tm_swz(rr)).  A K slice of a tile is
 // then ONE linear 16 KiB burst instead of 256 pieces of 64 B (gemm_tile256.hpp).
+// Slot swizzle of a 64-B row: q = (rr>>2)&3 -> q ^ ((q&1)<<1), i.e. 0,3,2,1.  ds_read_b128 serves a wave
+// in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) (MI355X_MICROARCH.md, LDS), and a
+// 16x16x32 MFMA fragment read has lane l -> (row l&15, chunk l>>4): with this map the four 4-lane sets
+// of a group that share a bank quarter (row mod 4) land on four different 16-B slots -> conflict free.
+// (The plain q map of the first version was conflict free for the 32x32x16 fragment pattern only.)
+__host__ __device__ __forceinline__ int tm_swz(int rr) {
+  const int q = (rr >> 2) & 3;
+  return q ^ ((q & 1) << 1);
+}
 constexpr int TM_ROWS = 256;
 constexpr int TM_BLOCK = TM_ROWS * 32;  // elements per block
 // element offset of A[r][k]
 __host__ __device__ __forceinline__ size_t tm_offset(int r, int k, int K) {
   const int rr = r & 255, c = (k >> 3) & 3;
-  return ((size_t)(r >> 8) * (K >> 5) + (k >> 5)) * TM_BLOCK + rr * 32 + ((c ^ ((rr >> 2) & 3)) << 3) + (k & 7);
+  return ((size_t)(r >> 8) * (K >> 5) + (k >> 5)) * TM_BLOCK + rr * 32 + ((c ^ tm_swz(rr)) << 3) + (k & 7);
 }
 
 }  // namespace smi

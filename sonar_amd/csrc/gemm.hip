@@ -346,7 +346,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       // chunk (kg&1)*2 + (kg>>1) of the k-block.  A wave instruction then stores 16 rows x 64 B = one
       // dense, contiguous 1 KiB run of a tile-major block.
       const int cidx = (kg & 1) * 2 + (kg >> 1);
-      const int sw = (l15 >> 2) & 3;
+      const int sw = tm_swz(l15);
       f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
                    (wr * 128 + l15) * 32 + ((cidx ^ sw) << 3);
 #pragma unroll

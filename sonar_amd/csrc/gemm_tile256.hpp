@@ -24,14 +24,14 @@
 // Operand layouts (per operand, template flags XTM / WTM):
 //  * row-major  A[r][k]: a slice is 256 rows x 64 B, rows K*2 bytes apart;
 //  * TILE-MAJOR: block (r/256, k/32) is 16 KiB contiguous and already holds the LDS image
-//    (row rr at rr*64, 16-B chunk c at slot c ^ ((rr>>2)&3)), so a slice is ONE contiguous
+//    (row rr at rr*64, 16-B chunk c at slot c ^ tm_swz(rr), common.hpp), so a slice is ONE contiguous
 //    16 KiB burst and every DMA instruction copies 1 KiB linearly.  Measured +26 % on the bare
 //    operand stream and +7 % on the full GEMM versus row-major: 64-B pieces
 //    2-16 KiB apart are a poor DRAM-page / L2-channel pattern.  Every producer in the
 //    encoder (LayerNorm, attention, the FFN-inner epilogue, weight packing) emits it directly.
 //
 // LDS slice layout: X rows [256][64 B] then W rows [256][64 B]; 16-B chunk c of
-// row r sits at slot c ^ ((r>>2)&3) -> conflict-free ds_read_b128 for the
+// row r sits at slot c ^ tm_swz(r) (common.hpp) -> conflict-free ds_read_b128 for the
 // 16x16x32 operand fragments (lane -> row l&15, chunk l>>4).
 //
 // Hazard bookkeeping (intervals are the spans between consecutive barriers;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int row = (wave * 2 + q) * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+      const int chunk = (lane & 3) ^ tm_swz(row);
       ag[q] = A + (size_t)(row0 + row) * K + chunk * 8;
     }
     kstep = G2_BK;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& sr
 
   // fragment of a 16-row block: lane -> row l&15, 16-B chunk l>>4 (the 8 k values of its MFMA slot)
   const int l15 = lane & 15, kg = lane >> 4;
-  const int t_sw = (kg ^ ((l15 >> 2) & 3)) << 4;
+  const int t_sw = (kg ^ tm_swz(l15)) << 4;
   const int xoff = (wr * 128 + l15) * 64 + t_sw;
   const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l15) * 64 + t_sw;
 

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int row = (wave * 2 + q) * 16 + (lane >> 2);
-      const int chunk16 = (lane & 3) ^ ((row >> 2) & 3);
+      const int chunk16 = (lane & 3) ^ tm_swz(row);
       xg[q] = Xn + (size_t)(m0 + row) * d + chunk16 * 8;
       yg[q] = Yn + ((size_t)t_begin * G2_BN + row) * d + chunk16 * 8;
     }
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
         yg[1] += (size_t)G2_BN * d;
       }
     };
-    const int t_sw = (kg ^ ((l15 >> 2) & 3)) << 4;
+    const int t_sw = (kg ^ tm_swz(l15)) << 4;
     const int xoff = (wr * 128 + l15) * 64 + t_sw;
     const int woff = G2_BM * G2_BK * 2 + (wc * 64 + l15) * 64 + t_sw;
 

@@ -22,15 +22,21 @@ def _stream():
     return int(torch.cuda.current_stream().cuda_stream)
 
 
+def _tm_swz(rr):
+    q = (rr >> 2) & 3
+    return q ^ ((q & 1) << 1)
+
+
 def to_tile_major(a):
     """Independent (torch index arithmetic) statement of the tile-major layout documented in
-    include/sonar_mi355.h: [rows/256][k/32] blocks of [256 rows][4 slots][8], slot = chunk ^ ((row>>2)&3)."""
+    include/sonar_mi355.h: [rows/256][k/32] blocks of [256 rows][4 slots][8], slot = chunk ^ s(row),
+    s(row) = q ^ ((q & 1) << 1) with q = (row >> 2) & 3."""
     rows, k = a.shape
     assert rows % 256 == 0 and k % 32 == 0
     blocks = a.view(rows // 256, 256, k // 32, 4, 8).permute(0, 2, 1, 3, 4)  # [rb, kb, rr, chunk, 8]
     rr = torch.arange(256, device=a.device)
     slot = torch.arange(4, device=a.device)
-    chunk_of_slot = slot[None, :] ^ ((rr[:, None] >> 2) & 3)                 # [rr, slot] -> chunk
+    chunk_of_slot = slot[None, :] ^ _tm_swz(rr)[:, None]                      # [rr, slot] -> chunk
     idx = chunk_of_slot[None, None, :, :, None].expand(rows // 256, k // 32, 256, 4, 8)
     return torch.gather(blocks, 3, idx).contiguous().view(-1)
 
@@ -39,7 +45,7 @@ def from_tile_major(flat, rows, k):
     blocks = flat.view(rows // 256, k // 32, 256, 4, 8)
     rr = torch.arange(256, device=flat.device)
     chunk = torch.arange(4, device=flat.device)
-    slot_of_chunk = chunk[None, :] ^ ((rr[:, None] >> 2) & 3)                # involution
+    slot_of_chunk = chunk[None, :] ^ _tm_swz(rr)[:, None]                     # involution
     idx = slot_of_chunk[None, None, :, :, None].expand(rows // 256, k // 32, 256, 4, 8)
     return torch.gather(blocks, 3, idx).permute(0, 2, 1, 3, 4).reshape(rows, k).contiguous()
 
