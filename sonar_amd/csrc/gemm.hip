@@ -144,11 +144,16 @@ template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
-                                                                void* __restrict__ out, int M, int N,
-                                                                int K, int ldo, GemmTileStats stats) {
+                                                                void* __restrict__ out_, int M, int N,
+                                                                int K, int ldo, GemmTileStats stats, int ksplit,
+                                                                size_t part_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool TM = LAYOUT > 0;
-  const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn, nt = K / G2_BK;
+  // work unit = (tile, K part kz): split-K (EPI_STORE_F32 only) gives each part its own fp32 output slab
+  // at out + kz * part_stride bytes; the bias goes into part 0; the consumer sums the slabs.
+  const int klen = K / ksplit;
+  const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn * ksplit, nt = klen / G2_BK;
+  void* out = out_;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // accumulator layout (gemm_tile256.hpp): lane -> row l15 of a 16-row block, 4 consecutive columns
   // at 4*kg of a 16-column block
@@ -160,19 +165,21 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   // read back with ds_reads, which do not touch the vmcnt queue the next tile's fill sits in.
   float* bias_lds = (float*)g2_stage(smem, 1);
   const int tid = threadIdx.x;
-  auto fetch_bias = [&](int n0) {
+  auto fetch_bias = [&](int n0, int kz) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (bias && tid < 64) v = *(const f32x4*)(bias + n0 + tid * 4);
+    if (bias && kz == 0 && tid < 64) v = *(const f32x4*)(bias + n0 + tid * 4);
     return v;
   };
 
   int tile = xcd_remap(blockIdx.x, gridDim.x);
   if (tile >= ntiles) return;
-  int tile_m, tile_n;
-  g2_tile_coords_of(tile, ntm, ntn, tile_m, tile_n);
-  G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN);
+  // unit id = kz * (ntm * ntn) + output tile: neighbouring ids share operand panels of one K part
+  const int nout = ntm * ntn;
+  int tile_m, tile_n, kz = tile / nout;
+  g2_tile_coords_of(tile % nout, ntm, ntn, tile_m, tile_n);
+  G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
   g2_prefetch(src, nt, smem);
-  f32x4 bias_next = fetch_bias(tile_n * G2_BN);
+  f32x4 bias_next = fetch_bias(tile_n * G2_BN, kz);
 
 #ifdef SMI_GEMM_TRACE
   int trace_i = 0;
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
     const int tile_n_cur = tile_n;
     (void)tile_n_cur;
+    out = (char*)out_ + (size_t)kz * part_stride;
     G2_TRACE(0);
     if (tid < 64) *(f32x4*)(bias_lds + tid * 4) = bias_next;
     GemmTile256Acc acc;
@@ -189,10 +197,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     g2_mainloop(acc, src, nt, smem);
     G2_TRACE(2);
     if (tile + (int)gridDim.x < ntiles) {  // fill for the next tile, behind this tile's epilogue
-      g2_tile_coords_of(tile + gridDim.x, ntm, ntn, tile_m, tile_n);
-      src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN);
+      const int next = tile + gridDim.x;
+      kz = next / nout;
+      g2_tile_coords_of(next % nout, ntm, ntn, tile_m, tile_n);
+      src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
       g2_prefetch(src, nt, smem);
-      bias_next = fetch_bias(tile_n * G2_BN);
+      bias_next = fetch_bias(tile_n * G2_BN, kz);
     }
     G2_TRACE(3);
     constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32;
@@ -427,7 +437,8 @@ static int num_cus() {
 
 template <int EPI, int LAYOUT>
 static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
-                                int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr) {
+                                int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr,
+                                int ksplit = 1, size_t part_stride = 0) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, LAYOUT>,
@@ -435,9 +446,10 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int grid = std::min((M / G2_BM) * (N / G2_BN), num_cus());
+  const int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
-                     stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0});
+                     stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0}, ksplit,
+                     part_stride);
   return hipGetLastError();
 }
 
@@ -515,6 +527,12 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
                                  int N, int K, int ksplit, hipStream_t stream) {
   if (M % GT_BM || N % GT_BN || ksplit < 1 || K % (GT_BK * ksplit) || M <= 0) return hipErrorInvalidValue;
+  // the 256x256 ping-pong engine is far more efficient per CU than the 128x128 one (decoder FFN inner:
+  // 160 tiles on 256 CUs still beat 640 small tiles); use it when the units roughly fill the chip once
+  // and every unit has a real K loop
+  const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
+  if (M % G2_BM == 0 && N % G2_BN == 0 && K / ksplit >= 16 * G2_BK && units256 >= 96 && units256 <= num_cus())
+    return launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
   return launch_one<EPI_STORE_F32>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
 }
 

@@ -75,11 +75,11 @@ struct G2Src {
 };
 
 template <bool TM>
-__device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row0, int wave, int lane,
+__device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row0, int k0, int wave, int lane,
                                        const f16* (&ag)[2], int& kstep) {
   if constexpr (TM) {
     // block (row0/256, kb) starts at ((row0/256)*(K/32) + kb) * 8192 elements; piece i at i*512
-    const f16* base = A + (size_t)(row0 >> 8) * (K >> 5) * TM_BLOCK;
+    const f16* base = A + ((size_t)(row0 >> 8) * (K >> 5) + (k0 >> 5)) * TM_BLOCK;
 #pragma unroll
     for (int q = 0; q < 2; ++q) ag[q] = base + (wave * 2 + q) * 512 + lane * 8;
     kstep = TM_BLOCK;
@@ -88,22 +88,22 @@ __device__ __forceinline__ void g2_src(const f16* __restrict__ A, int K, int row
     for (int q = 0; q < 2; ++q) {
       const int row = (wave * 2 + q) * 16 + (lane >> 2);
       const int chunk = (lane & 3) ^ tm_swz(row);
-      ag[q] = A + (size_t)(row0 + row) * K + chunk * 8;
+      ag[q] = A + (size_t)(row0 + row) * K + k0 + chunk * 8;
     }
     kstep = G2_BK;
   }
 }
 
 // X: [*, K], W: [*, K] (row-major or tile-major per XTM / WTM); rows m0..m0+255 / n0..n0+255
-// readable; K % 32 == 0.
+// readable; K % 32 == 0; the K loop starts at column k0 (k0 % 32 == 0; split-K units).
 template <bool XTM, bool WTM>
 __device__ __forceinline__ G2Src g2_make_src(const f16* __restrict__ X, const f16* __restrict__ W, int K,
-                                             int m0, int n0) {
+                                             int m0, int n0, int k0 = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   G2Src s;
-  g2_src<XTM>(X, K, m0, wave, lane, s.xg, s.xstep);
-  g2_src<WTM>(W, K, n0, wave, lane, s.wg, s.wstep);
+  g2_src<XTM>(X, K, m0, k0, wave, lane, s.xg, s.xstep);
+  g2_src<WTM>(W, K, n0, k0, wave, lane, s.wg, s.wstep);
   return s;
 }
 
