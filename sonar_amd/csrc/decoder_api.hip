@@ -108,7 +108,7 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
     HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
     HIP_TRY(launch_sum_layernorm(x, parts, ks_out, part_stride, D->cc.as<float>() + (size_t)l * n_pad * d, group,
                                  L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | (rows_pad % 256 == 0 && f % 256 == 0 ? 2 << 8 : 0), h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
     HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream));
   }
   HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,

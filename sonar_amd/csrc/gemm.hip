@@ -480,9 +480,10 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   if (out_tm && (!in_tm || ldo != N)) return hipErrorInvalidValue;
   const bool can256 = M % G2_BM == 0 && N % G2_BN == 0;
   if (sel == 2 && !can256) return hipErrorInvalidValue;
-  // the 256x256 engine runs one workgroup per CU: it needs a grid that fills the 256 CUs,
-  // otherwise the 128x128 engine (4x the workgroups) wins (decode-time GEMMs, M ~ 1k rows)
-  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 192);
+  // the 256x256 ping-pong engine is ~1.5x more efficient per CU than the 128x128 one but has a 21 us
+  // floor for a K = 1024 tile and one workgroup per CU; measured crossover (tools/probe_engines.py):
+  // 128 tiles tie, 160 tiles win -> use it from 144 tiles (56 % of the CUs) up
+  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 144);
   if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
     if (epi != EPI_STORE_F32 || in_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
     return launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);
