@@ -160,3 +160,36 @@ def test_basic_decoder_greedy_is_teacher_forced_argmax():
         norm = total / (len(prompt) + L - 1)
         assert abs(norm - scores[i, 0].item()) <= 2e-2
         assert scores5[i, 0].item() >= scores[i, 0].item() - 2e-2
+
+
+def test_speech_encoder_full_size_properties():
+    """sonar_speech_encoder_eng at full size (24 conformer blocks, d = 1024, random-init): batching
+    invariance of SpeechToEmbedding (reference: tests/integration_tests/test_sonar_speech_pipeline_models.py
+    batch-vs-single checks) and determinism, on clips of different lengths (1.3 - 6 s)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveform_to_fbank
+    from tools.synth import speech_encoder_state_dict
+
+    dev = torch.device("cuda:0")
+    eng = SpeechEncoderEngine(get_speech_encoder_config("english"), speech_encoder_state_dict(dev), device=dev)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    nsamp = [96000, 21000, 64000, 33333, 80640]
+    feats = [waveform_to_fbank(torch.rand(n, device=dev, generator=g) * 2 - 1) for n in nsamp]
+    tmax = max(f.shape[0] for f in feats)
+    tmax += tmax % 2
+    batch = torch.zeros(len(feats), tmax, 80, device=dev)
+    lens = torch.tensor([f.shape[0] for f in feats])
+    for i, f in enumerate(feats):
+        batch[i, : f.shape[0]] = f
+    out = eng.forward(batch, lens, torch.float32)
+    assert out.shape == (5, 1024) and torch.isfinite(out).all()
+    assert torch.equal(out, eng.forward(batch, lens, torch.float32))
+    for i, f in enumerate(feats):
+        t = f.shape[0] + f.shape[0] % 2
+        one = torch.zeros(1, t, 80, device=dev)
+        one[0, : f.shape[0]] = f
+        alone = eng.forward(one, torch.tensor([f.shape[0]]), torch.float32)
+        assert _cos_err(alone, out[i:i + 1]) <= 1e-3
