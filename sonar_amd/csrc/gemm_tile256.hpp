@@ -208,10 +208,12 @@ __device__ __forceinline__ int g2_col(int n0, int ni) {
   return n0 + (wave & 3) * 64 + ni * 16 + 4 * (lane >> 4);
 }
 
-// XCD-aware grouped raster over 256x256 tiles: the ~32 workgroups resident on
-// one XCD (1 per CU) cover a 4(m) x 8(n) super-tile.
+// XCD-aware grouped raster over 256x256 tiles: the 32 workgroups resident on one XCD (1 per CU)
+// cover an 8(m) x 4(n) super-tile, and with N/256 = 32 column tiles a persistent round is exactly one
+// group, so an XCD keeps the SAME 4 W panels (2 MiB of its 4 MiB L2) round after round while the X
+// panels stream through (measured against 4 x 8: FFN-inner 45.3 -> 44.7 ms per step).
 __device__ __forceinline__ void g2_tile_coords_of(int id, int ntm, int ntn, int& tile_m, int& tile_n) {
-  constexpr int GM = 4;
+  constexpr int GM = 8;
   const int per_group = GM * ntn;
   const int group = id / per_group;
   const int first_m = group * GM;
