@@ -96,9 +96,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
   }
 }
 
-// TM: h in the tile-major GEMM operand layout (common.hpp); 8 lanes then cover one 64-B row piece
-// of a block and the 4 waves of a workgroup (4 consecutive rows) one 256-B run per k-block.
-template <int NV, bool TM>
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps,
@@ -114,26 +112,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       half4 o;
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = (f16)y[k][i];
-      if constexpr (TM)
-        *(half4*)(h + tm_offset(r, k * 256 + lane * 4, D)) = o;
-      else
-        *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+      *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
     }
+  }
+}
+
+// Tile-major output (the GEMM operand layout of common.hpp).  A workgroup normalises 16 consecutive
+// rows into an LDS tile and then writes them out per 32-column k-block: 16 rows x 64 B are one
+// contiguous 1 KiB run of a tile-major block, i.e. one fully coalesced wave store (a row-at-a-time
+// writer would scatter 64-B pieces 16 KiB apart).  h holds rows rounded up to 16 (256 in practice).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_tm_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b, float eps,
+                                                           f16* __restrict__ h, int rows) {
+  constexpr int D = NV * 256;
+  constexpr int RS = D * 2 + 16;  // LDS row stride in bytes (+16: the 16 rows of a read hit different banks)
+  __shared__ __attribute__((aligned(16))) char tile[16 * RS];
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  for (int r0 = blockIdx.x * 16; r0 < rows; r0 += gridDim.x * 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lr = wv + 4 * q;
+      f32x4 y[NV];
+      if (r0 + lr < rows) {
+        ln_row<NV>(x + (size_t)(r0 + lr) * D, w, b, eps, lane, y);
+      } else {  // rows past the end of x inside the last 16-row group: zeros
+#pragma unroll
+        for (int k = 0; k < NV; ++k) y[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        half4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (f16)y[k][i];
+        *(half4*)(tile + lr * RS + (k * 256 + lane * 4) * 2) = o;
+      }
+    }
+    __syncthreads();
+    // wave wv copies k-blocks wv, wv+4, ...: lane -> (row lane>>2, slot lane&3)
+    const int lr = lane >> 2, slot = lane & 3;
+    const int rr = (r0 & 255) + lr;
+    const int chunk = slot ^ tm_swz(rr);
+    f16* dst = h + (size_t)(r0 >> 8) * (D >> 5) * TM_BLOCK + rr * 32 + slot * 8;
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) {
+      const int kb = wv + 4 * i;
+      const f32x4 v = *(const f32x4*)(tile + lr * RS + (kb * 32 + chunk * 8) * 2);
+      *(f32x4*)(dst + (size_t)kb * TM_BLOCK) = v;
+    }
+    __syncthreads();
   }
 }
 
 hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
                             int rows, int d, hipStream_t stream, int out_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
-  const int blocks = min((rows + 3) / 4, 256 * 32);
-#define SMI_LN_CASE(NV)                                                                              \
-  case NV * 256:                                                                                     \
-    if (out_tm)                                                                                      \
-      hipLaunchKernelGGL((layernorm_kernel<NV, true>), dim3(blocks), dim3(256), 0, stream, x, w, b, \
-                         eps, h, rows);                                                              \
-    else                                                                                             \
-      hipLaunchKernelGGL((layernorm_kernel<NV, false>), dim3(blocks), dim3(256), 0, stream, x, w, b, \
-                         eps, h, rows);                                                              \
+  const int blocks = out_tm ? min((rows + 15) / 16, 256 * 16) : min((rows + 3) / 4, 256 * 32);
+#define SMI_LN_CASE(NV)                                                                                 \
+  case NV * 256:                                                                                        \
+    if (out_tm)                                                                                         \
+      hipLaunchKernelGGL(layernorm_tm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, h, \
+                         rows);                                                                         \
+    else                                                                                                \
+      hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, h,    \
+                         rows);                                                                         \
     break;
   switch (d) {
     SMI_LN_CASE(1)
