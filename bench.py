@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--xsim-nx", type=int, default=65536, help="X rows per rank")
     ap.add_argument("--xsim-ny", type=int, default=1 << 20, help="total Y rows (sharded over ranks)")
     ap.add_argument("--cpu-sentences", type=int, default=96)
+    ap.add_argument("--fp32-residual", action="store_true",
+                    help="keep the encoder's residual stream in fp32 (default: fp16, as the reference's fp16 model)")
     args = ap.parse_args()
 
     import torch
@@ -147,7 +149,8 @@ def main():
     cfg = get_text_encoder_config("basic")
     t0 = time.time()
     sd = text_encoder_state_dict(dev)
-    model = SonarTextTransformerEncoderModel(cfg, sd, device=dev, dtype=torch.float16, max_tokens_hint=BATCH * SEQ)
+    model = SonarTextTransformerEncoderModel(cfg, sd, device=dev, dtype=torch.float16, max_tokens_hint=BATCH * SEQ,
+                                             fp16_residual=not args.fp32_residual)
     del sd
     torch.cuda.empty_cache()
     log(f"[rank {rank}] engine ready in {time.time() - t0:.1f}s, {model.engine.device_bytes / 1e9:.2f} GB in HBM")

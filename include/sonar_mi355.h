@@ -63,8 +63,15 @@ typedef struct smi_text_encoder_config {
   float embed_scale;     /* sqrt(model_dim), or 1 if no_scale_embedding */
   float ln_eps;          /* 1e-5 */
   int32_t pooling;       /* smi_pooling (config.py: pooling="mean") */
-  int32_t reserved;
+  int32_t flags;         /* SMI_ENC_* */
 } smi_text_encoder_config;
+
+/* smi_text_encoder_config.flags */
+/* Keep the residual stream in fp16 instead of fp32.  The reference's fp16 model does exactly this
+ * (every tensor of the model is fp16, sonar/inference_pipelines/text.py:161-162 `.to(device, dtype)`);
+ * the engine's default fp32 stream costs 2x the residual traffic and buys ~100x margin on the 1e-3
+ * parity bound.  With the flag each residual add is one fp32 add rounded once to fp16. */
+#define SMI_ENC_FP16_RESIDUAL 1
 
 /* Per-layer parameters, names as produced by the reference's checkpoint
  * conversion (sonar/models/sonar_text/handler.py:71-82).  Linear weights are
@@ -356,9 +363,10 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
                         void* stream);
 /* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi & 0xff: 0 f16 out, 1 f16 ReLU out,
  * 2 fp32 residual accumulate (out += ...), 3 fp32 store, 4 fp32 residual += 0.5 * (...),
- * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out (bias may be NULL);
+ * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out, 8 f16 residual accumulate
+ * (out_f16 = f16(float(out_f16) + ...), one rounding) (bias may be NULL);
  * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
- * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5).
+ * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 8) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5).
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);

@@ -16,6 +16,7 @@ SMI_OK = 0
 SMI_F32, SMI_F16 = 0, 1
 SMI_POOL = {"mean": 0, "max": 1, "last": 2}
 SMI_GEMM_IN_TM, SMI_GEMM_OUT_TM = 1 << 12, 1 << 13
+SMI_ENC_FP16_RESIDUAL = 1
 PROF_SLOTS = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_ffn1", "gemm_ffn2", "ln_pool"]
 STATUS_NAMES = {
     0: "SMI_OK",
@@ -54,7 +55,7 @@ class smi_text_encoder_config(C.Structure):
         ("embed_scale", C.c_float),
         ("ln_eps", C.c_float),
         ("pooling", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 

@@ -93,6 +93,7 @@ struct smi_text_encoder {
   int64_t weight_bytes = 0;
   // every GEMM operand (weights, h, ctx, ffn) in the tile-major layout of common.hpp
   bool tile_major = false;
+  bool x16 = false;  // SMI_ENC_FP16_RESIDUAL: the residual stream x is fp16
   // optional per-launch event timing
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
@@ -131,7 +132,7 @@ int ensure_workspace(smi_text_encoder* e, int64_t rows) {
   HIP_TRY(hipDeviceSynchronize());
   const int64_t d = e->cfg.model_dim, f = e->cfg.ffn_inner_dim;
   e->cap_rows = 0;
-  HIP_TRY(e->x.alloc((size_t)rows * d * 4));
+  HIP_TRY(e->x.alloc((size_t)rows * d * (e->x16 ? 2 : 4)));
   HIP_TRY(e->h.alloc((size_t)rows * d * 2));
   HIP_TRY(e->qkv.alloc((size_t)rows * 3 * d * 2));
   HIP_TRY(e->ctx.alloc((size_t)rows * d * 2));
@@ -227,6 +228,7 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
   up(w->final_layer_norm_b, d, false, e->lnf_b, "layer_norm.bias");
   e->layers.resize(cfg->num_layers);
   e->tile_major = f % 256 == 0;  // d % 256 == 0 always (check_cfg)
+  e->x16 = (cfg->flags & SMI_ENC_FP16_RESIDUAL) != 0;
   for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
     const smi_text_encoder_layer& s = w->layers[l];
     Layer& L = e->layers[l];
@@ -340,44 +342,47 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   if (int rc = ensure_workspace(e, rows)) return rc;
   const int M = (int)rows;
 
-  float* x = e->x.as<float>();
+  void* x = e->x.p;
+  const int x16 = e->x16;
+  const size_t xes = x16 ? 2 : 4;
+  const int epi_resid = x16 ? EPI_RESID_F16 : EPI_RESID_F32;
   f16* h = e->h.as<f16>();
   f16* qkv = e->qkv.as<f16>();
   f16* ctx = e->ctx.as<f16>();
   f16* ffn = e->ffn.as<f16>();
 
   if (rows > total)
-    HIP_TRY(hipMemsetAsync(x + (size_t)total * d, 0, (size_t)(rows - total) * d * 4, stream));
+    HIP_TRY(hipMemsetAsync((char*)x + (size_t)total * d * xes, 0, (size_t)(rows - total) * d * xes, stream));
   { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
-                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream)); }
-  // x (fp32 residual stream) stays row-major; h, qkv, ctx, ffn and the weights are tile-major
+                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream, x16)); }
+  // x (residual stream, fp32 or fp16 with SMI_ENC_FP16_RESIDUAL) stays row-major; h, qkv, ctx, ffn and the weights are tile-major
   const int tm = e->tile_major;
   const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   for (int l = 0; l < c.num_layers; ++l) {
     Layer& L = e->layers[l];
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm)); }
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16)); }
     { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
                            d, 3 * d, stream)); }
     { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
     HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
     { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32 | in_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
+    HIP_TRY(launch_gemm_tn(epi_resid | in_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
                            stream)); }
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm)); }
+    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f,
                            stream)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32 | in_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
+    HIP_TRY(launch_gemm_tn(epi_resid | in_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
                            stream)); }
   }
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
-                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream)); }
+                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream, x16)); }
   return SMI_OK;
 }
 
@@ -446,10 +451,10 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
   if (!x || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
   const int e = epi & 0xff, sel = (epi >> 8) & 0xf;
   const bool in_tm = epi & GEMM_IN_TM, out_tm = epi & GEMM_OUT_TM;
-  if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 7 || sel > 2 || m <= 0 || m % 128 ||
+  if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 8 || sel > 2 || m <= 0 || m % 128 ||
       n <= 0 || n % 128 || k <= 0 || k % 64 || ldo < (e == 6 ? n / 2 : n) || (sel == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
-  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5) : (e != 0 && e != 2 && e != 3 && e != 4))))
+  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5) : (e != 0 && e != 2 && e != 3 && e != 4 && e != 8))))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major gemm: m=%d n=%d epi=%d", m, n, epi);
   if (out_tm && (!in_tm || ldo != n))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n");

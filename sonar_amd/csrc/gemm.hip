@@ -18,6 +18,7 @@ namespace smi {
 // EPI_RESID_HALF_F32: resid[m][n] += 0.5 * (acc + bias[n])    (macaron half-step FFN)
 // EPI_SILU_F16      : out_h[m][n]  = f16(silu(acc + bias[n]))
 // EPI_TANH_F16      : out_h[m][n]  = f16(tanh(acc + bias[n]))
+// EPI_RESID_F16     : resid_h[m][n] = f16(float(resid_h[m][n]) + acc + bias[n])   (fp16 residual stream)
 // EPI_GLU_F16       : out_h[m][g*32+c] = f16(a * sigmoid(b)), a/b = columns g*64+c / g*64+32+c
 //                     (W rows interleaved in 32-channel groups at pack time), out width N/2
 // bias may be null for every epilogue.
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
             f32x4 o = *(f32x4*)p;
             if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
             *(f32x4*)p = o + v;
+          } else if constexpr (EPI == EPI_RESID_F16) {
+            f16* p = (f16*)out + (size_t)m * ldo + n;
+            const half4 o = *(const half4*)p;
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (f16)((float)o[e] + v[e]);
+            *(half4*)p = h;
           } else if constexpr (EPI == EPI_STORE_F32) {
             *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
           } else {
@@ -205,7 +213,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       bias_next = fetch_bias(tile_n * G2_BN, kz);
     }
     G2_TRACE(3);
-    constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32;
+    // epilogues that leave through the fp32 staging passes (fp32 outputs and the fp16 residual stream,
+    // whose read-modify-write adds in fp32 and rounds once)
+    constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32 || EPI == EPI_RESID_F16;
     // bias of the lane's columns (fp16-output epilogues; the fp32 ones add it at read-out time)
     f32x4 b[4];
     if constexpr (!F32_OUT) {
@@ -285,10 +295,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         for (int it = 0; it < 4; ++it) {
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
-          if constexpr (EPI == EPI_STORE_F32)
+          if constexpr (EPI == EPI_STORE_F32) {
             o[it] = bro[nh];
-          else
+          } else if constexpr (EPI == EPI_RESID_F16) {
+            const half4 hv = *(const half4*)((const f16*)out + (size_t)row * ldo + gcol);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[it][e] = (float)hv[e] + bro[nh][e];
+          } else {
             o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol) + bro[nh];
+          }
         }
       };
       f32x4 old[2][4];
@@ -316,7 +331,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
-          *(f32x4*)((float*)out + (size_t)row * ldo + gcol) = old[sp & 1][it] + v;
+          if constexpr (EPI == EPI_RESID_F16) {
+            const f32x4 sum = old[sp & 1][it] + v;
+            half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (f16)sum[e];
+            *(half4*)((f16*)out + (size_t)row * ldo + gcol) = hv;
+          } else {
+            *(f32x4*)((float*)out + (size_t)row * ldo + gcol) = old[sp & 1][it] + v;
+          }
         }
       }
     } else if constexpr (EPI == EPI_GLU_F16) {
@@ -506,6 +529,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       SMI_EPI_CASE(EPI_RESID_F32, 1)
       SMI_EPI_CASE(EPI_STORE_F32, 1)
       SMI_EPI_CASE(EPI_RESID_HALF_F32, 1)
+      SMI_EPI_CASE(EPI_RESID_F16, 1)
     }
     return hipErrorInvalidValue;
   }
@@ -518,6 +542,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     SMI_EPI_CASE(EPI_SILU_F16, 0)
     SMI_EPI_CASE(EPI_GLU_F16, 0)
     SMI_EPI_CASE(EPI_TANH_F16, 0)
+    SMI_EPI_CASE(EPI_RESID_F16, 0)
   }
 #undef SMI_EPI_CASE
   return hipErrorInvalidValue;

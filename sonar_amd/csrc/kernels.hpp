@@ -10,7 +10,7 @@ typedef _Float16 f16;
 
 enum GemmEpilogue {
   EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3,
-  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6, EPI_TANH_F16 = 7
+  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6, EPI_TANH_F16 = 7, EPI_RESID_F16 = 8
 };
 
 // layout flags OR-ed into epi_sel (tile-major layout: common.hpp tm_offset)
@@ -36,22 +36,23 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
                                  int N, int K, int ksplit, hipStream_t stream);
 
 // x[row(n,p), :] = E[ids[n*S+p], :] * scale + PE[p + pos_offset, :]   (packed rows)
+// x_f16: the residual stream x is fp16 (SMI_ENC_FP16_RESIDUAL) instead of fp32
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu_seqlens, const f16* table,
-                             const float* pos_table, float scale, int pos_offset, float* x, int N,
-                             int S, int max_len, int d, int64_t vocab, hipStream_t stream);
+                             const float* pos_table, float scale, int pos_offset, void* x, int N,
+                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16 = 0);
 
 // h[r,:] = f16(LN(x[r,:]) * w + b)
 // out_tm: h is written tile-major (rows rounded up to 256 must be allocated)
-hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream, int out_tm = 0);
+hipError_t launch_layernorm(const void* x, const float* w, const float* b, float eps, f16* h,
+                            int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0);
 // dst (tile-major) <- src (row-major [rows][K]), rows % 256 == 0, K % 32 == 0; and the inverse
 hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int inverse, hipStream_t stream);
 
 // Final LN + masked pooling (mean) over each sentence's packed rows.
 // out: [N, d] in fp16 or fp32; encoded (optional): [N, S, d] same dtype, pads zeroed.
-hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float eps,
+hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float eps,
                           const int32_t* cu_seqlens, void* out, int out_is_f32, void* encoded, int N,
-                          int S, int d, int pooling, hipStream_t stream);
+                          int S, int d, int pooling, hipStream_t stream, int x_f16 = 0);
 
 // Self-attention over packed rows. qkv: [T, 3*d] (q | k | v), ctx: [T, d].  head_dim 64.
 // ctx_tm bit 0: ctx is written tile-major; bit 1: qkv is read tile-major (K = 3d).

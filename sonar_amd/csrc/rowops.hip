@@ -17,12 +17,14 @@ namespace smi {
 // ---------------------------------------------------------------- embed+pack
 // grid (N, ceil(max_len/4)), 256 threads: wave w handles position blockIdx.y*4+w
 // of sentence blockIdx.x; rows beyond the sentence length do nothing.
+// XT: type of the residual stream x (float, or f16 when the encoder runs with SMI_ENC_FP16_RESIDUAL)
+template <typename XT>
 __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restrict__ ids,
                                                          const int32_t* __restrict__ cu,
                                                          const f16* __restrict__ table,
                                                          const float* __restrict__ pos_table,
                                                          float scale, int pos_offset,
-                                                         float* __restrict__ x, int S, int d,
+                                                         XT* __restrict__ x, int S, int d,
                                                          int64_t vocab) {
   const int n = blockIdx.x;
   const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -34,7 +36,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // never read out of the table
   const f16* e = table + (size_t)tok * d;
   const float* pe = pos_table + (size_t)(p + pos_offset) * d;
-  float* o = x + (size_t)(start + p) * d;
+  XT* o = x + (size_t)(start + p) * d;
   for (int c = lane * 8; c < d; c += 512) {
     const half8 ev = *(const half8*)(e + c);
     const f32x4 p0 = *(const f32x4*)(pe + c);
@@ -46,32 +48,52 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
       o0[i] = (float)(f16)((float)ev[i] * scale) + p0[i];
       o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
     }
-    *(f32x4*)(o + c) = o0;
-    *(f32x4*)(o + c + 4) = o1;
+    if constexpr (sizeof(XT) == 4) {
+      *(f32x4*)(o + c) = o0;
+      *(f32x4*)(o + c + 4) = o1;
+    } else {
+      half8 h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h[i] = (f16)o0[i];
+        h[i + 4] = (f16)o1[i];
+      }
+      *(half8*)(o + c) = h;
+    }
   }
 }
 
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* table,
-                             const float* pos_table, float scale, int pos_offset, float* x, int N,
-                             int S, int max_len, int d, int64_t vocab, hipStream_t stream) {
+                             const float* pos_table, float scale, int pos_offset, void* x, int N,
+                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16) {
   if (d % 8 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(N, (max_len + 3) / 4);
-  hipLaunchKernelGGL(embed_pack_kernel, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                     pos_offset, x, S, d, vocab);
+  if (x_f16)
+    hipLaunchKernelGGL(embed_pack_kernel<f16>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
+                       pos_offset, (f16*)x, S, d, vocab);
+  else
+    hipLaunchKernelGGL(embed_pack_kernel<float>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
+                       pos_offset, (float*)x, S, d, vocab);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- LayerNorm
 // NV = d / 256 float4 vectors per lane; lane l owns columns 256*k + 4*l .. +3.
-template <int NV>
-__device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float* __restrict__ w,
+template <int NV, typename XT = float>
+__device__ __forceinline__ void ln_row(const XT* __restrict__ xr, const float* __restrict__ w,
                                        const float* __restrict__ b, float eps, int lane,
                                        f32x4 (&y)[NV]) {
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    if constexpr (sizeof(XT) == 4) {
+      v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    } else {
+      const half4 hv = *(const half4*)(xr + k * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = (float)hv[i];
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   constexpr float inv_d = 1.0f / (NV * 256);
@@ -96,8 +118,8 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, const float
   }
 }
 
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps,
                                                         f16* __restrict__ h, int rows) {
@@ -106,7 +128,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   constexpr int D = NV * 256;
   for (int r = blockIdx.x * 4 + wv; r < rows; r += gridDim.x * 4) {
     f32x4 y[NV];
-    ln_row<NV>(x + (size_t)r * D, w, b, eps, lane, y);
+    ln_row<NV, XT>(x + (size_t)r * D, w, b, eps, lane, y);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       half4 o;
@@ -121,8 +143,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // rows into an LDS tile and then writes them out per 32-column k-block: 16 rows x 64 B are one
 // contiguous 1 KiB run of a tile-major block, i.e. one fully coalesced wave store (a row-at-a-time
 // writer would scatter 64-B pieces 16 KiB apart).  h holds rows rounded up to 16 (256 in practice).
-template <int NV>
-__global__ __launch_bounds__(256) void layernorm_tm_kernel(const float* __restrict__ x,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps,
                                                            f16* __restrict__ h, int rows) {
@@ -137,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const float* __restri
       const int lr = wv + 4 * q;
       f32x4 y[NV];
       if (r0 + lr < rows) {
-        ln_row<NV>(x + (size_t)(r0 + lr) * D, w, b, eps, lane, y);
+        ln_row<NV, XT>(x + (size_t)(r0 + lr) * D, w, b, eps, lane, y);
       } else {  // rows past the end of x inside the last 16-row group: zeros
 #pragma unroll
         for (int k = 0; k < NV; ++k) y[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -166,18 +188,24 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const float* __restri
   }
 }
 
-hipError_t launch_layernorm(const float* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream, int out_tm) {
+hipError_t launch_layernorm(const void* x, const float* w, const float* b, float eps, f16* h,
+                            int rows, int d, hipStream_t stream, int out_tm, int x_f16) {
   if (rows <= 0) return hipErrorInvalidValue;
   const int blocks = out_tm ? min((rows + 15) / 16, 256 * 16) : min((rows + 3) / 4, 256 * 32);
-#define SMI_LN_CASE(NV)                                                                                 \
-  case NV * 256:                                                                                        \
-    if (out_tm)                                                                                         \
-      hipLaunchKernelGGL(layernorm_tm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, h, \
-                         rows);                                                                         \
-    else                                                                                                \
-      hipLaunchKernelGGL(layernorm_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, w, b, eps, h,    \
-                         rows);                                                                         \
+#define SMI_LN_LAUNCH(NV, XT)                                                                                      \
+  if (out_tm)                                                                                                      \
+    hipLaunchKernelGGL((layernorm_tm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, \
+                       h, rows);                                                                                   \
+  else                                                                                                             \
+    hipLaunchKernelGGL((layernorm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, h, \
+                       rows);
+#define SMI_LN_CASE(NV)             \
+  case NV * 256:                    \
+    if (x_f16) {                    \
+      SMI_LN_LAUNCH(NV, f16)        \
+    } else {                        \
+      SMI_LN_LAUNCH(NV, float)      \
+    }                               \
     break;
   switch (d) {
     SMI_LN_CASE(1)
@@ -188,14 +216,15 @@ hipError_t launch_layernorm(const float* x, const float* w, const float* b, floa
     default: return hipErrorInvalidValue;
   }
 #undef SMI_LN_CASE
+#undef SMI_LN_LAUNCH
   return hipGetLastError();
 }
 
 // ------------------------------------------------- final LayerNorm + pooling
 // One workgroup per sentence; wave w walks rows w, w+4, ...; the pooled vector
 // is combined across the 4 waves through LDS.  pooling: 0 mean, 1 max, 2 last.
-template <int NV, typename OutT>
-__global__ __launch_bounds__(256) void ln_pool_kernel(const float* __restrict__ x,
+template <int NV, typename OutT, typename XT>
+__global__ __launch_bounds__(256) void ln_pool_kernel(const XT* __restrict__ x,
                                                       const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps,
                                                       const int32_t* __restrict__ cu,
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const float* __restrict__ 
 
   for (int p = wv; p < len; p += 4) {
     f32x4 y[NV];
-    ln_row<NV>(x + (size_t)(start + p) * D, w, b, eps, lane, y);
+    ln_row<NV, XT>(x + (size_t)(start + p) * D, w, b, eps, lane, y);
     if (encoded) {
       OutT* e = encoded + ((size_t)n * S + p) * D;
 #pragma unroll
@@ -260,18 +289,28 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const float* __restrict__ 
   }
 }
 
-hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float eps,
+hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float eps,
                           const int32_t* cu, void* out, int out_is_f32, void* encoded, int N, int S,
-                          int d, int pooling, hipStream_t stream) {
+                          int d, int pooling, hipStream_t stream, int x_f16) {
   if (N <= 0 || pooling < 0 || pooling > 2) return hipErrorInvalidValue;
-#define SMI_LP_CASE(NV)                                                                            \
-  case NV * 256:                                                                                   \
-    if (out_is_f32)                                                                                \
-      hipLaunchKernelGGL((ln_pool_kernel<NV, float>), dim3(N), dim3(256), 0, stream, x, w, b, eps, \
-                         cu, (float*)out, (float*)encoded, S, pooling);                            \
-    else                                                                                           \
-      hipLaunchKernelGGL((ln_pool_kernel<NV, f16>), dim3(N), dim3(256), 0, stream, x, w, b, eps,   \
-                         cu, (f16*)out, (f16*)encoded, S, pooling);                                \
+#define SMI_LP_LAUNCH(NV, OutT, XT)                                                                               \
+  hipLaunchKernelGGL((ln_pool_kernel<NV, OutT, XT>), dim3(N), dim3(256), 0, stream, (const XT*)x, w, b, eps, cu, \
+                     (OutT*)out, (OutT*)encoded, S, pooling);
+#define SMI_LP_CASE(NV)                 \
+  case NV * 256:                        \
+    if (out_is_f32) {                   \
+      if (x_f16) {                      \
+        SMI_LP_LAUNCH(NV, float, f16)   \
+      } else {                          \
+        SMI_LP_LAUNCH(NV, float, float) \
+      }                                 \
+    } else {                            \
+      if (x_f16) {                      \
+        SMI_LP_LAUNCH(NV, f16, f16)     \
+      } else {                          \
+        SMI_LP_LAUNCH(NV, f16, float)   \
+      }                                 \
+    }                                   \
     break;
   switch (d) {
     SMI_LP_CASE(1)
@@ -282,6 +321,7 @@ hipError_t launch_ln_pool(const float* x, const float* w, const float* b, float 
     default: return hipErrorInvalidValue;
   }
 #undef SMI_LP_CASE
+#undef SMI_LP_LAUNCH
   return hipGetLastError();
 }
 

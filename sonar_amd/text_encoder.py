@@ -184,9 +184,13 @@ class TextEncoderEngine:
     """Owns one `smi_text_encoder` handle (packed fp16 weights + workspace in HBM)."""
 
     def __init__(self, cfg: SonarTextEncoderConfig, state_dict: Mapping[str, torch.Tensor],
-                 device: Union[str, torch.device] = "cuda:0", max_tokens_hint: int = 0):
+                 device: Union[str, torch.device] = "cuda:0", max_tokens_hint: int = 0,
+                 fp16_residual: bool = False):
+        """fp16_residual: keep the residual stream in fp16 as the reference's fp16 model does
+        (SMI_ENC_FP16_RESIDUAL); default is an fp32 stream (more accurate, 2x the residual traffic)."""
         check_supported(cfg)
         self.cfg = cfg
+        self.fp16_residual = bool(fp16_residual)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the SONAR MI355X engine runs on a HIP device only (no CPU path)")
@@ -200,7 +204,8 @@ class TextEncoderEngine:
             ffn_inner_dim=cfg.ffn_inner_dim, vocab_size=cfg.vocab_info.size,
             max_seq_len=cfg.model_max_seq_len, pos_offset=cfg.pos_offset,
             embed_scale=1.0 if cfg.no_scale_embedding else math.sqrt(d), ln_eps=1e-5,
-            pooling=_lib.SMI_POOL[cfg.pooling], reserved=0)
+            pooling=_lib.SMI_POOL[cfg.pooling],
+            flags=_lib.SMI_ENC_FP16_RESIDUAL if fp16_residual else 0)
         keep: List[torch.Tensor] = []
         sd = state_dict
 
@@ -333,14 +338,20 @@ class SonarTextTransformerEncoderModel:
 
     def __init__(self, cfg: SonarTextEncoderConfig, state_dict: Mapping[str, torch.Tensor],
                  device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
-                 return_encoded_seqs: bool = False, max_tokens_hint: int = 0):
+                 return_encoded_seqs: bool = False, max_tokens_hint: int = 0,
+                 fp16_residual: Optional[bool] = None):
+        """dtype: dtype of the returned embeddings and, as in the reference (`model.to(device, dtype)`,
+        text.py:161-162), of the residual stream: fp16 model -> fp16 residual adds (one rounding each),
+        fp32 model -> fp32 residual stream.  `fp16_residual` overrides that choice."""
+        if fp16_residual is None:
+            fp16_residual = dtype == torch.float16
         self.config = cfg
         self.dtype = dtype
         self.model_dim = cfg.model_dim
         self.pooling = cfg.pooling
         self.return_encoded_seqs = return_encoded_seqs
         self.encoder_frontend = _FrontendInfo(cfg.model_max_seq_len)
-        self.engine = TextEncoderEngine(cfg, state_dict, device, max_tokens_hint)
+        self.engine = TextEncoderEngine(cfg, state_dict, device, max_tokens_hint, fp16_residual)
         self.device = self.engine.device
 
     def eval(self):

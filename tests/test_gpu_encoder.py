@@ -24,7 +24,8 @@ def _cos_err(a, b):
 
 @pytest.mark.parametrize("pooling", ["mean", "max", "last"])
 @pytest.mark.parametrize("ragged", [True, False])
-def test_encoder_small_vs_oracle(pooling, ragged):
+@pytest.mark.parametrize("fp16_residual", [False, True])
+def test_encoder_small_vs_oracle(pooling, ragged, fp16_residual):
     from oracle import text_encoder as O
     from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch, PaddingMask
 
@@ -38,7 +39,7 @@ def test_encoder_small_vs_oracle(pooling, ragged):
     enc_ref, emb_ref = O.text_encoder_forward(params, ocfg, ids, lens if ragged else None)
 
     model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32,
-                                             return_encoded_seqs=True)
+                                             return_encoded_seqs=True, fp16_residual=fp16_residual)
     mask = PaddingMask(lens, ids.shape[1]) if ragged else None
     out = model(SequenceBatch(ids.cuda(), mask))
     torch.cuda.synchronize()

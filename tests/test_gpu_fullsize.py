@@ -19,7 +19,8 @@ def _cos_err(a, b):
     return (1 - F.cosine_similarity(a.float().cpu(), b.float().cpu(), dim=-1)).abs().max().item()
 
 
-def test_encoder_full_width_vs_oracle():
+@pytest.mark.parametrize("fp16_residual", [False, True])
+def test_encoder_full_width_vs_oracle(fp16_residual):
     from oracle import text_encoder as O
     from sonar_amd.text_encoder import (PaddingMask, SequenceBatch, SonarTextEncoderConfig,
                                         SonarTextTransformerEncoderModel, VocabularyInfo)
@@ -32,9 +33,11 @@ def test_encoder_full_width_vs_oracle():
     assert int(lens.sum()) >= 9216   # >= 36 row tiles: all four projections take the 256x256 engine
     torch.set_num_threads(min(32, torch.get_num_threads()))
     _, ref = O.text_encoder_forward(params, ocfg, ids, lens)
-    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32,
+                                             fp16_residual=fp16_residual)
     emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
     assert torch.isfinite(emb).all()
+    print(f"fp16_residual={fp16_residual}: max (1 - cos) vs oracle = {_cos_err(emb, ref):.2e}")
     assert _cos_err(emb, ref) <= 1e-3          # north_star tolerance
     # a small slice of the same sentences goes through the 128x128 engine: same vectors
     sub = model(SequenceBatch(ids[:3].cuda(), PaddingMask(lens[:3], ids.shape[1]))).sentence_embeddings
@@ -193,3 +196,28 @@ def test_speech_encoder_full_size_properties():
         one[0, : f.shape[0]] = f
         alone = eng.forward(one, torch.tensor([f.shape[0]]), torch.float32)
         assert _cos_err(alone, out[i:i + 1]) <= 1e-3
+
+
+@pytest.mark.parametrize("fp16_residual", [False, True])
+def test_encoder_full_depth_vs_oracle(fp16_residual):
+    """All 24 layers at the real widths (d = 1024, F = 8192, 16 heads; small vocabulary) against the fp32
+    CPU oracle on a small ragged batch: the accumulated error of the whole stack, for both residual-stream
+    precisions, against the north_star bound."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import (PaddingMask, SequenceBatch, SonarTextEncoderConfig,
+                                        SonarTextTransformerEncoderModel, VocabularyInfo)
+
+    ocfg = O.OracleTextEncoderConfig(model_dim=1024, num_layers=24, num_heads=16, ffn_inner_dim=8192, vocab_size=3000)
+    cfg = SonarTextEncoderConfig(model_dim=1024, num_encoder_layers=24, num_encoder_attn_heads=16, ffn_inner_dim=8192,
+                                 vocab_info=VocabularyInfo(size=3000), _from_fairseq=True)
+    params = O.make_synthetic_params(ocfg, seed=2024, std=0.02)
+    ids, lens = O.synthetic_batch(6, 12, 64, ocfg.vocab_size, seed=4)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    _, ref = O.text_encoder_forward(params, ocfg, ids, lens)
+    for dt in (torch.float32, torch.float16):
+        model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=dt, fp16_residual=fp16_residual)
+        emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+        err = _cos_err(emb, ref)
+        print(f"24 layers, fp16_residual={fp16_residual}, out {dt}: max (1 - cos) vs fp32 oracle = {err:.2e}")
+        assert torch.isfinite(emb).all() and err <= 1e-3
+        del model

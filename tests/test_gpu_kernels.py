@@ -69,7 +69,7 @@ def test_pack_tile_major(lib, rows, k):
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (256, 512, 192), (512, 1024, 1024), (256, 256, 8192),
                                    (1024, 768, 256)])
-@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1)])
+@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1), (8, 0)])
 def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
     """Tile-major operands (and output) on both tile engines against the same fp32 reference."""
     from sonar_amd import _lib
@@ -86,6 +86,10 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
             resid = torch.randn(m, n, device="cuda", generator=g)
             out = resid.clone()
             want = resid + (ref if epi == 2 else 0.5 * ref)
+        elif epi == 8:
+            resid = torch.randn(m, n, device="cuda", generator=g).half()
+            out = resid.clone()
+            want = resid.float() + ref
         elif epi == 3:
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
             want = ref
@@ -99,7 +103,7 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
         assert torch.isfinite(got).all()
         err = (got - want).abs().max().item()
         scale = max(want.abs().max().item(), 1.0)
-        assert err <= (2e-3 if epi in (0, 1, 5) else 2e-5) * scale, (sel, err, scale)
+        assert err <= (2e-3 if epi in (0, 1, 5, 8) else 2e-5) * scale, (sel, err, scale)
     # unsupported combinations are refused, not mis-computed
     assert lib.smi_gemm_tn(6 | flags, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n, _stream()) != 0
     assert lib.smi_gemm_tn(0 | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n,
@@ -109,7 +113,7 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
                                    (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
                                    (256, 256, 8192), (1024, 768, 256)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_tn(lib, m, n, k, epi):
     from sonar_amd import _lib
 
@@ -127,6 +131,10 @@ def test_gemm_tn(lib, m, n, k, epi):
             resid = torch.randn(m, n, device="cuda", generator=g)
             out = resid.clone()
             ref = resid + (ref if epi == 2 else 0.5 * ref)
+        elif epi == 8:   # fp16 residual stream: out = f16(float(out) + x.w^T + b), one rounding
+            resid = torch.randn(m, n, device="cuda", generator=g).half()
+            out = resid.clone()
+            ref = resid.float() + ref
         elif epi in (5, 7):
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
             ref = torch.nn.functional.silu(ref) if epi == 5 else torch.tanh(ref)
@@ -149,7 +157,7 @@ def test_gemm_tn(lib, m, n, k, epi):
         err = (got - ref).abs().max().item()
         scale = max(ref.abs().max().item(), 1.0)
         # fp16 output: half-ulp rounding of the result; fp32 outputs: accumulation order only
-        allowed = (2e-3 if epi in (0, 1, 5, 6, 7) else 2e-5) * scale
+        allowed = (2e-3 if epi in (0, 1, 5, 6, 7, 8) else 2e-5) * scale
         assert err <= allowed, (sel, err, scale)
 
 
