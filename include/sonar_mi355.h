@@ -229,6 +229,8 @@ typedef struct smi_speech_encoder_config {
   int32_t bos_idx;          /* 2 */
   int32_t max_frames;       /* largest number of STACKED frames per clip (rel-pos table), e.g. 4096 */
   float ln_eps, bn_eps;     /* 1e-5, 1e-5 */
+  int32_t flags;            /* SMI_ENC_FP16_RESIDUAL: fp16 residual stream, as the reference's `.half()` model */
+  int32_t reserved;
 } smi_speech_encoder_config;
 
 typedef struct smi_conformer_layer {
@@ -364,9 +366,9 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
 /* out = epilogue(X[m,k] . W[n,k]^T + bias[n]); epi & 0xff: 0 f16 out, 1 f16 ReLU out,
  * 2 fp32 residual accumulate (out += ...), 3 fp32 store, 4 fp32 residual += 0.5 * (...),
  * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out, 8 f16 residual accumulate
- * (out_f16 = f16(float(out_f16) + ...), one rounding) (bias may be NULL);
+ * (out_f16 = f16(float(out_f16) + ...), one rounding), 9 the same with 0.5 * (...) (bias may be NULL);
  * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
- * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 8) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5).
+ * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 8, 9) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5).
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);

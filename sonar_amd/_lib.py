@@ -140,7 +140,7 @@ class smi_speech_encoder_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model_dim", "num_layers", "num_heads", "ffn_inner_dim", "conv_kernel", "num_mel_bins",
         "pooler_layers", "pooler_heads", "pooler_ffn_dim", "pooler_vocab", "bos_idx", "max_frames")] + [
-        ("ln_eps", C.c_float), ("bn_eps", C.c_float)]
+        ("ln_eps", C.c_float), ("bn_eps", C.c_float), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 _CONF_LAYER_FIELDS = [

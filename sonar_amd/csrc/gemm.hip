@@ -19,6 +19,7 @@ namespace smi {
 // EPI_SILU_F16      : out_h[m][n]  = f16(silu(acc + bias[n]))
 // EPI_TANH_F16      : out_h[m][n]  = f16(tanh(acc + bias[n]))
 // EPI_RESID_F16     : resid_h[m][n] = f16(float(resid_h[m][n]) + acc + bias[n])   (fp16 residual stream)
+// EPI_RESID_HALF_F16: resid_h[m][n] = f16(float(resid_h[m][n]) + 0.5 * (acc + bias[n]))
 // EPI_GLU_F16       : out_h[m][g*32+c] = f16(a * sigmoid(b)), a/b = columns g*64+c / g*64+32+c
 //                     (W rows interleaved in 32-channel groups at pack time), out width N/2
 // bias may be null for every epilogue.
@@ -107,9 +108,10 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
             f32x4 o = *(f32x4*)p;
             if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
             *(f32x4*)p = o + v;
-          } else if constexpr (EPI == EPI_RESID_F16) {
+          } else if constexpr (EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16) {
             f16* p = (f16*)out + (size_t)m * ldo + n;
             const half4 o = *(const half4*)p;
+            if constexpr (EPI == EPI_RESID_HALF_F16) v = v * 0.5f;
             half4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e) h[e] = (f16)((float)o[e] + v[e]);
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     G2_TRACE(3);
     // epilogues that leave through the fp32 staging passes (fp32 outputs and the fp16 residual stream,
     // whose read-modify-write adds in fp32 and rounds once)
-    constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32 || EPI == EPI_RESID_F16;
+    constexpr bool F16_RESID = EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16;
+    constexpr bool HALF_STEP = EPI == EPI_RESID_HALF_F32 || EPI == EPI_RESID_HALF_F16;
+    constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32 || F16_RESID;
     // bias of the lane's columns (fp16-output epilogues; the fp32 ones add it at read-out time)
     f32x4 b[4];
     if constexpr (!F32_OUT) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       for (int nh = 0; nh < 2; ++nh) {
         bro[nh] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (bias) bro[nh] = *(const f32x4*)(bias + n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4);
-        if constexpr (EPI == EPI_RESID_HALF_F32) bro[nh] = bro[nh] * 0.5f;
+        if constexpr (HALF_STEP) bro[nh] = bro[nh] * 0.5f;
       }
       auto load_old = [&](int sp, f32x4 (&o)[4]) {
         const int p = sp >> 1, nh = sp & 1;
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           if constexpr (EPI == EPI_STORE_F32) {
             o[it] = bro[nh];
-          } else if constexpr (EPI == EPI_RESID_F16) {
+          } else if constexpr (F16_RESID) {
             const half4 hv = *(const half4*)((const f16*)out + (size_t)row * ldo + gcol);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[it][e] = (float)hv[e] + bro[nh][e];
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           for (int nl = 0; nl < 2; ++nl) {
             const int mi = 2 * p + mh, ni = 2 * nh + nl;
             f32x4 v = acc.v[ni][mi];
-            if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
+            if constexpr (HALF_STEP) v = v * 0.5f;
             const int lr = lr_w(mi);
             // 16-B chunk (4 floats) of the 128 staged columns: wc*8 + nl*4 + kg
             *(f32x4*)(st + lr * 512 + (((wc * 8 + nl * 4 + kg) ^ g2_stage_swz(lr)) << 4)) = v;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
-          if constexpr (EPI == EPI_RESID_F16) {
+          if constexpr (F16_RESID) {
             const f32x4 sum = old[sp & 1][it] + v;
             half4 hv;
 #pragma unroll
@@ -530,6 +534,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       SMI_EPI_CASE(EPI_STORE_F32, 1)
       SMI_EPI_CASE(EPI_RESID_HALF_F32, 1)
       SMI_EPI_CASE(EPI_RESID_F16, 1)
+      SMI_EPI_CASE(EPI_RESID_HALF_F16, 1)
     }
     return hipErrorInvalidValue;
   }
@@ -543,6 +548,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     SMI_EPI_CASE(EPI_GLU_F16, 0)
     SMI_EPI_CASE(EPI_TANH_F16, 0)
     SMI_EPI_CASE(EPI_RESID_F16, 0)
+    SMI_EPI_CASE(EPI_RESID_HALF_F16, 0)
   }
 #undef SMI_EPI_CASE
   return hipErrorInvalidValue;

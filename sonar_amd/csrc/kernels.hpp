@@ -10,7 +10,8 @@ typedef _Float16 f16;
 
 enum GemmEpilogue {
   EPI_BIAS_F16 = 0, EPI_RELU_F16 = 1, EPI_RESID_F32 = 2, EPI_STORE_F32 = 3,
-  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6, EPI_TANH_F16 = 7, EPI_RESID_F16 = 8
+  EPI_RESID_HALF_F32 = 4, EPI_SILU_F16 = 5, EPI_GLU_F16 = 6, EPI_TANH_F16 = 7, EPI_RESID_F16 = 8,
+  EPI_RESID_HALF_F16 = 9
 };
 
 // layout flags OR-ed into epi_sel (tile-major layout: common.hpp tm_offset)
@@ -128,8 +129,8 @@ hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int st
 hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t* cu, int max_len, const float* w,
                            const float* b, float eps, f16* out, int ldo, hipStream_t stream);
 // x = LN1(x) in place; h = f16(w2 ? LN2(x) : x) (h may be null)
-hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream, int out_tm = 0);
+hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0);
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
                                    int heads, hipStream_t stream);

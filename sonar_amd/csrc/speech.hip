@@ -202,8 +202,8 @@ hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t*
 
 // =============================================================== LayerNorm variants (fp32 stream)
 // x = LN1(x) in place (fp32); h = f16(w2 ? LN2(x) : x).  One wave per row.
-template <int NV, bool TM>
-__global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const float* __restrict__ w1,
+template <int NV, bool TM, typename XT>
+__global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const float* __restrict__ w1,
                                                   const float* __restrict__ b1,
                                                   const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float eps,
@@ -213,12 +213,18 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const f
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
-  float* xr = x + (size_t)r * D;
+  XT* xr = x + (size_t)r * D;
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    if constexpr (sizeof(XT) == 4) {
+      v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    } else {
+      const half4 hv = *(const half4*)(xr + k * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = (float)hv[i];
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   float mean = wave_sum(s) * inv_d, q = 0.f;
@@ -237,7 +243,17 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const f
     const f32x4 bv = *(const f32x4*)(b1 + k * 256 + lane * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[k][i] = v[k][i] * rstd * wv[i] + bv[i];
-    *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    if constexpr (sizeof(XT) == 4) {
+      *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    } else {
+      half4 hv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hv[i] = (f16)v[k][i];
+        v[k][i] = (float)hv[i];  // the second LayerNorm sees what the stream holds
+      }
+      *(half4*)(xr + k * 256 + lane * 4) = hv;
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   if (!h) return;
@@ -272,18 +288,27 @@ __global__ __launch_bounds__(256) void ln2_kernel(float* __restrict__ x, const f
   }
 }
 
-hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream, int out_tm) {
+hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm, int x_f16) {
   if (rows <= 0) return hipErrorInvalidValue;
   const int blocks = (rows + 3) / 4;
-#define SMI_LN2_CASE(NV)                                                                                       \
-  case NV * 256:                                                                                               \
-    if (out_tm)                                                                                                \
-      hipLaunchKernelGGL((ln2_kernel<NV, true>), dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
-                         rows);                                                                                \
-    else                                                                                                       \
-      hipLaunchKernelGGL((ln2_kernel<NV, false>), dim3(blocks), dim3(256), 0, stream, x, w1, b1, w2, b2, eps, h, \
-                         rows);                                                                                \
+#define SMI_LN2_LAUNCH(NV, TMF, XT) \
+  hipLaunchKernelGGL((ln2_kernel<NV, TMF, XT>), dim3(blocks), dim3(256), 0, stream, (XT*)x, w1, b1, w2, b2, eps, h, rows);
+#define SMI_LN2_CASE(NV)                 \
+  case NV * 256:                         \
+    if (out_tm) {                        \
+      if (x_f16) {                       \
+        SMI_LN2_LAUNCH(NV, true, f16)    \
+      } else {                           \
+        SMI_LN2_LAUNCH(NV, true, float)  \
+      }                                  \
+    } else {                             \
+      if (x_f16) {                       \
+        SMI_LN2_LAUNCH(NV, false, f16)   \
+      } else {                           \
+        SMI_LN2_LAUNCH(NV, false, float) \
+      }                                  \
+    }                                    \
     break;
   switch (d) {
     SMI_LN2_CASE(1)
@@ -294,6 +319,7 @@ hipError_t launch_ln2(float* x, const float* w1, const float* b1, const float* w
     default: return hipErrorInvalidValue;
   }
 #undef SMI_LN2_CASE
+#undef SMI_LN2_LAUNCH
   return hipGetLastError();
 }
 

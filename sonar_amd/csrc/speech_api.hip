@@ -117,6 +117,7 @@ struct smi_speech_encoder {
   smi_speech_encoder_config cfg;
   int kpad = 0;  // stacked feature dim padded to a multiple of 64
   int ffn_tile_major = 0;  // macaron FFN operands (LN output, hidden, weights) in the tile-major layout
+  int x16 = 0;             // SMI_ENC_FP16_RESIDUAL: the conformer's residual stream is fp16
   DevBuf pe_ln_w, pe_ln_b, proj_w, proj_b, ln_w, ln_b, pool_q0, pool_out_w, rel_table;
   std::vector<ConfLayer> layers;
   std::vector<PoolLayer> pooler;
@@ -231,6 +232,7 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
   }
   E->layers.resize(c.num_layers);
   E->ffn_tile_major = f % 256 == 0;  // d % 256 == 0 is checked above
+  E->x16 = (c.flags & SMI_ENC_FP16_RESIDUAL) != 0;
   for (int l = 0; l < c.num_layers && rc == SMI_OK; ++l) {
     const smi_conformer_layer& s = w->layers[l];
     ConfLayer& L = E->layers[l];
@@ -371,7 +373,7 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   const int32_t* dcu = E->cu.as<int32_t>();
   const size_t before = E->hf.bytes + E->x.bytes + E->ctx.bytes + E->glu.bytes + E->dw.bytes + E->big.bytes;
   HIP_TRY(E->hf.reserve((size_t)R * E->kpad * 2));
-  HIP_TRY(E->x.reserve((size_t)R * d * 4));
+  HIP_TRY(E->x.reserve((size_t)R * d * 4));  // sized for fp32; an fp16 stream uses half of it
   HIP_TRY(E->h.reserve((size_t)R * d * 2));
   HIP_TRY(E->big.reserve((size_t)R * f * 2));
   HIP_TRY(E->qkv.reserve((size_t)R * 3 * d * 2));
@@ -397,7 +399,9 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
     HIP_TRY(hipMemsetAsync(E->hq.p, 0, E->hq.bytes, stream));
     HIP_TRY(hipMemsetAsync(E->xq.p, 0, E->xq.bytes, stream));
   }
-  float* x = E->x.as<float>();
+  void* x = E->x.p;
+  const int x16 = E->x16;
+  const int epi_res = x16 ? EPI_RESID_F16 : EPI_RESID_F32, epi_half = x16 ? EPI_RESID_HALF_F16 : EPI_RESID_HALF_F32;
   f16* h = E->h.as<f16>();
   f16* big = E->big.as<f16>();
   f16* qkv = E->qkv.as<f16>();
@@ -406,7 +410,8 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   // frontend: stack 2 frames -> LN(160) -> Linear(160 -> d)
   HIP_TRY(launch_stack_ln(fbank, n, t, c.num_mel_bins, dcu, tm, E->pe_ln_w.as<float>(), E->pe_ln_b.as<float>(), c.ln_eps,
                           E->hf.as<f16>(), E->kpad, stream));
-  HIP_TRY(launch_gemm_tn(EPI_STORE_F32, E->hf.as<f16>(), E->proj_w.as<f16>(), E->proj_b.as<float>(), x, R, d, E->kpad, d, stream));
+  HIP_TRY(launch_gemm_tn(x16 ? EPI_BIAS_F16 : EPI_STORE_F32, E->hf.as<f16>(), E->proj_w.as<f16>(), E->proj_b.as<float>(), x, R, d,
+                         E->kpad, d, stream));
   // relative positions rel in [-(tm-1), tm-1] (+ tile padding) from the ascending table
   const int64_t P = c.max_frames + 192;
   const f16* pe_slice = E->rel_table.as<f16>() + (size_t)((P - 1) - (tm - 1)) * d;
@@ -416,37 +421,37 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   const int tmf = E->ffn_tile_major;
   const int ffn_in = tmf ? GEMM_IN_TM : 0, ffn_io = tmf ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream,
-                           tmf));
+                           tmf, x16));
   for (int l = 0; l < c.num_layers; ++l) {
     ConfLayer& L = E->layers[l];
     // x += 0.5 * FFN1(LN(x))
     HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn1_w1.as<f16>(), L.ffn1_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32 | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
+    HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
                            stream));
     // x += RelPosMHA(LN(x))
-    HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream));
+    HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream, 0, x16));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, pe_slice, L.w_r.as<f16>(), nullptr, E->rp.p, rp_m, d, d, d, stream));
     HIP_TRY(launch_relpos_attention(qkv, dcu, E->rp.as<f16>(), tm - 1, rp_m, L.u_bias.as<float>(), L.v_bias.as<float>(), ctx,
                                     n, tm, d, c.num_heads, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
+    HIP_TRY(launch_gemm_tn(epi_res, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
     // x += Conv(LN(x)): pointwise(d->2d)+GLU, depthwise+BN+SiLU, pointwise(d->d)
-    HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream));
+    HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, 0, x16));
     HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8), h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
     HIP_TRY(launch_dwconv_bn_silu(E->glu.as<f16>(), dcu, L.w_dw.as<float>(), L.bn_scale.as<float>(), L.bn_shift.as<float>(),
                                   E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_F32, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
+    HIP_TRY(launch_gemm_tn(epi_res, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
     // x += 0.5 * FFN2(LN(x))
-    HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf));
+    HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
     HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F32 | ffn_in, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d,
+    HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d,
                            stream));
     // x = LN_block(x); h = next block's ffn1 LN, or the model-level LayerNorm after the last block
     const bool last = l + 1 == c.num_layers;
     const float* w2 = last ? E->ln_w.as<float>() : E->layers[l + 1].ffn1_ln_w.as<float>();
     const float* b2 = last ? E->ln_b.as<float>() : E->layers[l + 1].ffn1_ln_b.as<float>();
     // (the last block's h is the encoder output the pooler reads row-major)
-    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream, last ? 0 : tmf));
+    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream, last ? 0 : tmf, x16));
   }
   // ---- attention pooler: h now holds the encoder output (fp16) ----
   float* xq = E->xq.as<float>();

@@ -117,7 +117,9 @@ class SpeechEncoderEngine:
     """Owns one `smi_speech_encoder` handle."""
 
     def __init__(self, cfg: SonarSpeechEncoderConfig, state_dict: Mapping[str, torch.Tensor],
-                 device: Union[str, torch.device] = "cuda:0"):
+                 device: Union[str, torch.device] = "cuda:0", fp16_residual: bool = True):
+        """fp16_residual: the conformer's residual stream in fp16, as the reference's `.half()` model on a GPU
+        (speech.py:426-429); False keeps it in fp32."""
         if cfg.fbank_stride != 2:
             raise NotImplementedError("only 2-frame stacking is covered by the MI355X engine")
         self.cfg = cfg
@@ -135,7 +137,8 @@ class SpeechEncoderEngine:
             num_mel_bins=cfg.num_fbank_channels, pooler_layers=cfg.num_decoder_layers,
             pooler_heads=cfg.num_decoder_attn_heads, pooler_ffn_dim=cfg.decoder_ffn_inner_dim,
             pooler_vocab=int(state_dict["encoder_pooler.decoder_frontend.embed.weight"].shape[0]),
-            bos_idx=cfg.bos_idx, max_frames=cfg.max_frames, ln_eps=1e-5, bn_eps=1e-5)
+            bos_idx=cfg.bos_idx, max_frames=cfg.max_frames, ln_eps=1e-5, bn_eps=1e-5,
+            flags=_lib.SMI_ENC_FP16_RESIDUAL if fp16_residual else 0, reserved=0)
         keep: List[torch.Tensor] = []
 
         def tv(name: str, flat: bool = False) -> _lib.smi_tensor:
@@ -260,11 +263,15 @@ class SonarSpeechEncoderModel:
     (speech.py:452): SequenceBatch of fbank features -> SonarEncoderOutput."""
 
     def __init__(self, cfg: SonarSpeechEncoderConfig, state_dict: Mapping[str, torch.Tensor],
-                 device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16):
+                 device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
+                 fp16_residual: Optional[bool] = None):
+        """dtype: dtype of the returned embeddings and (as in the reference) of the residual stream, unless
+        `fp16_residual` says otherwise."""
         self.config = cfg
         self.model_dim = cfg.model_dim
         self.dtype = dtype
-        self.engine = SpeechEncoderEngine(cfg, state_dict, device)
+        self.engine = SpeechEncoderEngine(cfg, state_dict, device,
+                                          dtype == torch.float16 if fp16_residual is None else fp16_residual)
         self.device = self.engine.device
 
     def eval(self):

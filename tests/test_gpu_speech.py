@@ -44,7 +44,8 @@ def test_fbank_vs_oracle(nsamples, standardize):
 
 
 @pytest.mark.parametrize("ragged", [True, False])
-def test_speech_encoder_vs_oracle(ragged):
+@pytest.mark.parametrize("fp16_residual", [True, False])
+def test_speech_encoder_vs_oracle(ragged, fp16_residual):
     from oracle import speech_encoder as OS
     from sonar_amd.speech_encoder import SpeechEncoderEngine
 
@@ -58,7 +59,7 @@ def test_speech_encoder_vs_oracle(ragged):
         for i, L in enumerate(lens.tolist()):
             fb[i, L:] = 0
     _, ref = OS.speech_encoder_forward(params, ocfg, fb, lens)
-    eng = SpeechEncoderEngine(cfg, params, device="cuda:0")
+    eng = SpeechEncoderEngine(cfg, params, device="cuda:0", fp16_residual=fp16_residual)
     emb = eng.forward(fb.cuda(), lens, torch.float32)
     torch.cuda.synchronize()
     assert emb.shape == (n, 256) and torch.isfinite(emb).all()
