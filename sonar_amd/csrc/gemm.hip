@@ -202,7 +202,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     G2_TRACE(0);
     if (tid < 64) *(f32x4*)(bias_lds + tid * 4) = bias_next;
     GemmTile256Acc acc;
-    g2_begin(acc);
+    g2_begin(acc, bias_lds);
     G2_TRACE(1);
     g2_mainloop(acc, src, nt, smem);
     G2_TRACE(2);
@@ -220,12 +220,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     constexpr bool F16_RESID = EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16;
     constexpr bool HALF_STEP = EPI == EPI_RESID_HALF_F32 || EPI == EPI_RESID_HALF_F16;
     constexpr bool F32_OUT = EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_HALF_F32 || F16_RESID;
-    // bias of the lane's columns (fp16-output epilogues; the fp32 ones add it at read-out time)
-    f32x4 b[4];
-    if constexpr (!F32_OUT) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b[ni] = *(const f32x4*)(bias_lds + wc * 64 + ni * 16 + 4 * kg);
-    }
     // staged epilogues: pass p holds tile rows wr*128 + p*32 + (0..31) of both row groups =
     // accumulator blocks mi = 2p, 2p+1; a lane writes staging row lr_w(mi)
     auto lr_w = [&](int mi) { return wr * 32 + (mi & 1) * 16 + l15; };
@@ -283,15 +277,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       // of sub-pass sp (the barrier's memory clobber would otherwise pin every load behind it and
       // expose one HBM latency per sub-pass).
       const int c = lane & 31;
-      // what the read-out adds to the staged accumulators: the old residual values (RESID) and the
-      // bias of the lane's 4 read-out columns (same columns for every row)
-      f32x4 bro[2];
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        bro[nh] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (bias) bro[nh] = *(const f32x4*)(bias + n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4);
-        if constexpr (HALF_STEP) bro[nh] = bro[nh] * 0.5f;
-      }
       auto load_old = [&](int sp, f32x4 (&o)[4]) {
         const int p = sp >> 1, nh = sp & 1;
         const int gcol = n0 + (c >> 3) * 64 + nh * 32 + (c & 7) * 4;
@@ -300,13 +285,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
           if constexpr (EPI == EPI_STORE_F32) {
-            o[it] = bro[nh];
+            o[it] = f32x4{0.f, 0.f, 0.f, 0.f};
           } else if constexpr (F16_RESID) {
             const half4 hv = *(const half4*)((const f16*)out + (size_t)row * ldo + gcol);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[it][e] = (float)hv[e] + bro[nh][e];
+            for (int e = 0; e < 4; ++e) o[it][e] = (float)hv[e];
           } else {
-            o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol) + bro[nh];
+            o[it] = *(const f32x4*)((const float*)out + (size_t)row * ldo + gcol);
           }
         }
       };
@@ -360,7 +345,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             half4 h;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              h[e] = (f16)((acc.v[nl][mi][e] + b[nl][e]) * sigmoid_f(acc.v[nl + 2][mi][e] + b[nl + 2][e]));
+              h[e] = (f16)(acc.v[nl][mi][e] * sigmoid_f(acc.v[nl + 2][mi][e]));
             const int lr = lr_w(mi);
             // 16-B chunk (8 channels) of the 128 staged channels: wc*4 + nl*2 + (kg>>1), half kg&1
             *(half4*)(st + lr * 512 + (((wc * 4 + nl * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
@@ -393,7 +378,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           uint32_t h[2][2];
 #pragma unroll
           for (int nl = 0; nl < 2; ++nl) {
-            f32x4 v = acc.v[2 * j + nl][mi] + b[2 * j + nl];
+            f32x4 v = acc.v[2 * j + nl][mi];
             v = epi_act<EPI>(v);
             const half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
             h[nl][0] = __builtin_bit_cast(uint32_t, lo);
@@ -416,7 +401,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) {
             const int mi = 2 * p + mh;
-            f32x4 v = acc.v[ni][mi] + b[ni];
+            f32x4 v = acc.v[ni][mi];
             v = epi_act<EPI>(v);
             half4 h;
 #pragma unroll

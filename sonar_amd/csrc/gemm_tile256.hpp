@@ -129,16 +129,20 @@ __device__ __forceinline__ void g2_prefetch(const G2Src& s, int nt, char* smem) 
   if (nt > 2) g2_issue(s, 2, smem, wave);
 }
 
-// Tile start: clear the accumulators and retire the pipeline fill issued by g2_prefetch together
-// with the previous epilogue's stores (vmcnt does not tell loads from stores); after this only
-// counted waits.  Separate from the loop so the caller can pin its own early loads (bias) here.
-__device__ __forceinline__ void g2_begin(GemmTile256Acc& acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc.v[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+// Tile start: retire the pipeline fill issued by g2_prefetch together with the previous epilogue's
+// stores (vmcnt does not tell loads from stores) and the bias slice written to LDS by the caller; after
+// this only counted waits.  The accumulators start from the bias of their columns (bias_lds: the
+// tile's 256 bias values, zeros if there is none), so no epilogue has to add it.
+__device__ __forceinline__ void g2_begin(GemmTile256Acc& acc, const float* bias_lds) {
   SMI_WAIT_VMCNT(0);
-  SMI_BARRIER();  // slices 0..2 complete for everyone
+  SMI_LGKM0_BARRIER();  // slices 0..2 and the bias slice complete for everyone
+  const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) & 3;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const f32x4 b = *(const f32x4*)(bias_lds + wc * 64 + ni * 16 + 4 * (lane >> 4));
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) acc.v[ni][mi] = b;
+  }
 }
 
 // K loop of one tile (after g2_begin).
