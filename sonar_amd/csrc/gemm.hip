@@ -2,7 +2,8 @@
 // (q/k/v/out projections, FFNs, pointwise convolutions: reference wiring at
 // sonar/models/sonar_text/factory.py:130-153 and, for the conformer, fairseq2's
 // ConformerBlock built by sonar/models/sonar_speech/factory.py:64-71), fp16 in, fp32
-// accumulate on v_mfma_f32_32x32x16_f16, with the epilogues fused.
+// accumulate on MFMA (v_mfma_f32_16x16x32_f16 in the 256x256 engine, 32x32x16 in the 128x128 one),
+// with the epilogues fused.
 #include <algorithm>
 
 #include "gemm_tile.hpp"
