@@ -168,3 +168,25 @@ def test_predict_pipeline_end_to_end(tmp_path):
         assert _cos_err(out, ref) <= 1e-3, kw
         assert (out.cpu() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     assert pipe.predict(texts[:2], "eng_Latn", target_device=torch.device("cpu")).device.type == "cpu"
+
+
+def test_encoder_empty_sentences_in_batch():
+    """seq_lens[i] = 0 is legal at the C ABI: the empty sentence pools to zeros and does not disturb its
+    neighbours (packed rows: it simply owns no row); an all-empty batch returns zeros."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch, PaddingMask
+
+    ocfg, cfg = _cfgs()
+    params = O.make_synthetic_params(ocfg, seed=7, std=0.08)
+    ids, lens = O.synthetic_batch(5, 4, 30, ocfg.vocab_size, seed=8)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    full = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+    lens0 = lens.clone()
+    lens0[1] = 0
+    lens0[4] = 0
+    out = model(SequenceBatch(ids.cuda(), PaddingMask(lens0, ids.shape[1]))).sentence_embeddings
+    assert (out[1] == 0).all() and (out[4] == 0).all()
+    for i in (0, 2, 3):
+        assert (out[i] - full[i]).abs().max().item() <= 1e-5 * max(1.0, full.abs().max().item())
+    none = model(SequenceBatch(ids.cuda(), PaddingMask(torch.zeros_like(lens), ids.shape[1]))).sentence_embeddings
+    assert (none == 0).all()
