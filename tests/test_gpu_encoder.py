@@ -190,3 +190,26 @@ def test_encoder_empty_sentences_in_batch():
         assert (out[i] - full[i]).abs().max().item() <= 1e-5 * max(1.0, full.abs().max().item())
     none = model(SequenceBatch(ids.cuda(), PaddingMask(torch.zeros_like(lens), ids.shape[1]))).sentence_embeddings
     assert (none == 0).all()
+
+
+def test_encoder_max_seq_len_514():
+    """The longest sequence the model accepts (512 + pad_idx + 1 = 514 positions, factory.py:56-59) next to
+    short ones, against the oracle; one more token is refused (text.py:202-209 raises for max_seq_len)."""
+    from oracle import text_encoder as O
+    from sonar_amd import _lib
+    from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, SequenceBatch, PaddingMask
+
+    ocfg, cfg = _cfgs()
+    assert cfg.model_max_seq_len == 514
+    params = O.make_synthetic_params(ocfg, seed=3, std=0.08)
+    g = torch.Generator().manual_seed(12)
+    lens = torch.tensor([514, 1, 257, 64])
+    ids = torch.zeros(4, 514, dtype=torch.int64)
+    for i, L in enumerate(lens.tolist()):
+        ids[i, :L] = torch.randint(4, ocfg.vocab_size, (L,), generator=g)
+    _, ref = O.text_encoder_forward(params, ocfg, ids, lens)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, 514))).sentence_embeddings
+    assert _cos_err(emb, ref) <= 1e-3
+    with pytest.raises(_lib.SmiError):
+        model(SequenceBatch(torch.zeros(1, 515, dtype=torch.int64).cuda(), None))
