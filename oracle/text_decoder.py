@@ -14,8 +14,13 @@ Pinning status:
     and translations (:107-118) need the real checkpoint: PARITY UNPINNED for those;
   * the beam search restates fairseq2 ~=0.4 `BeamSearchSeq2SeqGenerator` /
     `StandardBeamSearchAlgorithm` (un-vendored dependency, pyproject.toml:27) from its
-    published behaviour: PARITY UNPINNED beyond self-consistency
-    (greedy beam == argmax decoding, scores == teacher-forced log-probs).
+    published behaviour.  The beam_size=1 generation loop (prompt forcing,
+    incremental steps, EOS stop, min-length EOS suppression) is pinned token-for-token to
+    HuggingFace `generate(num_beams=1)` through tests/golden/m2m100_greedy_twin.pt
+    (generator tests/golden/make_golden_generate.py); beam_size>1 hypothesis bookkeeping
+    (2*beam candidates, length normalisation, forced EOS at the cap) is PARITY UNPINNED
+    beyond self-consistency (scores == teacher-forced log-probs, ordering, EOS rules) --
+    HF's beam scorer finalises hypotheses differently and cannot serve as its twin.
 """
 from __future__ import annotations
 

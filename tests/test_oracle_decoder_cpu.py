@@ -81,3 +81,40 @@ def test_beam_search_properties():
         assert all(len(h.seq) <= 1 + 6 + 0 for h in hs)                   # source_len*1 + 6 generated tokens max
         assert [h.score for h in hs] == sorted((h.score for h in hs), reverse=True)
         assert all(0 not in h.seq.tolist() for h in hs)                   # PAD never generated
+
+
+GREEDY = os.path.join(os.path.dirname(__file__), "golden", "m2m100_greedy_twin.pt")
+
+
+def test_greedy_generation_matches_hf_generate():
+    """The generation loop (prompt forcing, incremental steps, EOS stop, min-length EOS
+    suppression) against HuggingFace generate(num_beams=1) on a tied twin
+    (tests/golden/make_golden_generate.py).  At the length cap the reference forces EOS
+    (fairseq2 beam search) where HF just stops: that last token is excluded."""
+    from sonar_amd.text_decoder import convert_sonar_text_decoder_checkpoint
+
+    fx = torch.load(GREEDY, weights_only=False)
+    c = fx["config"]
+    cfg = OD.OracleTextDecoderConfig(model_dim=c["model_dim"], num_layers=c["num_layers"], num_heads=c["num_heads"],
+                                     ffn_inner_dim=c["ffn_inner_dim"], vocab_size=c["vocab_size"],
+                                     max_seq_len=c["max_seq_len"])
+    params = convert_sonar_text_decoder_checkpoint(fx["checkpoint"])
+    stopped = capped = 0
+    for run in fx["runs"]:
+        hyps = OD.beam_search(params, cfg, fx["embeddings"], run["prompt"], beam_size=1,
+                              min_gen_len=run["min_gen_len"], max_gen_len=(0, run["max_new"]))
+        greedy = OD.greedy_decode(params, cfg, fx["embeddings"], run["prompt"], max_new=run["max_new"])
+        for h, g, want in zip(hyps, greedy, run["generated"]):
+            got = h[0].seq.tolist()                       # generated part only
+            if want[-1] == 3:
+                assert got == want
+                assert len(want) > run["min_gen_len"]
+                stopped += 1
+            else:
+                assert len(want) == run["max_new"] and len(got) == run["max_new"]
+                assert got[:-1] == want[:-1] and got[-1] == 3
+                capped += 1
+            if run["min_gen_len"] == 1:
+                m = len(want) - 1
+                assert g[:m] == want[:m]
+    assert stopped >= 10 and capped >= 10     # the fixture exercises both exits
