@@ -44,6 +44,25 @@ __device__ __forceinline__ f32x4 epi_act(f32x4 v) {
   return v;
 }
 
+// Activation + rounding of 4 accumulator values to fp16.  relu runs on the rounded halves as a packed
+// signed 16-bit integer max with 0 (a negative fp16 is a negative int16): one v_pk_max_i16 per two
+// values instead of the canonicalise + v_max_f32 pair per value that fmaxf compiles to (MFMA results
+// are not known-canonical), and relu(round(x)) == round(relu(x)).
+template <int EPI>
+__device__ __forceinline__ half4 epi_act_pack(f32x4 v) {
+  typedef short short2v __attribute__((ext_vector_type(2)));
+  if constexpr (EPI != EPI_RELU_F16) v = epi_act<EPI>(v);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);  // v_cvt_pk_f16_f32
+  half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
+  if constexpr (EPI == EPI_RELU_F16) {
+    const short2v z = {0, 0};
+    lo = __builtin_bit_cast(half2v, __builtin_elementwise_max(__builtin_bit_cast(short2v, lo), z));
+    hi = __builtin_bit_cast(half2v, __builtin_elementwise_max(__builtin_bit_cast(short2v, hi), z));
+  }
+  return half4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // LAYOUT: 0 = row-major operands and output; 1 = tile-major X and W (common.hpp), row-major
 // output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N).
 template <int EPI, int LAYOUT = 0>
@@ -120,10 +139,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
           } else if constexpr (EPI == EPI_STORE_F32) {
             *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
           } else {
-            v = epi_act<EPI>(v);
-            half4 h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
+            const half4 h = epi_act_pack<EPI>(v);
             if constexpr (LAYOUT == 2)
               *(half4*)((f16*)out + tm_offset(m, n, N)) = h;
             else
@@ -379,11 +395,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           uint32_t h[2][2];
 #pragma unroll
           for (int nl = 0; nl < 2; ++nl) {
-            f32x4 v = acc.v[2 * j + nl][mi];
-            v = epi_act<EPI>(v);
-            const half2v lo = {(f16)v[0], (f16)v[1]}, hh = {(f16)v[2], (f16)v[3]};
-            h[nl][0] = __builtin_bit_cast(uint32_t, lo);
-            h[nl][1] = __builtin_bit_cast(uint32_t, hh);
+            const f32x4 v = acc.v[2 * j + nl][mi];
+            const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(v));
+            h[nl][0] = hp.x;
+            h[nl][1] = hp.y;
           }
           // rows 16..31 / 48..63 of h[0] <-> rows 0..15 / 32..47 of h[1]
           const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
@@ -403,10 +418,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           for (int ni = 0; ni < 4; ++ni) {
             const int mi = 2 * p + mh;
             f32x4 v = acc.v[ni][mi];
-            v = epi_act<EPI>(v);
-            half4 h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (f16)v[e];
+            const half4 h = epi_act_pack<EPI>(v);
             const int lr = lr_w(mi);
             // 16-B chunk (8 columns) of the 256 staged columns: wc*8 + ni*2 + (kg>>1), half kg&1
             *(half4*)(st + lr * 512 + (((wc * 8 + ni * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
