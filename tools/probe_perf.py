@@ -23,6 +23,9 @@ def timeit(fn, iters=10, warmup=3):
 
 
 def main():
+    if os.environ.get("SMI_LIB"):  # a variant build of the library
+        from pathlib import Path
+        _lib.LIB_PATH = Path(os.environ["SMI_LIB"]).resolve()
     lib = _lib.load()
     _lib.check(lib.smi_init(0))
     st = lambda: int(torch.cuda.current_stream().cuda_stream)

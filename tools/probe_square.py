@@ -2,6 +2,9 @@ import sys, os, torch
 sys.path.insert(0, "/root/repo")
 from sonar_amd import _lib
 from tools.probe_perf import timeit
+if os.environ.get("SMI_LIB"):  # a variant build of the library
+    from pathlib import Path
+    _lib.LIB_PATH = Path(os.environ["SMI_LIB"]).resolve()
 lib=_lib.load(); _lib.check(lib.smi_init(0))
 st=lambda:int(torch.cuda.current_stream().cuda_stream)
 for n in (4096, 8192):
