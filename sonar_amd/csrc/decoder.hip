@@ -73,14 +73,33 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   float* xr = x + (size_t)r * D;
-  f32x4 v[NV];
-  float s = 0.f;
+  // The kernel is one dependent chain per wave (loads -> two wave reductions -> store) at ~1 wave per
+  // SIMD, so every load is issued before the first add: x, the constant, then the slabs four at a time.
+  // The summation order (x, slabs ascending, constant) is fixed.
+  f32x4 v[NV], cv[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
-    for (int z = 0; z < nparts; ++z)
-      v[k] += *(const f32x4*)(parts + (size_t)z * part_stride + (size_t)r * D + k * 256 + lane * 4);
-    if (c) v[k] += *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4);
+    cv[k] = c ? *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* pr = parts + (size_t)r * D + lane * 4;
+  for (int z0 = 0; z0 < nparts; z0 += 4) {
+    f32x4 p[4][NV];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        p[j][k] = z0 + j < nparts ? *(const f32x4*)(pr + (size_t)(z0 + j) * part_stride + k * 256)
+                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] += p[j][k];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    v[k] += cv[k];
     *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
@@ -166,7 +185,18 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
       const bool valid = j <= pos;
       const int src = valid ? (j == pos ? r : ar[j]) : 0;
       row[it] = kbase + (size_t)(valid ? j : 0) * slab + (size_t)src * ld;
-      const half8 kk = *(const half8*)row[it];
+    }
+    // all 8 K rows and all 8 V rows (the V row follows its K row at +d) are requested before the
+    // first score is formed: one memory round trip per 64 positions instead of two
+    half8 kr[8], vr[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) kr[it] = *(const half8*)row[it];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) vr[it] = *(const half8*)(row[it] + d);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const bool valid = j0 + it * 8 + pg <= pos;
+      const half8 kk = kr[it];
       float acc = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += q[e] * (float)kk[e];
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
     for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const half8 vv = *(const half8*)(row[it] + d);  // the V row follows the K row at +d
+      const half8 vv = vr[it];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += s[it] * (float)vv[e];
     }
