@@ -209,6 +209,43 @@ int smi_text_decoder_generate(smi_text_decoder* dec, const void* emb, int32_t em
                               const int64_t* prompt, int32_t prompt_len, const smi_beam_search_params* params,
                               int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
 
+/* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
+ * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).
+ * Per step: probs = softmax(logits / temperature) in fp32, pad -> 0, EOS -> 0 before min_seq_len,
+ * EOS forced at max_seq_len - 1; TopKSampler keeps the k most probable tokens, TopPSampler the sorted
+ * prefix whose exclusive cumulative probability stays <= p; one token is drawn from the renormalised
+ * kept set; the step score is log(probs[token]).  The draw is a counter-based hash of
+ * (seed, sentence, step): a call is reproducible, and independent of the batch it runs in. */
+#define SMI_SAMPLER_TOP_K 0
+#define SMI_SAMPLER_TOP_P 1
+typedef struct smi_sampling_params {
+  int32_t sampler;          /* SMI_SAMPLER_TOP_K / SMI_SAMPLER_TOP_P */
+  int32_t top_k;            /* TopKSampler(k), k >= 1 */
+  float top_p;              /* TopPSampler(p), 0 < p <= 1 */
+  float temperature;        /* 1.0 */
+  int32_t max_seq_len;      /* as smi_beam_search_params */
+  int32_t min_seq_len;
+  int32_t normalize_scores; /* 1: score / (len - 1)^len_penalty */
+  float len_penalty;        /* 1.0 */
+  uint64_t seed;
+} smi_sampling_params;
+
+/* Outputs (device): out_tokens int32 [n, max_seq_len] generated tokens after the prompt incl. the final
+ * EOS, -1 padded; out_lens int32 [n]; out_scores fp32 [n].  prompt: HOST int64 [prompt_len]. */
+int smi_text_decoder_sample(smi_text_decoder* dec, const void* emb, int32_t emb_dtype, int32_t n,
+                            const int64_t* prompt, int32_t prompt_len, const smi_sampling_params* params,
+                            int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
+
+/* The filter + draw of one sampling step on given logits (device fp32 [rows, ld], ld % 4 == 0,
+ * ld >= vocab rounded up to 4, vocab <= 2^18), exposed for the parity tests: z device uint64 [rows]
+ * random words (the draw is floor(z * kept_mass / 2^64) into the kept mass); outputs device:
+ * out_token int32 [rows], out_logprob fp32 [rows], and optionally the kept set's size and its mass in
+ * Q40 fixed point relative to exp(max scaled logit). */
+int smi_sample_rows(const float* logits, int64_t ld, int32_t rows, int32_t vocab, int32_t sampler, int32_t top_k,
+                    float top_p, float temperature, int32_t pad_idx, int32_t eos_idx, int32_t block_eos,
+                    const uint64_t* z, int32_t* out_token, float* out_logprob, uint64_t* out_kept_mass,
+                    int32_t* out_kept_count, void* stream);
+
 /* Speech encoder -------------------------------------------------------------------
  * Stands in for: WaveformToFbankConverter(num_mel_bins=80, waveform_scale=2**15,
  * standardize=True) (sonar/inference_pipelines/speech.py:283-290), SonarSpeechEncoderFactory +

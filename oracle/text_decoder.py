@@ -20,7 +20,9 @@ Pinning status:
     (generator tests/golden/make_golden_generate.py); beam_size>1 hypothesis bookkeeping
     (2*beam candidates, length normalisation, forced EOS at the cap) is PARITY UNPINNED
     beyond self-consistency (scores == teacher-forced log-probs, ordering, EOS rules) --
-    HF's beam scorer finalises hypotheses differently and cannot serve as its twin.
+    HF's beam scorer finalises hypotheses differently and cannot serve as its twin;
+  * the sampling generator (second half of this file) restates fairseq2's TopKSampler /
+    TopPSampler / SamplingSeq2SeqGenerator from recall: PARITY UNPINNED.
 """
 from __future__ import annotations
 
@@ -252,3 +254,135 @@ def greedy_decode(params, cfg, embeddings, prompt, max_new: int, eos_idx: int = 
                 break
         outs.append(seq[len(prompt):])
     return outs
+
+
+# ------------------------------------------------------------------------------ sampling
+# fairseq2 ~=0.4 SamplingSeq2SeqGenerator / TopKSampler / TopPSampler (un-vendored; restated from
+# their published behaviour, sonar/inference_pipelines/text.py:315-320 is the call site):
+# PARITY UNPINNED -- no sampling test or fixture exists in the reference, and a sampled sequence
+# depends on the random stream.  What the HIP path is held to: the same kept set as this restatement
+# on the same logits, the same token for the same random word, top_k=1 == greedy, scores == the
+# teacher-forced log-probs of the sampled tokens.
+SAMPLE_THREADS = 1024          # workgroup size of csrc/sampling.hip: fixes the order the draw walks in
+_MASK64 = (1 << 64) - 1
+
+
+def sampling_probs(logits: torch.Tensor, temperature: float = 1.0, pad_idx: int = 0, eos_idx: int = 3,
+                   block_eos: bool = False) -> torch.Tensor:
+    """probs = softmax(logits / T, fp32); pad (and EOS before min_len) zeroed, NOT renormalised."""
+    probs = torch.softmax(logits.float() / temperature, dim=-1, dtype=torch.float32).clone()
+    probs[..., pad_idx] = 0.0
+    if block_eos:
+        probs[..., eos_idx] = 0.0
+    return probs
+
+
+def top_p_mask(probs: torch.Tensor, p: float) -> torch.Tensor:
+    """TopPSampler: sort descending, drop rank r when (cumsum - prob)[r] > p.  [..., V] bool."""
+    sp, idx = torch.sort(probs, dim=-1, descending=True, stable=True)
+    drop = (torch.cumsum(sp, dim=-1) - sp) > p
+    return torch.zeros_like(probs, dtype=torch.bool).scatter(-1, idx, ~drop)
+
+
+def top_k_mask(probs: torch.Tensor, k: int) -> torch.Tensor:
+    """TopKSampler: the k largest (ties: lowest token id first)."""
+    _, idx = torch.sort(probs, dim=-1, descending=True, stable=True)
+    keep = torch.zeros_like(probs, dtype=torch.bool)
+    return keep.scatter(-1, idx[..., : min(k, probs.shape[-1])], True)
+
+
+def sample_filter(logits: torch.Tensor, sampler: Tuple[str, float], temperature: float = 1.0, pad_idx: int = 0,
+                  eos_idx: int = 3, block_eos: bool = False) -> torch.Tensor:
+    """Kept set of one sampling step ([..., V] bool; masked tokens are never kept)."""
+    probs = sampling_probs(logits, temperature, pad_idx, eos_idx, block_eos)
+    if sampler[0] == "top_k":
+        # rank the maskable tokens last even when their zero ties with underflowed probabilities
+        ranked = probs.clone()
+        ranked[..., pad_idx] = -1.0
+        if block_eos:
+            ranked[..., eos_idx] = -1.0
+        keep = top_k_mask(ranked, int(sampler[1]))
+    else:
+        keep = top_p_mask(probs, float(sampler[1]))
+    keep[..., pad_idx] = False
+    if block_eos:
+        keep[..., eos_idx] = False
+    return keep
+
+
+def splitmix_word(seed: int, row: int, step: int) -> int:
+    """The 64-bit random word of (seed, sentence, step) -- csrc/sampling.hip smp_hash."""
+    z = (seed + 0x9E3779B97F4A7C15 * (row * 65536 + step + 1)) & _MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _MASK64
+    return z ^ (z >> 31)
+
+
+def q40_masses(logits: torch.Tensor, temperature: float = 1.0):
+    """Integer token masses floor(exp(l/T - max) * 2^40) of one row (numpy uint64) and the max."""
+    import numpy as np
+
+    t = (logits.float() * np.float32(1.0 / temperature)).numpy().astype(np.float32)
+    m = t.max()
+    e = np.exp2(((t - m) * np.float32(1.4426950408889634)).astype(np.float32)).astype(np.float32)
+    return (e * np.float32(2.0 ** 40)).astype(np.uint64), float(m)
+
+
+def sample_draw(masses, keep, z: int) -> Tuple[int, float]:
+    """Token whose span of the kept integer mass holds floor(z * kept / 2^64), walking the vocabulary
+    in the device's order: thread t of 1024 owns the 4-token groups g = i * 1024 + t, i = 0, 1, ...
+    Returns (token, distance of the target to the nearest span boundary / kept mass)."""
+    import numpy as np
+
+    v = masses.shape[0]
+    idx = np.arange(v)
+    g = idx // 4
+    order = np.lexsort((idx % 4, g // SAMPLE_THREADS, g % SAMPLE_THREADS))   # thread, iteration, lane-element
+    w = np.where(keep[order], masses[order], 0).astype(object)
+    csum = np.cumsum(w)
+    kept = int(csum[-1])
+    target = (z * kept) >> 64
+    pos = int(np.searchsorted(np.array(csum, dtype=object), target, side="right"))
+    lo = int(csum[pos - 1]) if pos else 0
+    margin = min(target - lo, int(csum[pos]) - 1 - target) / max(kept, 1)
+    return int(order[pos]), margin
+
+
+@torch.inference_mode()
+def sampling_generate(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, prompt: Sequence[int],
+                      sampler: Tuple[str, float], seed: int, min_gen_len: int = 1,
+                      max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
+                      normalize_scores: bool = True, len_penalty: float = 1.0, temperature: float = 1.0,
+                      pad_idx: int = 0, eos_idx: int = 3, row_offset: int = 0):
+    """SamplingSeq2SeqGenerator, one hypothesis per embedding; sampler = ("top_k", k) | ("top_p", p).
+    Returns [(tokens after the prompt, score, step log-probs)] per embedding."""
+    model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
+    plen = len(prompt)
+    max_len = min(plen + int(max_gen_len[0] + max_gen_len[1]), model_max)
+    min_len = min(plen + min_gen_len, max_len)
+    out = []
+    for r, e in enumerate(embeddings):
+        seq, cum, steps = list(prompt), 0.0, []
+        if plen > 1:
+            lp = torch.log_softmax(decoder_logits(params, cfg, e.unsqueeze(0), torch.tensor([seq[:-1]])) / temperature,
+                                   dim=-1, dtype=torch.float32)
+            cum = float(lp[0, torch.arange(plen - 1), torch.tensor(seq[1:])].sum())
+        step_nr = plen
+        while True:
+            logits = decoder_logits(params, cfg, e.unsqueeze(0), torch.tensor([seq]))[0, -1]
+            lprobs = torch.log_softmax(logits.float() / temperature, dim=-1, dtype=torch.float32)
+            if step_nr == max_len - 1:
+                tok = eos_idx
+            else:
+                keep = sample_filter(logits, sampler, temperature, pad_idx, eos_idx, block_eos=step_nr < min_len)
+                masses, _ = q40_masses(logits, temperature)
+                tok, _ = sample_draw(masses, keep.numpy(), splitmix_word(seed, row_offset + r, step_nr))
+            seq.append(tok)
+            cum += float(lprobs[tok])
+            steps.append(float(lprobs[tok]))
+            step_nr += 1
+            if tok == eos_idx:
+                break
+        score = cum / (step_nr - 1) ** len_penalty if normalize_scores else cum
+        out.append((seq[plen:], score, steps))
+    return out

@@ -136,6 +136,23 @@ class smi_beam_search_params(C.Structure):
     ]
 
 
+SMI_SAMPLER_TOP_K, SMI_SAMPLER_TOP_P = 0, 1
+
+
+class smi_sampling_params(C.Structure):
+    _fields_ = [
+        ("sampler", C.c_int32),
+        ("top_k", C.c_int32),
+        ("top_p", C.c_float),
+        ("temperature", C.c_float),
+        ("max_seq_len", C.c_int32),
+        ("min_seq_len", C.c_int32),
+        ("normalize_scores", C.c_int32),
+        ("len_penalty", C.c_float),
+        ("seed", C.c_uint64),
+    ]
+
+
 class smi_speech_encoder_config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model_dim", "num_layers", "num_heads", "ffn_inner_dim", "conv_kernel", "num_mel_bins",
@@ -205,6 +222,10 @@ SYMBOLS = {
     "smi_text_decoder_logits": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "smi_text_decoder_generate": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                             C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
+    "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
+                                          C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
+    "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp,
+                                  _vp, _vp, _vp]),
     "smi_speech_encoder_create": (C.c_int, [C.POINTER(smi_speech_encoder_config),
                                             C.POINTER(smi_speech_encoder_weights), C.POINTER(_vp)]),
     "smi_speech_encoder_destroy": (None, [_vp]),

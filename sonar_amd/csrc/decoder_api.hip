@@ -369,4 +369,87 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   return SMI_OK;
 }
 
+int smi_text_decoder_sample(smi_text_decoder* D, const void* emb, int32_t emb_dtype, int32_t n,
+                            const int64_t* prompt, int32_t prompt_len, const smi_sampling_params* sp,
+                            int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream_v) {
+  if (!D || !emb || !prompt || !sp || !out_tokens || !out_lens || !out_scores)
+    return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || prompt_len <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (emb_dtype != SMI_F32 && emb_dtype != SMI_F16) return fail(SMI_ERR_INVALID_ARG, "bad emb dtype");
+  const smi_text_decoder_config& c = D->cfg;
+  if (sp->sampler == SMI_SAMPLER_TOP_K) {
+    if (sp->top_k < 1) return fail(SMI_ERR_INVALID_ARG, "top_k must be >= 1");
+  } else if (sp->sampler == SMI_SAMPLER_TOP_P) {
+    if (!(sp->top_p > 0.f && sp->top_p <= 1.f)) return fail(SMI_ERR_INVALID_ARG, "top_p must be in (0, 1]");
+  } else {
+    return fail(SMI_ERR_INVALID_ARG, "unknown sampler %d", sp->sampler);
+  }
+  if (c.vocab_size > (1 << 18))
+    return fail(SMI_ERR_UNSUPPORTED, "vocab %d: sampling covers up to 2^18 tokens", (int)c.vocab_size);
+  const int max_len = sp->max_seq_len, min_len = sp->min_seq_len;
+  if (max_len > c.max_seq_len || max_len <= prompt_len)
+    return fail(SMI_ERR_INVALID_ARG, "max_seq_len %d must be in (prompt_len %d, model max %d]", max_len, prompt_len,
+                c.max_seq_len);
+  if (!(sp->temperature > 0.f)) return fail(SMI_ERR_INVALID_ARG, "temperature must be positive");
+  for (int i = 0; i < prompt_len; ++i)
+    if (prompt[i] < 0 || prompt[i] >= c.vocab_size) return fail(SMI_ERR_INVALID_ARG, "prompt token out of range");
+  hipStream_t stream = (hipStream_t)stream_v;
+
+  // one hypothesis per sentence (fairseq2 num_gens = 1): rows = sentences, identity ancestry
+  const int rows_pad = (int)round_up(n, 256), n_pad = rows_pad;
+  const int stride = c.max_seq_len + 1;
+  if (int rc = ensure_step_workspace(D, rows_pad, max_len)) return rc;
+  HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
+  HIP_TRY(D->cum.reserve((size_t)n * 4));
+  HIP_TRY(D->done.reserve((size_t)n * 4));
+  HIP_TRY(D->ndone.reserve(4));
+  HIP_TRY(D->new_tok.reserve((size_t)n * 4));
+  HIP_TRY(D->new_cum.reserve((size_t)n * 4));
+  HIP_TRY(D->anc[0].reserve((size_t)rows_pad * stride * 4));
+  {
+    std::vector<int32_t> ident((size_t)n * stride), first((size_t)n, (int32_t)prompt[0]);
+    for (int r = 0; r < n; ++r)
+      for (int j = 0; j < stride; ++j) ident[(size_t)r * stride + j] = r;
+    HIP_TRY(hipMemcpyAsync(D->anc[0].p, ident.data(), ident.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(D->tok.p, first.data(), first.size() * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  HIP_TRY(hipMemsetAsync(D->cum.p, 0, (size_t)n * 4, stream));
+  HIP_TRY(hipMemsetAsync(D->done.p, 0, (size_t)n * 4, stream));
+  HIP_TRY(hipMemsetAsync(D->ndone.p, 0, 4, stream));
+  HIP_TRY(hipMemsetAsync(out_tokens, 0xff, (size_t)n * max_len * 4, stream));
+  HIP_TRY(hipMemsetAsync(out_lens, 0, (size_t)n * 4, stream));
+  HIP_TRY(hipMemsetAsync(out_scores, 0, (size_t)n * 4, stream));
+  if (int rc = compute_cross_constants(D, emb, emb_dtype, n, n_pad, stream)) return rc;
+
+  for (int pos = 0; pos + 1 < max_len; ++pos) {
+    const int step_nr = pos + 1;
+    if (int rc = decoder_step(D, n, rows_pad, 1, n_pad, pos, D->anc[0].as<int32_t>(), stride, stream)) return rc;
+    const bool forced_prompt = step_nr < prompt_len;
+    const bool force_eos = !forced_prompt && step_nr == max_len - 1;
+    SampleRowsArgs a{};
+    a.logits = D->logits.as<float>(); a.ld = D->vocab_pad; a.rows = n; a.vocab = (int)c.vocab_size;
+    a.inv_temp = 1.0f / sp->temperature; a.pad_idx = c.pad_idx; a.eos_idx = c.eos_idx;
+    a.block_eos = !forced_prompt && !force_eos && step_nr < min_len;
+    a.forced_tok = forced_prompt ? (int)prompt[step_nr] : (force_eos ? c.eos_idx : -1);
+    a.mode = sp->sampler; a.top_k = sp->top_k; a.top_p = sp->top_p; a.z = nullptr; a.seed = sp->seed; a.step = step_nr;
+    a.done = D->done.as<int32_t>(); a.out_tok = D->new_tok.as<int32_t>(); a.out_logp = D->new_cum.as<float>();
+    HIP_TRY(launch_sample_rows(a, stream));
+    SampleUpdateArgs u{};
+    u.samp_tok = D->new_tok.as<int32_t>(); u.samp_logp = D->new_cum.as<float>(); u.tok = D->tok.as<int32_t>();
+    u.cum = D->cum.as<float>(); u.done = D->done.as<int32_t>(); u.ndone = D->ndone.as<int32_t>();
+    u.out_tokens = out_tokens; u.out_lens = out_lens; u.out_scores = out_scores; u.n = n; u.out_stride = max_len;
+    u.pos = pos; u.prompt_len = prompt_len; u.eos_idx = c.eos_idx; u.normalize = sp->normalize_scores;
+    u.len_penalty = sp->len_penalty;
+    HIP_TRY(launch_sample_update(u, stream));
+    if ((step_nr & 7) == 0 && !force_eos) {
+      int32_t nd = 0;
+      HIP_TRY(hipMemcpyAsync(&nd, D->ndone.p, 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (nd >= n) break;
+    }
+  }
+  return SMI_OK;
+}
+
 }  // extern "C"

@@ -141,4 +141,41 @@ hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu,
                                  hipStream_t stream);
 hipError_t launch_broadcast_row(const float* row, float* x, int rows, int d, hipStream_t stream);
 
+
+// ---- sampling generation (sampling.hip)
+struct SampleRowsArgs {
+  const float* logits;
+  int64_t ld;
+  int rows, vocab;
+  float inv_temp;
+  int pad_idx, eos_idx, block_eos;
+  int forced_tok;  // >= 0: no draw, the token is given (prompt forcing, forced EOS)
+  int mode, top_k;
+  float top_p;
+  const unsigned long long* z;          // [rows] random words, or null: hash(seed, row, step)
+  unsigned long long seed;
+  int step;
+  const int32_t* done;   // [rows] rows to skip, may be null
+  int32_t* out_tok;
+  float* out_logp;
+  unsigned long long* out_kept_mass;    // optional
+  int32_t* out_kept_count;
+};
+
+struct SampleUpdateArgs {
+  const int32_t* samp_tok;
+  const float* samp_logp;
+  int32_t* tok;   // next step's input token
+  float* cum;
+  int32_t* done;
+  int32_t* ndone;
+  int32_t* out_tokens;
+  int32_t* out_lens;
+  float* out_scores;
+  int n, out_stride, pos, prompt_len, eos_idx, normalize;
+  float len_penalty;
+};
+hipError_t launch_sample_rows(const SampleRowsArgs& a, hipStream_t stream);
+hipError_t launch_sample_update(const SampleUpdateArgs& a, hipStream_t stream);
+
 }  // namespace smi

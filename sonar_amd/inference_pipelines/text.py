@@ -234,8 +234,6 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
     @torch.inference_mode()
     def predict(self, inputs: torch.Tensor, target_lang: str, batch_size: int = 5, progress_bar: bool = False,
                 sampler=None, **generator_kwargs) -> List[str]:
-        if sampler is not None:
-            raise NotImplementedError("sampling generators are not covered by the MI355X engine (beam search only)")
         if batch_size <= 0:
             raise ValueError("`batch_size` should be strictly positive")
         prompt = self.tokenizer.create_encoder(task="translation", lang=target_lang, mode="target").prefix
@@ -247,10 +245,15 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
         texts: List[str] = []
         for chunk in batches:
             emb = torch.stack(chunk).to(self.device)
-            toks, lens, _ = self.model.engine.generate(emb, prompt, **generator_kwargs)
-            toks, lens = toks.cpu(), lens.cpu()
+            if sampler is None:   # text.py:315-320: beam search by default, a sampling generator otherwise
+                toks, lens, _ = self.model.engine.generate(emb, prompt, **generator_kwargs)
+                toks, lens = toks[:, 0].cpu(), lens[:, 0].cpu()
+            else:
+                toks, lens, _ = self.model.engine.sample(emb, prompt, sampler, sentence_offset=len(texts),
+                                                         **generator_kwargs)
+                toks, lens = toks.cpu(), lens.cpu()
             for i in range(emb.shape[0]):
-                texts.append(decode(toks[i, 0, : int(lens[i, 0])]))
+                texts.append(decode(toks[i, : int(lens[i])]))
         return texts
 
 

@@ -259,6 +259,46 @@ class TextDecoderEngine:
                 _lib.current_stream_ptr()))
         return toks, lens, scores
 
+    def sample(self, embeddings: torch.Tensor, prompt: Sequence[int], sampler, min_gen_len: int = 1,
+               max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
+               normalize_scores: bool = True, len_penalty: float = 1.0, unk_penalty: float = 0.0,
+               temperature: float = 1.0, seed: Optional[int] = None, sentence_offset: int = 0):
+        """fairseq2's SamplingSeq2SeqGenerator (one hypothesis per sentence) with a TopKSampler /
+        TopPSampler (sonar_amd.generation).  Returns (tokens int32 [n, L] (-1 padded), lens int32 [n],
+        scores fp32 [n]).  `seed` None draws one from torch's global CPU generator, so
+        `torch.manual_seed` makes a run repeatable as it does for the reference; the random stream of a
+        sentence depends on (seed, sentence_offset + its index, step) only, not on the batch."""
+        from .generation import resolve_sampler
+
+        kind, k, p = resolve_sampler(sampler)
+        if unk_penalty != 0.0:
+            raise NotImplementedError("unk_penalty is not covered by the sampling path of the MI355X engine")
+        e = self._emb(embeddings)
+        n = e.shape[0]
+        plen = len(prompt)
+        model_max = max_seq_len if max_seq_len is not None else self.cfg.max_seq_len
+        if model_max > self.cfg.max_seq_len:
+            raise ValueError(f"max_seq_len cannot be larger than the decoder's {self.cfg.max_seq_len}")
+        gen_cap = int(max_gen_len[0] * 1 + max_gen_len[1])
+        max_len = min(plen + gen_cap, model_max)
+        min_len = min(plen + min_gen_len, max_len)
+        if seed is None:
+            seed = int(torch.randint(0, 2**62, (1,)).item())
+        seed = (int(seed) + 0x9E3779B97F4A7C15 * 65536 * int(sentence_offset)) & 0xFFFFFFFFFFFFFFFF
+        sp = _lib.smi_sampling_params(sampler=kind, top_k=k, top_p=p, temperature=temperature, max_seq_len=max_len,
+                                      min_seq_len=min_len, normalize_scores=1 if normalize_scores else 0,
+                                      len_penalty=len_penalty, seed=seed)
+        toks = torch.empty((n, max_len), dtype=torch.int32, device=self.device)
+        lens = torch.empty((n,), dtype=torch.int32, device=self.device)
+        scores = torch.empty((n,), dtype=torch.float32, device=self.device)
+        prompt_arr = (C.c_int64 * plen)(*[int(t) for t in prompt])
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_decoder_sample(
+                self._handle, e.data_ptr(), _lib.SMI_F32 if e.dtype == torch.float32 else _lib.SMI_F16, n,
+                prompt_arr, plen, C.byref(sp), toks.data_ptr(), lens.data_ptr(), scores.data_ptr(),
+                _lib.current_stream_ptr()))
+        return toks, lens, scores
+
 
 class ConditionalTransformerDecoderModel:
     """Drop-in for the object `EmbeddingToTextModelPipeline` receives as `decoder`

@@ -147,6 +147,15 @@ def test_embedding_to_text_pipeline(setup, tmp_path):
     assert same >= 5
     with pytest.raises(NotImplementedError):
         pipe.predict(emb, target_lang="fra_Latn", sampler=object())
+    # a sampler switches predict() to the sampling generator (text.py:315-320); torch's global seed
+    # makes it repeatable as it does for the reference
+    from sonar_amd.generation import TopPSampler
+
+    torch.manual_seed(4)
+    s1 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8), sampler=TopPSampler(0.9))
+    torch.manual_seed(4)
+    s2 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8), sampler=TopPSampler(0.9))
+    assert s1 == s2 and len(s1) == 6 and all(isinstance(t, str) for t in s1)
 
 
 def test_text_to_text_and_speech_to_text_chain(setup, tmp_path):

@@ -25,6 +25,16 @@ def main():
         torch.cuda.synchronize()
         dt = time.time() - t0
         print(f"  rep {rep}: {dt*1e3:.1f} ms")
+    if len(sys.argv) > 3 and sys.argv[3] == "sample":   # the sampling generator on the same shapes
+        from sonar_amd.generation import TopKSampler, TopPSampler
+        for smp in (TopPSampler(0.9), TopKSampler(50)):
+            for rep in range(2):
+                t0 = time.time()
+                st, sl, _ = eng.sample(emb, [3, 256047], smp, seed=1, min_gen_len=steps, max_gen_len=(0, steps))
+                torch.cuda.synchronize()
+                dts = time.time() - t0
+            print(f"sampling {smp}: n={n} steps={steps + 1}: {dts*1e3:.1f} ms  {dts/(steps + 1)*1e3:.2f} ms/step  "
+                  f"{n/dts:.1f} sentences/s")
     nsteps = steps + 1
     flops = n * 5 * nsteps * (24 * (16 * d * d + 4 * d * f) / 2 * 1 + 2 * d * V)  # self-attn qkv+out (8d^2) + ffn + logits
     print(f"decoder n={n} beam=5 steps={nsteps}: {dt*1e3:.1f} ms  {dt/nsteps*1e3:.2f} ms/step  {n/dt:.1f} sentences/s  lens {lens[0].tolist()}")
