@@ -331,6 +331,26 @@ hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2
 // pad and is read back at row (ii - jj + 31), column ii -- bank = ii, conflict-free both ways.
 constexpr int RA_QB = 128, RA_KB = 32;
 
+// K and V blocks (32 keys x 128 B each) go global -> LDS by DMA, double-buffered: the block of the next
+// iteration is in flight while this one is consumed, one barrier per block, no staging registers.
+//  * both are ROW-major [key][128 B]; 16-B chunk c of key r sits at slot c ^ swz(r).  K: swz = (r>>1)&7
+//    (conflict-free ds_read_b128 of the S^T = K (Q+u)^T A fragments).  V: swz = ((r>>1)&1)<<2, read with
+//    ds_read_b64_tr_b16: a 16-lane group fetches a [4 keys][16 dims] block and every lane receives the 4
+//    keys of ITS dim -- the V^T fragment of O^T += V^T P^T without a transposed copy (the swizzle puts
+//    keys r, r+2 of a group in different halves of the 128-B row: 4 rows x 64 B = all 64 banks).
+//  * a DMA instruction writes wave-base + lane*16: thread -> (key = tid>>3, slot = tid&7) fetches the
+//    chunk that belongs in that slot.
+// The transpose reads are inline asm: for the builtin, hipcc's LDS-DMA alias tracking puts
+// `s_waitcnt vmcnt(0)` in front of the first read while the NEXT block's DMA is in flight (it cannot see
+// that the DMA targets the other buffer), which would expose that latency in every iteration.  The asm
+// results are waited for explicitly (lgkmcnt(0)) before the MFMAs read them.
+template <int OFF>
+__device__ __forceinline__ half4 ra_tr_read(unsigned lds_addr) {
+  half4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __restrict__ qkv,
                                                                const int32_t* __restrict__ cu,
                                                                const f16* __restrict__ rp, int rp_zero,
@@ -338,16 +358,15 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
                                                                const float* __restrict__ u_bias,
                                                                const float* __restrict__ v_bias,
                                                                f16* __restrict__ ctx, int d, float sl2e) {
-  __shared__ __attribute__((aligned(16))) char lds[RA_KB * 128 + 64 * 64 + 4 * 64 * 32 * 4];
-  char* Ks = lds;                       // [32 keys][128 B], chunk c of key r at slot c ^ ((r>>1)&7)
-  char* Vt = lds + RA_KB * 128;         // [64 dims][64 B], 8-B key granule g of dim r at g ^ ((r>>2)&7)
+  constexpr int BLK = RA_KB * 128;  // 4 KiB
+  __shared__ __attribute__((aligned(16))) char lds[4 * BLK + 4 * 64 * 32 * 4];
   const int n = blockIdx.x, h = blockIdx.y;
   const int start = cu[n], len = cu[n + 1] - start;
   const int q0 = blockIdx.z * RA_QB;
   if (q0 >= len) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  float* Gs = (float*)(lds + RA_KB * 128 + 64 * 64) + wave * 64 * 32;  // [64 rho][32 queries]
+  float* Gs = (float*)(lds + 4 * BLK) + wave * 64 * 32;  // [64 rho][32 queries]
   const size_t ld = (size_t)3 * d;
   const f16* qbase = qkv + (size_t)start * ld + h * 64;
   const f16* kbase = qbase + d;
@@ -369,6 +388,20 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
     }
   }
 
+  // DMA sources of this thread: key tid>>3 of a block, the chunk that lands in slot tid&7
+  const int skey = tid >> 3, sslot = tid & 7;
+  const int kchunk = sslot ^ ((skey >> 1) & 7), vchunk = sslot ^ (((skey >> 1) & 1) << 2);
+  auto stage = [&](int j0, int buf) {
+    const int row = min(j0 + skey, len - 1);
+    glds16(kbase + (size_t)row * ld + kchunk * 8, lds + buf * 2 * BLK + wave * 1024);
+    glds16(vbase + (size_t)row * ld + vchunk * 8, lds + buf * 2 * BLK + BLK + wave * 1024);
+  };
+  // position rows of a key block: rp[rel_lo + 32 gb + l31], rel_lo = i0 - j0 - 31
+  auto rp_row = [&](int j0, int gb) {
+    const int row = min(max(i0 - j0 - 31 + gb * 32 + l31 + rp_zero, 0), rp_rows - 1);
+    return rph + (size_t)row * d;
+  };
+
   float m = -1e30f, lsum = 0.f;
   f32x16 o[2];
 #pragma unroll
@@ -376,26 +409,39 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 
-  for (int j0 = 0; j0 < len; j0 += RA_KB) {
-    __syncthreads();
-    {  // stage K (row-major, swizzled): 32 keys x 8 chunks = 256 chunks, one per thread
-      const int key = tid >> 3, slot = tid & 7;
-      const int chunk = slot ^ ((key >> 1) & 7);
-      const int krow = min(j0 + key, len - 1);
-      *(half8*)(Ks + tid * 16) = *(const half8*)(kbase + (size_t)krow * ld + chunk * 8);
-    }
-    {  // stage V transposed: thread -> key = tid & 31, dim chunk = tid >> 5
-      const int key = tid & 31, dc = tid >> 5;
-      const int vrow = min(j0 + key, len - 1);
-      const half8 v = *(const half8*)(vbase + (size_t)vrow * ld + dc * 8);
-      const int kg = key >> 2, kw = (key & 3) * 2;
+  // V^T fragments: lane p of a 16-lane group feeds row (p>>2) of its [4 keys][16 dims] block and gets
+  // the 4 keys of dim p; block of MFMA (db, u), half `part`: keys 16u + 4hi + 8 part + (0..3), dims
+  // 32 db + 16 (l31>>4) + (0..15).  16u + 8 part never changes the swizzle bit: immediate offsets.
+  unsigned vaddr[2];
+  {
+    const int p16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int key = 4 * hi + (p16 >> 2);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int dd = dc * 8 + e;
-        *(f16*)(Vt + dd * 64 + ((kg ^ ((dd >> 2) & 7)) << 3) + kw) = v[e];
-      }
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + g16 * 2 + ((p16 & 3) >> 1);
+      vaddr[db] = (unsigned)(size_t)(lds + BLK + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
     }
-    __syncthreads();
+  }
+  // pad read offsets (bytes from Gs) for an EVEN key block: rho = l31 - jj + 31, half 0 = this block's
+  // rows, half 1 (+4 KiB) = the previous block's; an odd block swaps the halves: offset ^ 4096
+  int gread[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rho = l31 - ((r & 3) + 8 * (r >> 2) + 4 * hi) + 31;  // 0..62
+    gread[r] = ((rho < 32 ? 0 : 32 * 32) + (rho & 31) * 32 + l31) * 4;
+  }
+  stage(0, 0);
+  half8 rf[4];  // the position rows of the NEXT block travel through the softmax / PV half of this one
+  {
+    const f16* rrow = rp_row(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rf[ks] = *(const half8*)(rrow + (ks * 2 + hi) * 8);
+  }
+
+  for (int j0 = 0, kb = 0; j0 < len; j0 += RA_KB, ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // block kb has landed for everyone; everyone is done with the other buffer
+    const char* Ks = lds + (kb & 1) * 2 * BLK;
 
     // ---- content term: S^T = K . (Q+u)^T ----
     f32x16 s;
@@ -409,79 +455,107 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
     // ---- position term: G[rho][i] = rp[rel_lo + rho] . (q_i + v), rho = 0..63 ----
     // rel_lo drops by 32 per key block, so rows 32..63 of this block are rows 0..31 of the previous
     // one: the pad is two 32-row halves used alternately, and only the first key block computes both.
-    const int rel_lo = i0 - j0 - 31;
-    const int kb = j0 / RA_KB;
     float* Gnew = Gs + (kb & 1) * 32 * 32;        // rho 0..31 of this block
     float* Gold = Gs + ((kb + 1) & 1) * 32 * 32;  // rho 32..63 = the previous block's rho 0..31
-#pragma unroll
-    for (int gb = 0; gb < 2; ++gb) {
-      if (gb == 1 && kb > 0) break;
+    {
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
-      const int row = min(max(rel_lo + gb * 32 + l31 + rp_zero, 0), rp_rows - 1);
-      const f16* rrow = rph + (size_t)row * d;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf[ks], qv[ks], g, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Gnew[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
+    }
+    if (kb == 0) {
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+      const f16* rrow = rp_row(0, 1);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const half8 rf = *(const half8*)(rrow + (ks * 2 + hi) * 8);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf, qv[ks], g, 0, 0, 0);
+        const half8 r1 = *(const half8*)(rrow + (ks * 2 + hi) * 8);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, qv[ks], g, 0, 0, 0);
       }
-      float* Gw = gb ? Gold : Gnew;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        Gw[rho * 32 + l31] = g[r];
-      }
+      for (int r = 0; r < 16; ++r) Gold[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
+    }
+    // next block: K / V by DMA into the other buffer, its position rows into rf
+    if (j0 + RA_KB < len) {
+      stage(j0 + RA_KB, (kb + 1) & 1);
+      const f16* rrow = rp_row(j0 + RA_KB, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) rf[ks] = *(const half8*)(rrow + (ks * 2 + hi) * 8);
     }
     // (each wave reads back only what it wrote: no workgroup barrier needed, only LDS ordering)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    float mx = -INFINITY;
+    // the 16 pad reads are issued back to back and waited for once (left to itself hipcc sinks each
+    // read into the branch of its `< len` mask: 16 exec-masked blocks, each with its own LDS wait)
+    float bd[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const int rho = l31 - jj + 31;  // 0..62
-      const float bd = (rho < 32 ? Gnew : Gold)[(rho & 31) * 32 + l31];
-      const float val = (j0 + jj) < len ? (s[r] + bd) * sl2e : -INFINITY;
-      s[r] = val;
-      mx = fmaxf(mx, val);
+    for (int r = 0; r < 16; ++r) bd[r] = *(const float*)((const char*)Gs + (gread[r] ^ ((kb & 1) << 12)));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bd[r]));
+    // x = content + position (unscaled); only the last key block of a clip has keys to mask
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += bd[r];
+    if (j0 + RA_KB > len) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= len) s[r] = -INFINITY;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    m = m_new;
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;  // sl2e > 0: the scaled maximum
+    // Lazy rescale: the running reference m only moves when some query's block maximum exceeds it by
+    // more than 2^8; until then p = exp2(x - m) <= 256 (exact in fp32, in range for the fp16 P operand)
+    // and the 32 output accumulators, which live in AGPRs, are left alone.
+    if (__any(mx > m + 8.0f)) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     float psum = 0.f;
     half8 pf[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+      const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2e, -m));
       psum += p;
       pf[r >> 3][r & 7] = (f16)p;
     }
-    lsum = lsum * alpha + psum;
+    lsum += psum;
+    // ---- O^T += V^T . P^T ----  k slot e of MFMA u <-> key 16u + 4hi + 8(e>>2) + (e&3) (the S^T layout)
+    half4 va[2][2][2];  // [db][u][part]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const unsigned a = vaddr[db] + (kb & 1) * 2 * BLK;
+      va[db][0][0] = ra_tr_read<0>(a);
+      va[db][0][1] = ra_tr_read<1024>(a);
+      va[db][1][0] = ra_tr_read<2048>(a);
+      va[db][1][1] = ra_tr_read<3072>(a);
+    }
+    // the wait carries the 8 results as operands: the MFMAs below depend on IT, not just on the reads
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]), "+v"(va[1][0][0]),
+                   "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1])
+                 :
+                 : "memory");
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    // ---- O^T += V^T . P^T ----
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const int dd = db * 32 + l31;
-      const char* vrow = Vt + dd * 64;
-      const int sw = (dd >> 2) & 7;
-#pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int g0 = 4 * u + hi;
-        const half4 a0 = *(const half4*)(vrow + ((g0 ^ sw) << 3));
-        const half4 a1 = *(const half4*)(vrow + (((g0 + 2) ^ sw) << 3));
         half8 vf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          vf[e] = a0[e];
-          vf[e + 4] = a1[e];
+          vf[e] = va[db][u][0][e];
+          vf[4 + e] = va[db][u][1][e];
         }
         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
       }
-    }
   }
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = 1.0f / ltot;
