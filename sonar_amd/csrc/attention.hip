@@ -12,8 +12,8 @@
 // O^T = V^T.P^T -- the 16-wide MFMA K-slot order is a free permutation as long
 // as V^T is fetched in the same order, so P never moves between lanes or
 // through LDS.  K is staged row-major with the 16-B XOR swizzle (conflict-free
-// ds_read_b128), V is staged transposed with an 8-B granule swizzle
-// (conflict-free ds_read_b64 / ds_write_b16).  S <= 514 in SONAR, so the
+// ds_read_b128), V row-major too and read through the LDS transpose read
+// (ds_read_b64_tr_b16); both arrive by double-buffered global->LDS DMA.  S <= 514 in SONAR, so the
 // kernel is HBM-bound (~64 flop/B); the score matrix never leaves registers.
 #include "common.hpp"
 #include "kernels.hpp"
@@ -23,17 +23,33 @@ namespace smi {
 constexpr int AT_QB = 128;  // queries per workgroup
 constexpr int AT_KB = 64;   // keys per K/V tile
 
+// ds_read_b64_tr_b16 as inline asm (see speech.hip: for the builtin hipcc's LDS-DMA alias tracking waits
+// for the next tile's DMA in front of the first read); results are waited for with an lgkmcnt(0) that
+// carries them as operands.
+template <int OFF>
+__device__ __forceinline__ half4 at_tr_read(unsigned lds_addr) {
+  half4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+  return v;
+}
+
 // TM: ctx is written in the tile-major GEMM operand layout (common.hpp) -- a wave then stores
 // 2 KiB runs (32 rows x 64 B of one k-block) instead of 8-B pieces one row stride apart.
 // QTM: qkv is READ tile-major ([T, 3d] as K = 3d blocks, the QKV GEMM's register-direct output):
 // the 64-key x 64-B halves of a K or V tile are then contiguous 4 KiB runs.
+//
+// K and V tiles (64 keys x 128 B) go global -> LDS by DMA into two buffers: tile t+1 is in flight while
+// tile t is consumed, one barrier per tile, no staging registers.  Both are row-major [key][128 B] with
+// 16-B chunk c of key r at slot c ^ swz(r): K swz = (r>>1)&7 (conflict-free ds_read_b128 of the K
+// fragments), V swz = ((r>>1)&1)<<2, read with ds_read_b64_tr_b16 -- a 16-lane group fetches a
+// [4 keys][16 dims] block and every lane receives the 4 keys of its dim, i.e. the V^T fragment without
+// a transposed copy (keys r, r+2 of a group sit in different halves of the 128-B row: all 64 banks).
 template <bool TM, bool QTM>
 __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         f16* __restrict__ ctx, int d, float sl2e) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * AT_KB * 128];
-  char* Ks = lds;                // [64 keys][128 B], 16-B chunk c of key r at slot c ^ ((r>>1)&7)
-  char* Vt = lds + AT_KB * 128;  // [64 dims][128 B], 8-B key granule g of dim r at slot g ^ ((r>>1)&15)
+  constexpr int TILE = AT_KB * 128;  // 8 KiB
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE];  // [buffer][K | V]
 
   const int n = blockIdx.x, h = blockIdx.y;
   const int start = cu[n];
@@ -56,41 +72,47 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)at(min(qi, len - 1), h * 64 + (ks * 2 + hi) * 8);
 
-  float m = -1e30f, lsum = 0.f;
+  // DMA: instruction x of wave w fills LDS bytes [x*4096 + w*1024, +1024) of a tile: thread ->
+  // (key = c>>3, slot = c&7), c = x*256 + tid, fetches the chunk that belongs in that slot
+  auto stage = [&](int kv0, int buf) {
+    char* kt = lds + buf * 2 * TILE;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int c = tid + 256 * x;
+      const int key = c >> 3, slot = c & 7;
+      const int row = min(kv0 + key, len - 1);
+      glds16(at(row, d + h * 64 + (slot ^ ((key >> 1) & 7)) * 8), kt + x * 4096 + wave * 1024);
+      glds16(at(row, 2 * d + h * 64 + (slot ^ (((key >> 1) & 1) << 2)) * 8), kt + TILE + x * 4096 + wave * 1024);
+    }
+  };
+  // V^T fragments: lane p of a 16-lane group feeds row (p>>2) of its [4 keys][16 dims] block and gets
+  // the 4 keys of dim p.  MFMA (db, kb, u), half `part`: keys 32 kb + 16 u + 4 hi + 8 part + (0..3),
+  // dims 32 db + 16 (l31>>4) + (0..15); 32 kb + 16 u + 8 part never changes the swizzle bit, so it is
+  // an immediate offset.  (k slot e of the MFMA <-> key 16u + 4hi + 8(e>>2) + (e&3): the S^T layout.)
+  unsigned vaddr[2];
+  {
+    const int p16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int key = 4 * hi + (p16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + g16 * 2 + ((p16 & 3) >> 1);
+      vaddr[db] = (unsigned)(size_t)(lds + TILE + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
+    }
+  }
+
+  float m = -1e30f, lsum = 0.f;  // m: running reference of the SCALED scores (log2 domain)
   f32x16 o[2];
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
 
-  for (int kv0 = 0; kv0 < len; kv0 += AT_KB) {
-    __syncthreads();
-    // ---- stage K (row-major, swizzled) ----
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const int c = tid + 256 * x;
-      const int key = c >> 3, slot = c & 7;
-      const int chunk = slot ^ ((key >> 1) & 7);
-      const int krow = min(kv0 + key, len - 1);
-      *(half8*)(Ks + c * 16) = *(const half8*)at(krow, d + h * 64 + chunk * 8);
-    }
-    // ---- stage V transposed ----
-    {
-      const int keyl = wave * 16 + (lane & 15);
-      const int vrow = min(kv0 + keyl, len - 1);
-      const int kg = keyl >> 2, kw = (keyl & 3) * 2;
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int dc = (lane >> 4) + 4 * x;
-        const half8 v = *(const half8*)at(vrow, 2 * d + h * 64 + dc * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int dd = dc * 8 + e;
-          *(f16*)(Vt + dd * 128 + ((kg ^ ((dd >> 1) & 15)) << 3) + kw) = v[e];
-        }
-      }
-    }
-    __syncthreads();
+  stage(0, 0);
+  for (int kv0 = 0, t = 0; kv0 < len; kv0 += AT_KB, ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile t has landed for everyone; everyone is done with the other buffer
+    if (kv0 + AT_KB < len) stage(kv0 + AT_KB, (t + 1) & 1);
+    const char* Ks = lds + (t & 1) * 2 * TILE;
 
     // ---- S^T = K . Q^T for 2 blocks of 32 keys ----
     f32x16 s[2];
@@ -107,58 +129,80 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     }
 
     // ---- online softmax (per query = per lane, halves joined by one shuffle) ----
-    float mx = -INFINITY;
+    if (kv0 + AT_KB > len) {  // only the last tile of a sentence has keys to mask
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= len) s[kb][r] = -INFINITY;
+    }
+    float mx = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float v = key < len ? s[kb][r] * sl2e : -INFINITY;
-        s[kb][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    m = m_new;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;  // sl2e > 0: the scaled maximum
+    // Lazy rescale: the reference m only moves when some query's tile maximum exceeds it by more than
+    // 2^8; until then p = exp2(x - m) <= 256 (fine in fp32 and for the fp16 P operand) and the 32
+    // output accumulators are left alone.
+    if (__any(mx > m + 8.0f)) {
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
     float psum = 0.f;
     half8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl2e, -m));
         psum += p;
         pf[kb][r >> 3][r & 7] = (f16)p;
       }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    lsum += psum;
 
     // ---- O^T += V^T . P^T ----
+    half4 va[2][2][2][2];  // [db][kb][u][part]
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const int dd = db * 32 + l31;
-      const char* vrow = Vt + dd * 128;
-      const int sw = (dd >> 1) & 15;
+      const unsigned a = vaddr[db] + (t & 1) * 2 * TILE;
+      va[db][0][0][0] = at_tr_read<0>(a);
+      va[db][0][0][1] = at_tr_read<1024>(a);
+      va[db][0][1][0] = at_tr_read<2048>(a);
+      va[db][0][1][1] = at_tr_read<3072>(a);
+      va[db][1][0][0] = at_tr_read<4096>(a);
+      va[db][1][0][1] = at_tr_read<5120>(a);
+      va[db][1][1][0] = at_tr_read<6144>(a);
+      va[db][1][1][1] = at_tr_read<7168>(a);
+    }
+    // the wait carries the results as operands: the MFMAs below depend on IT, not just on the reads
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(va[0][0][0][0]), "+v"(va[0][0][0][1]), "+v"(va[0][0][1][0]), "+v"(va[0][0][1][1]),
+                   "+v"(va[0][1][0][0]), "+v"(va[0][1][0][1]), "+v"(va[0][1][1][0]), "+v"(va[0][1][1][1]),
+                   "+v"(va[1][0][0][0]), "+v"(va[1][0][0][1]), "+v"(va[1][0][1][0]), "+v"(va[1][0][1][1]),
+                   "+v"(va[1][1][0][0]), "+v"(va[1][1][0][1]), "+v"(va[1][1][1][0]), "+v"(va[1][1][1][1])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int g0 = kb * 8 + 4 * u + hi;
-          const half4 a0 = *(const half4*)(vrow + ((g0 ^ sw) << 3));
-          const half4 a1 = *(const half4*)(vrow + (((g0 + 2) ^ sw) << 3));
           half8 vf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            vf[e] = a0[e];
-            vf[e + 4] = a1[e];
+            vf[e] = va[db][kb][u][0][e];
+            vf[e + 4] = va[db][kb][u][1][e];
           }
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][u], o[db], 0, 0, 0);
         }
-    }
   }
 
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
