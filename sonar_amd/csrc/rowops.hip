@@ -154,6 +154,58 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   for (int r0 = blockIdx.x * 16; r0 < rows; r0 += gridDim.x * 16) {
+    if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
+      // fp16 stream: a lane owns 8 consecutive columns per 512-column block, so every global load and
+      // every LDS store moves 16 B per lane (8-B accesses run at 0.54-0.70x the 16-B rate), and the
+      // loads of the wave's 4 rows are all in flight before the first reduction
+      constexpr int NH = NV / 2;
+      half8 raw[4][NH];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = min(r0 + wv + 4 * q, rows - 1);
+#pragma unroll
+        for (int k = 0; k < NH; ++k) raw[q][k] = *(const half8*)(x + (size_t)row * D + k * 512 + lane * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int lr = wv + 4 * q;
+        float v[NH][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NH; ++k)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v[k][i] = (float)raw[q][k][i];
+            sum += v[k][i];
+          }
+        constexpr float inv_d = 1.0f / D;
+        const float mean = wave_sum(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NH; ++k)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v[k][i] -= mean;
+            sq += v[k][i] * v[k][i];
+          }
+        const float rstd = r0 + lr < rows ? 1.0f / sqrtf(wave_sum(sq) * inv_d + eps) : 0.f;
+        const float keep = r0 + lr < rows ? 1.f : 0.f;  // rows past the end of x: zeros
+#pragma unroll
+        for (int k = 0; k < NH; ++k) {
+          const float* wp = w + k * 512 + lane * 8;
+          const float* bp = b + k * 512 + lane * 8;
+          const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+          const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+          half8 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = (f16)(v[k][i] * rstd * w0[i] + keep * b0[i]);
+            o[4 + i] = (f16)(v[k][4 + i] * rstd * w1[i] + keep * b1[i]);
+          }
+          *(half8*)(tile + lr * RS + (k * 512 + lane * 8) * 2) = o;
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int lr = wv + 4 * q;
@@ -171,6 +223,7 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
         for (int i = 0; i < 4; ++i) o[i] = (f16)y[k][i];
         *(half4*)(tile + lr * RS + (k * 256 + lane * 4) * 2) = o;
       }
+    }
     }
     __syncthreads();
     // wave wv copies k-blocks wv, wv+4, ...: lane -> (row lane>>2, slot lane&3)
