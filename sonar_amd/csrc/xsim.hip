@@ -341,6 +341,43 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ src, 
     return;
   }
   const T* s = src + r * d;
+  // fast path (d = 1024 in SONAR): one pass, 16 B per lane per access, the row stays in registers
+  constexpr int VEC = 16 / sizeof(T);      // elements per 16-B access
+  constexpr int MAXV = 4;                  // up to d = 64 * VEC * MAXV
+  if (d % (64 * VEC) == 0 && d <= 64 * VEC * MAXV && d % 512 == 0) {
+    typedef T vec_t __attribute__((ext_vector_type(VEC)));
+    const int nv = d / (64 * VEC);
+    vec_t v[MAXV];
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k)
+      if (k < nv) {
+        v[k] = *(const vec_t*)(s + (k * 64 + lane) * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) q += (float)v[k][e] * (float)v[k][e];
+      }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    if constexpr (VEC == 8) {
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k)
+        if (k < nv) {
+          half8 h;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) h[e] = (f16)((float)v[k][e] * inv);
+          *(half8*)(o + (k * 64 + lane) * 8) = h;
+        }
+    } else {  // fp32 source: two 16-B loads make one 16-B store -- pair the accesses of lanes' chunks
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k)
+        if (k < nv) {
+          half4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (f16)((float)v[k][e] * inv);
+          *(half4*)(o + (k * 64 + lane) * 4) = h;
+        }
+    }
+    return;
+  }
   float q = 0.f;
   for (int c = lane; c < d; c += 64) {
     const float v = (float)s[c];
