@@ -14,8 +14,11 @@ Pinning status:
     consumes -> tests/golden/conformer_twin.pt;
   * the pooler's POST-norm decoder layer is pinned against HuggingFace `BartDecoderLayer`;
   * the filterbank restates kaldi-native-fbank / Kaldi `compute-fbank-feats` defaults as used
-    by fairseq2's WaveformToFbankConverter (un-vendored): PARITY UNPINNED
-    (no torchaudio / kaldi here; only the frame count and invariances are checked);
+    by fairseq2's WaveformToFbankConverter (un-vendored).  fairseq2n / kaldi are absent,
+    so it is pinned against an independent implementation of the same front end for the same
+    w2v-BERT encoder family, HuggingFace `SeamlessM4TFeatureExtractor`: log-mel features, the
+    per-utterance standardisation and the 2-frame stacking order agree to 2e-3 absolute on values
+    in [5, 30] (mean 2e-5) -> tests/golden/fbank_seamless_twin.pt (make_golden_fbank.py);
   * the reference's real-checkpoint goldens (tests/integration_tests/data/speech_embedding.pt,
     test_sonar_speech_pipeline_models.py:28-40) need the checkpoint: PARITY UNPINNED.
 """

@@ -84,3 +84,20 @@ def test_full_model_masks_padding():
     assert_close(emb[1], emb1[0], atol=1e-5, rtol=1e-4)            # batching / padding invariance
     assert_close(enc[1, :13], enc1[0], atol=1e-5, rtol=1e-4)
     assert emb.shape == (2, 64)
+
+
+def test_fbank_matches_hf_seamless_feature_extractor():
+    """The Kaldi filterbank restatement against HuggingFace SeamlessM4TFeatureExtractor (an independent
+    implementation of the same front end for the same w2v-BERT encoder family) on the committed twin
+    (tests/golden/make_golden_fbank.py): log-mel features, then the per-utterance standardisation and
+    the 2-frame stacking the encoder frontend consumes."""
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "fbank_seamless_twin.pt"), weights_only=False)
+    raw = OS.kaldi_fbank(fx["waveform"], standardize=False)
+    assert raw.shape == fx["fbank"].shape == (128, 80)
+    # log-mel values span ~[5, 30]; the two implementations differ by fp32 FFT / mel summation order
+    assert (raw - fx["fbank"]).abs().max().item() < 2e-3
+    assert (raw - fx["fbank"]).abs().mean().item() < 2e-5
+    std = OS.kaldi_fbank(fx["waveform"], standardize=True)
+    stacked = std[: std.shape[0] // 2 * 2].reshape(-1, 160)          # frames (2t, 2t+1) side by side
+    assert stacked.shape == fx["normalized_stacked"].shape
+    assert (stacked - fx["normalized_stacked"]).abs().max().item() < 2e-3
