@@ -4,8 +4,10 @@ xsim cosine mining on the CPU in fp32.  The reference does not implement xsim
 (it is only named, README.md:5); the nearest in-tree code is
 `F.normalize(x) @ F.normalize(y).T` at tests/integration_tests/test_text_sonar.py:42-53.
 The external definition restated here is LASER's xsim: nearest
-neighbour by cosine, or by ratio margin with k = 4.  PARITY IS UNPINNED for
-xsim: the reference holds no golden vector or fixture for it.
+neighbour by cosine, or by ratio margin with k = 4.  The reference holds no golden
+vector or fixture for xsim; the cosine top-k is pinned against scikit-learn's brute-force
+cosine NearestNeighbors (tests/golden/xsim_sklearn_twin.pt, make_golden_xsim.py), the
+ratio margin has no second implementation here: PARITY UNPINNED for it.
 """
 from __future__ import annotations
 

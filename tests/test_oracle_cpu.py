@@ -114,3 +114,14 @@ def test_xsim_oracle_properties():
     z = torch.cat([y[:3], y[:3]])
     _, j = OX.cosine_topk(y[:3], z, 1)
     assert j[:, 0].tolist() == [0, 1, 2]
+
+
+def test_xsim_cosine_topk_matches_sklearn_twin():
+    """cosine_topk against scikit-learn's brute-force cosine NearestNeighbors (independent implementation)
+    on the committed twin (tests/golden/make_golden_xsim.py)."""
+    import os
+
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "xsim_sklearn_twin.pt"), weights_only=False)
+    scores, idx = OX.cosine_topk(fx["x"], fx["y"], 4)
+    assert torch.equal(idx, fx["idx"])
+    assert (scores.double() - fx["cosine"]).abs().max().item() < 1e-5
