@@ -127,6 +127,47 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
   const int wv = threadIdx.x >> 6;
   constexpr int D = NV * 256;
   for (int r = blockIdx.x * 4 + wv; r < rows; r += gridDim.x * 4) {
+    if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
+      // fp16 stream: 8 consecutive columns per lane and 512-column block -> 16-B loads and stores
+      constexpr int NH = NV / 2;
+      float v[NH][8];
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const half8 raw = *(const half8*)(x + (size_t)r * D + k * 512 + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[k][i] = (float)raw[i];
+          sum += v[k][i];
+        }
+      }
+      constexpr float inv_d = 1.0f / D;
+      const float mean = wave_sum(sum) * inv_d;
+      float sq = 0.f;
+#pragma unroll
+      for (int k = 0; k < NH; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          v[k][i] -= mean;
+          sq += v[k][i] * v[k][i];
+        }
+      const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const float* wp = w + k * 512 + lane * 8;
+        const float* bp = b + k * 512 + lane * 8;
+        const f32x4 w0 = *(const f32x4*)wp, w1 = *(const f32x4*)(wp + 4);
+        const f32x4 b0 = *(const f32x4*)bp, b1 = *(const f32x4*)(bp + 4);
+        half8 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] = (f16)(v[k][i] * rstd * w0[i] + b0[i]);
+          o[4 + i] = (f16)(v[k][4 + i] * rstd * w1[i] + b1[i]);
+        }
+        *(half8*)(h + (size_t)r * D + k * 512 + lane * 8) = o;
+      }
+      continue;
+    }
     f32x4 y[NV];
     ln_row<NV, XT>(x + (size_t)r * D, w, b, eps, lane, y);
 #pragma unroll
