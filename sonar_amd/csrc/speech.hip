@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
 #pragma unroll
     for (int k = 0; k < KT; ++k) acc += wk[k] * win[tt + k];
     const float v = acc * sc + sh;
-    yout[tt][tid] = (f16)(v / (1.0f + __expf(-v)));
+    yout[tt][tid] = (f16)(v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)));  // SiLU
   }
   __syncthreads();
   for (int i = tid; i < TT * 32; i += 256) {
