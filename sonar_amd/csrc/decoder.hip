@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
                                                      const float* __restrict__ c, int group,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ b, float eps,
-                                                     f16* __restrict__ h, int rows) {
+                                                     f16* __restrict__ h, int rows, int h_tm) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -122,19 +122,22 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
     half4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (f16)(v[k][i] * rstd * wv[i] + bv[i]);
-    *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
+    if (h_tm)  // tile-major GEMM operand (common.hpp): the FFN inner projection's X
+      *(half4*)(h + tm_offset(r, k * 256 + lane * 4, D)) = o;
+    else
+      *(half4*)(h + (size_t)r * D + k * 256 + lane * 4) = o;
   }
 }
 
 hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
-                                f16* h, int rows, int d, hipStream_t stream) {
+                                f16* h, int rows, int d, hipStream_t stream, int h_tm) {
   const int blocks = (rows + 3) / 4;
   if (!parts) nparts = 0;
 #define SMI_AL_CASE(NV)                                                                            \
   case NV * 256:                                                                                   \
     hipLaunchKernelGGL(sum_ln_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, parts, nparts,    \
-                       part_stride, c, group, w, b, eps, h, rows);                                 \
+                       part_stride, c, group, w, b, eps, h, rows, h_tm);                           \
     break;
   switch (d) {
     SMI_AL_CASE(1)

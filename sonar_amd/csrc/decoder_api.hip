@@ -36,6 +36,7 @@ struct smi_text_decoder {
   DevBuf zero_cc;
   int64_t weight_bytes = 0;
   int kv_positions = 0;  // positions per layer in the current kv allocation
+  int ffn_tile_major = 0;  // FFN weights stored tile-major (d, f multiples of 256)
 };
 
 namespace {
@@ -106,10 +107,13 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
     // the two N = d projections have too few tiles to fill 256 CUs at decode batch sizes:
     // split K into fp32 slabs that the next fused sum+LayerNorm folds into the residual stream
     HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
+    // the FFN runs on tile-major operands (common.hpp): LN output, hidden activation and both weights
+    const int tm = D->ffn_tile_major;
     HIP_TRY(launch_sum_layernorm(x, parts, ks_out, part_stride, D->cc.as<float>() + (size_t)l * n_pad * d, group,
-                                 L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
-    HIP_TRY(launch_gemm_tn(EPI_RELU_F16, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream));
+                                 L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream, tm));
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | (tm ? GEMM_IN_TM | GEMM_OUT_TM : 0), h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn,
+                           rows_pad, f, d, f, stream));
+    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm));
   }
   HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,
                                D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
@@ -168,6 +172,7 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
   up(w->pos_table, (int64_t)(cfg->max_seq_len + cfg->pos_offset) * d, false, D->pos, "pos_table");
   up(w->final_layer_norm_w, d, false, D->lnf_w, "decoder.layer_norm.weight");
   up(w->final_layer_norm_b, d, false, D->lnf_b, "decoder.layer_norm.bias");
+  D->ffn_tile_major = d % 256 == 0 && f % 256 == 0;
   D->layers.resize(cfg->num_layers);
   for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
     const smi_text_decoder_layer& s = w->layers[l];
@@ -186,6 +191,10 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
     up(s.ffn_inner_b, f, false, L.b_1, "ffn.inner_proj.bias");
     up(s.ffn_out_w, d * f, true, L.w_2, "ffn.output_proj.weight");
     up(s.ffn_out_b, d, false, L.b_2, "ffn.output_proj.bias");
+    if (rc == SMI_OK && D->ffn_tile_major) {
+      rc = to_tile_major(L.w_1, (int)f, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_2, (int)d, (int)f);
+    }
     if (rc == SMI_OK) {
       DevBuf tq, tk, tv, bq, bk, bv;
       up(s.q_w, d * d, true, tq, "self_attn.q_proj.weight");

@@ -562,15 +562,18 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
 // Split-K GEMM into `ksplit` fp32 slabs: parts[z][m][n] = X[:, Kz] . W[:, Kz]^T (+ bias for z = 0);
 // the consumer (launch_sum_layernorm) adds the slabs to the residual stream.
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
-                                 int N, int K, int ksplit, hipStream_t stream) {
+                                 int N, int K, int ksplit, hipStream_t stream, int in_tm) {
   if (M % GT_BM || N % GT_BN || ksplit < 1 || K % (GT_BK * ksplit) || M <= 0) return hipErrorInvalidValue;
+  if (in_tm && (M % TM_ROWS || N % TM_ROWS)) return hipErrorInvalidValue;
   // the 256x256 ping-pong engine is far more efficient per CU than the 128x128 one (decoder FFN inner:
   // 160 tiles on 256 CUs still beat 640 small tiles); use it when the units roughly fill the chip once
   // and every unit has a real K loop
   const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
   if (M % G2_BM == 0 && N % G2_BN == 0 && K / ksplit >= 16 * G2_BK && units256 >= 96 && units256 <= num_cus())
-    return launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
-  return launch_one<EPI_STORE_F32>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
+    return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4)
+                 : launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
+  return in_tm ? launch_one<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4)
+               : launch_one<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
 }
 
 }  // namespace smi

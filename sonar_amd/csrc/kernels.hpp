@@ -33,8 +33,9 @@ struct GemmTileStats {
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
                           int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr);
 
+// in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
-                                 int N, int K, int ksplit, hipStream_t stream);
+                                 int N, int K, int ksplit, hipStream_t stream, int in_tm = 0);
 
 // x[row(n,p), :] = E[ids[n*S+p], :] * scale + PE[p + pos_offset, :]   (packed rows)
 // x_f16: the residual stream x is fp16 (SMI_ENC_FP16_RESIDUAL) instead of fp32
@@ -79,7 +80,7 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 // x[r] += sum_z parts[z][r] (+ c[r / group] if c); h[r] = LN(x[r])   (parts/c may be null)
 hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
-                                f16* h, int rows, int d, hipStream_t stream);
+                                f16* h, int rows, int d, hipStream_t stream, int h_tm = 0);
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream);
 constexpr int kVocabScanK2Max = 16;
