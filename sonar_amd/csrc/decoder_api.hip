@@ -26,6 +26,7 @@ struct smi_text_decoder {
   smi_text_decoder_config cfg;
   int64_t vocab_pad = 0;
   DevBuf embed, pos, lnf_w, lnf_b;
+  DevBuf embed_tm;  // tile-major copy of the (padded) table for the tied output projection
   std::vector<DecLayer> layers;
   // per-call workspace (grow-only)
   DevBuf x, h, ctx, ffn, logits, kv, cc, cvtmp, emb16, parts;
@@ -115,13 +116,15 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
                            rows_pad, f, d, f, stream));
     HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm));
   }
+  const int ltm = D->embed_tm.p != nullptr;  // the tied projection reads a tile-major copy of the table
   HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,
-                               D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+                               D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, ltm));
   // beam search (stats_scale = 1 / temperature > 0): the GEMM also leaves per-tile softmax
   // statistics, so the candidate selection never re-reads the 1 MB logits rows
   GemmTileStats st{D->tile_max.as<float>(), D->tile_sum.as<float>(), stats_scale, (int)c.vocab_size};
-  HIP_TRY(launch_gemm_tn(EPI_STORE_F32, h, D->embed.as<f16>(), nullptr, D->logits.p, rows_pad, (int)D->vocab_pad, d,
-                         (int)D->vocab_pad, stream, stats_scale > 0.f ? &st : nullptr));
+  HIP_TRY(launch_gemm_tn(EPI_STORE_F32 | (ltm ? GEMM_IN_TM : 0), h, (ltm ? D->embed_tm : D->embed).as<f16>(), nullptr,
+                         D->logits.p, rows_pad, (int)D->vocab_pad, d, (int)D->vocab_pad, stream,
+                         stats_scale > 0.f ? &st : nullptr));
   return SMI_OK;
 }
 
@@ -169,6 +172,10 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
   };
   // the tied output projection multiplies by the embedding table: pad it to 256-row tiles
   up(w->embed, cfg->vocab_size * d, true, D->embed, "decoder_frontend.embed.weight", D->vocab_pad * d);
+  if (rc == SMI_OK && d % 256 == 0) {  // [vocab_pad][d] -> tile-major (common.hpp), ~0.5 GB for NLLB
+    rc = upload(w->embed, cfg->vocab_size * d, true, D->embed_tm, "decoder_frontend.embed.weight", D->vocab_pad * d);
+    if (rc == SMI_OK) rc = to_tile_major(D->embed_tm, (int)D->vocab_pad, (int)d);
+  }
   up(w->pos_table, (int64_t)(cfg->max_seq_len + cfg->pos_offset) * d, false, D->pos, "pos_table");
   up(w->final_layer_norm_w, d, false, D->lnf_w, "decoder.layer_norm.weight");
   up(w->final_layer_norm_b, d, false, D->lnf_b, "decoder.layer_norm.bias");
@@ -222,7 +229,7 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
     delete D;
     return rc;
   }
-  D->weight_bytes = (int64_t)(D->embed.bytes + D->pos.bytes);
+  D->weight_bytes = (int64_t)(D->embed.bytes + D->embed_tm.bytes + D->pos.bytes);
   for (auto& L : D->layers)
     D->weight_bytes += (int64_t)(L.w_qkv.bytes + L.w_o.bytes + L.wc_v.bytes + L.wc_o.bytes + L.w_1.bytes + L.w_2.bytes);
   *out = D;

@@ -517,8 +517,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // 128 tiles tie, 160 tiles win -> use it from 144 tiles (56 % of the CUs) up
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 144);
   if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
-    if (epi != EPI_STORE_F32 || in_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
-    return launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);
+    if (epi != EPI_STORE_F32 || out_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
+    return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, out, M, N, K, ldo, stream, stats)
+                 : launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);
   }
 #define SMI_EPI_CASE(E, L)                                                     \
   case E:                                                                      \
