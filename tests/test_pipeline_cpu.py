@@ -48,6 +48,15 @@ def test_lang_order_matches_reference_card():
     assert card["langs"] == NLLB_LANGS
 
 
+def test_lang_order_matches_hf_fairseq_language_codes():
+    """The same order from an independent source: HuggingFace's FAIRSEQ_LANGUAGE_CODES
+    (tests/golden/make_golden_langs.py), which travels to machines without the reference tree."""
+    import json
+
+    hf = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "nllb_language_codes.json")))
+    assert hf == NLLB_LANGS and len(hf) == 202
+
+
 def test_tokenizer_layout(spm_model):
     tok = NllbTokenizer(spm_model)
     assert tok.vocab_info.pad_idx == 0 and tok.vocab_info.eos_idx == 3
