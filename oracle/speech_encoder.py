@@ -19,6 +19,9 @@ Pinning status:
     w2v-BERT encoder family, HuggingFace `SeamlessM4TFeatureExtractor`: log-mel features, the
     per-utterance standardisation and the 2-frame stacking order agree to 2e-3 absolute on values
     in [5, 30] (mean 2e-5) -> tests/golden/fbank_seamless_twin.pt (make_golden_fbank.py);
+  * the whole path waveform -> embedding (stacking order, frontend, block stack, moved LayerNorm,
+    pooler query and layers, projection) agrees to 1e-6 (1 - cos) with a composition of those
+    independent implementations on a GPU-sized twin -> tests/golden/speech_e2e_twin.pt;
   * the reference's real-checkpoint goldens (tests/integration_tests/data/speech_embedding.pt,
     test_sonar_speech_pipeline_models.py:28-40) need the checkpoint: PARITY UNPINNED.
 """

@@ -78,3 +78,31 @@ def test_greedy_generation_matches_hf_generate(fx, decoder):
                 break                                                            # ... and the paths part here
             compared += 1
     assert compared >= 80
+
+
+@pytest.mark.parametrize("fp16_residual", [False, True])
+def test_speech_pipeline_matches_hf_composition(fx_speech, fp16_residual):
+    """waveform -> sentence embedding through SpeechToEmbeddingModelPipeline.predict against the
+    composition of independent implementations of tests/golden/make_golden_speech_e2e.py."""
+    from oracle import speech_encoder as OS      # only for the seeded weights
+    from sonar_amd.inference_pipelines import SpeechToEmbeddingModelPipeline
+    from sonar_amd.speech_encoder import SonarSpeechEncoderConfig, SonarSpeechEncoderModel
+
+    c = fx_speech["config"]
+    p = OS.make_synthetic_params(OS.OracleSpeechEncoderConfig(**c), seed=fx_speech["seed"], std=fx_speech["std"])
+    cfg = SonarSpeechEncoderConfig(model_dim=c["model_dim"], num_encoder_layers=c["num_layers"],
+                                   num_encoder_attn_heads=c["num_heads"], ffn_inner_dim=c["ffn_inner_dim"],
+                                   depthwise_conv_kernel_size=c["conv_kernel"], num_decoder_layers=c["pooler_layers"],
+                                   num_decoder_attn_heads=c["pooler_heads"], decoder_ffn_inner_dim=c["pooler_ffn_dim"],
+                                   max_frames=512)
+    model = SonarSpeechEncoderModel(cfg, p, device="cuda:0", dtype=torch.float32, fp16_residual=fp16_residual)
+    pipe = SpeechToEmbeddingModelPipeline(model, device=torch.device("cuda:0"))
+    out = pipe.predict([w.unsqueeze(0) for w in fx_speech["waveforms"]], batch_size=2).cpu()
+    want = fx_speech["embeddings"]
+    assert (1 - F.cosine_similarity(out, want, dim=-1)).abs().max().item() <= 1e-3
+    assert (out - want).abs().max().item() <= 3e-2 * want.abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def fx_speech():
+    return torch.load(os.path.join(GOLDEN, "speech_e2e_twin.pt"), weights_only=False)

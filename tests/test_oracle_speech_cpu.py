@@ -101,3 +101,21 @@ def test_fbank_matches_hf_seamless_feature_extractor():
     stacked = std[: std.shape[0] // 2 * 2].reshape(-1, 160)          # frames (2t, 2t+1) side by side
     assert stacked.shape == fx["normalized_stacked"].shape
     assert (stacked - fx["normalized_stacked"]).abs().max().item() < 2e-3
+
+
+def test_speech_path_end_to_end_matches_hf_composition():
+    """waveform -> sentence embedding against the composition of independent implementations
+    (HF SeamlessM4TFeatureExtractor, torch LayerNorm/Linear, HF Wav2Vec2ConformerEncoderLayer, HF
+    BartDecoderLayer) on the GPU-sized twin -- tests/golden/make_golden_speech_e2e.py."""
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "speech_e2e_twin.pt"), weights_only=False)
+    cfg = OS.OracleSpeechEncoderConfig(**fx["config"])
+    p = OS.make_synthetic_params(cfg, seed=fx["seed"], std=fx["std"])
+    for i, wav in enumerate(fx["waveforms"]):
+        fb = OS.kaldi_fbank(wav)
+        fb = fb[: fb.shape[0] // 2 * 2].unsqueeze(0)
+        enc, emb = OS.speech_encoder_forward(p, cfg, fb, None)
+        want = fx["embeddings"][i]
+        assert (emb[0] - want).abs().max().item() <= 2e-3 * want.abs().max().item()
+        assert 1 - torch.nn.functional.cosine_similarity(emb[0], want, dim=0).item() <= 1e-6
+        if i == 0:
+            assert (enc[0] - fx["encoder_out_first_clip"]).abs().max().item() <= 5e-3
