@@ -87,7 +87,7 @@ def speech_leg(dev, n=64):
     """BASELINE configs[3]: sonar_speech_encoder_eng, 64 clips x 10 s @ 16 kHz (fbank + conformer + pooler)."""
     import torch
 
-    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveform_to_fbank
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveforms_to_fbank_batch
     from tools.synth import speech_encoder_state_dict
 
     eng = SpeechEncoderEngine(get_speech_encoder_config("english"), speech_encoder_state_dict(dev), device=dev)
@@ -95,7 +95,7 @@ def speech_leg(dev, n=64):
     wavs = torch.rand(n, 160000, device=dev, generator=g) * 2 - 1
 
     def run():
-        feats = torch.stack([waveform_to_fbank(wavs[i]) for i in range(n)])
+        feats, _ = waveforms_to_fbank_batch(list(wavs))     # one launch for the batch, as predict() does
         return eng.forward(feats, None, torch.float16)
 
     run()

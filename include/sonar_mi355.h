@@ -321,6 +321,14 @@ int64_t smi_fbank_num_frames(int64_t nsamples);
 int smi_fbank(const float* wave, int64_t nsamples, float waveform_scale, int32_t standardize, float* out,
               void* stream);
 
+/* The same filterbank for a whole batch in one launch: waves device fp32, the clips back to back;
+ * offsets HOST int64 [n + 1] (clip i = samples offsets[i] .. offsets[i+1]); out device fp32
+ * [n, tpad, 80], tpad >= every clip's frame count, rows past a clip's frames are set to 0 (the
+ * reference's Collater pad value, speech.py:444).  Stands in for the per-file
+ * WaveformToFbankConverter map + Collater of SpeechToEmbeddingModelPipeline.predict (speech.py:431-452). */
+int smi_fbank_batch(const float* waves, const int64_t* offsets, int32_t n, float waveform_scale, int32_t standardize,
+                    float* out, int64_t tpad, void* stream);
+
 /* xsim mining ---------------------------------------------------------------
  * Stands in for the similarity search the reference performs as
  * F.normalize(x) @ F.normalize(y).T (tests/integration_tests/test_text_sonar.py:42-53)

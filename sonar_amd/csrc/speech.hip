@@ -131,6 +131,118 @@ __global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restric
   }
 }
 
+// ---- batched filterbank: every clip of a batch in one launch, output zero-padded [n][tpad][80] ----
+// grid (tpad, n): workgroup (f, c) computes frame f of clip c (samples off[c] + 160 f ..), or writes the
+// zero padding the encoder's collation expects (speech.py:444, pad value 0) when f >= frames(c).
+__global__ __launch_bounds__(256) void fbank_batch_kernel(const float* __restrict__ waves,
+                                                          const int64_t* __restrict__ off, float scale,
+                                                          const float* __restrict__ window,
+                                                          const float* __restrict__ mel_w,
+                                                          const int* __restrict__ mel_range,
+                                                          float* __restrict__ out, int tpad) {
+  __shared__ float re[FB_NFFT], im[FB_NFFT];
+  __shared__ float red[4];
+  const int f = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t ns = off[c + 1] - off[c];
+  const int frames = ns < FB_WIN ? 0 : (int)(1 + (ns - FB_WIN) / FB_SHIFT);
+  float* dst = out + ((size_t)c * tpad + f) * FB_BINS;
+  if (f >= frames) {
+    if (tid < FB_BINS) dst[tid] = 0.f;
+    return;
+  }
+  const float* src = waves + off[c] + (size_t)f * FB_SHIFT;
+  float a0 = tid < FB_WIN ? src[tid] * scale : 0.f;
+  float a1 = tid + 256 < FB_WIN ? src[tid + 256] * scale : 0.f;
+  float s = wave_sum(a0 + a1);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / FB_WIN;
+  if (tid < FB_WIN) re[tid] = a0 - mean;
+  if (tid + 256 < FB_WIN) re[tid + 256] = a1 - mean;
+  __syncthreads();
+  float y0 = 0.f, y1 = 0.f;
+  if (tid < FB_WIN) y0 = (re[tid] - 0.97f * re[tid == 0 ? 0 : tid - 1]) * window[tid];
+  if (tid + 256 < FB_WIN) y1 = (re[tid + 256] - 0.97f * re[tid + 255]) * window[tid + 256];
+  __syncthreads();
+  {
+    const int r0 = __brev((unsigned)tid) >> 23, r1 = __brev((unsigned)(tid + 256)) >> 23;
+    re[r0] = y0;
+    im[r0] = 0.f;
+    re[r1] = y1;
+    im[r1] = 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int st = 1; st <= 9; ++st) {
+    const int half = 1 << (st - 1);
+    const int grp = tid >> (st - 1), pos = tid & (half - 1);
+    const int i0 = grp * (half << 1) + pos, i1 = i0 + half;
+    float sn, cs;
+    sincospif(-(float)pos / (float)half, &sn, &cs);
+    const float xr = re[i1], xi = im[i1];
+    const float tr = xr * cs - xi * sn, ti = xr * sn + xi * cs;
+    const float ur = re[i0], ui = im[i0];
+    re[i0] = ur + tr;
+    im[i0] = ui + ti;
+    re[i1] = ur - tr;
+    im[i1] = ui - ti;
+    __syncthreads();
+  }
+  const float pw = re[tid] * re[tid] + im[tid] * im[tid];
+  __syncthreads();
+  re[tid] = pw;
+  __syncthreads();
+  if (tid < FB_BINS) {
+    const int k0 = mel_range[tid * 2], k1 = mel_range[tid * 2 + 1];
+    float e = 0.f;
+    for (int k = k0; k < k1; ++k) e += mel_w[tid * 256 + k] * re[k];
+    dst[tid] = __logf(fmaxf(e, 1.1920929e-07f));
+  }
+}
+
+// per-clip standardisation of the batch: one workgroup of 12 x 80 threads per clip walks its frames
+// three times (mean, unbiased variance around it, normalise) -- the same arithmetic order per column
+// group as the single-clip path's partial sums is not needed for parity (both are two-pass fp32).
+__global__ __launch_bounds__(960) void fbank_batch_standardize_kernel(float* __restrict__ fb,
+                                                                      const int64_t* __restrict__ off, int tpad) {
+  __shared__ float red[12][FB_BINS];
+  __shared__ float stat[2][FB_BINS];
+  const int c = blockIdx.x, b = threadIdx.x % FB_BINS, g = threadIdx.x / FB_BINS;
+  const int64_t ns = off[c + 1] - off[c];
+  const int frames = ns < FB_WIN ? 0 : (int)(1 + (ns - FB_WIN) / FB_SHIFT);
+  if (frames < 2) return;
+  float* x = fb + (size_t)c * tpad * FB_BINS + b;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float mean = pass ? stat[0][b] : 0.f;
+    float acc = 0.f;
+    for (int f = g; f < frames; f += 12) {
+      const float d = x[(size_t)f * FB_BINS] - mean;
+      acc += pass ? d * d : d;
+    }
+    red[g][b] = acc;
+    __syncthreads();
+    if (g == 0) {
+      float v = 0.f;
+      for (int i = 0; i < 12; ++i) v += red[i][b];
+      stat[pass][b] = pass ? 1.0f / sqrtf(v / (frames - 1)) : v / frames;
+    }
+    __syncthreads();
+  }
+  const float mean = stat[0][b], inv = stat[1][b];
+  for (int f = g; f < frames; f += 12) x[(size_t)f * FB_BINS] = (x[(size_t)f * FB_BINS] - mean) * inv;
+}
+
+hipError_t launch_fbank_batch(const float* waves, const int64_t* off_dev, int n, int tpad, float scale,
+                              int standardize, const float* window, const float* mel_w, const int* mel_range,
+                              float* out, hipStream_t stream) {
+  if (n <= 0 || tpad <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fbank_batch_kernel, dim3(tpad, n), dim3(256), 0, stream, waves, off_dev, scale, window, mel_w,
+                     mel_range, out, tpad);
+  if (standardize)
+    hipLaunchKernelGGL(fbank_batch_standardize_kernel, dim3(n), dim3(960), 0, stream, out, off_dev, tpad);
+  return hipGetLastError();
+}
+
 hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int standardize, const float* window,
                         const float* mel_w, const int* mel_range, float* out, hipStream_t stream) {
   if (nsamples < FB_WIN) return hipSuccess;

@@ -159,6 +159,28 @@ int smi_fbank(const float* wave, int64_t nsamples, float waveform_scale, int32_t
   return SMI_OK;
 }
 
+int smi_fbank_batch(const float* waves, const int64_t* offsets, int32_t n, float waveform_scale, int32_t standardize,
+                    float* out, int64_t tpad, void* stream_v) {
+  if (!waves || !offsets || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || tpad <= 0 || tpad > (1 << 24)) return fail(SMI_ERR_INVALID_ARG, "bad n / tpad");
+  for (int i = 0; i < n; ++i) {
+    if (offsets[i + 1] < offsets[i]) return fail(SMI_ERR_INVALID_ARG, "offsets must be non-decreasing");
+    if (smi_fbank_num_frames(offsets[i + 1] - offsets[i]) > tpad)
+      return fail(SMI_ERR_INVALID_ARG, "clip %d has more than tpad = %lld frames", i, (long long)tpad);
+  }
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  if (int rc = ensure_fbank_consts()) return rc;
+  FbankConsts& c = fbank_consts();
+  hipStream_t stream = (hipStream_t)stream_v;
+  int64_t* off_dev = nullptr;
+  HIP_TRY(hipMallocAsync((void**)&off_dev, (size_t)(n + 1) * sizeof(int64_t), stream));
+  HIP_TRY(hipMemcpyAsync(off_dev, offsets, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(launch_fbank_batch(waves, off_dev, n, (int)tpad, waveform_scale, standardize, c.window.as<float>(),
+                             c.mel_w.as<float>(), c.mel_range.as<int>(), out, stream));
+  HIP_TRY(hipFreeAsync(off_dev, stream));
+  return SMI_OK;
+}
+
 int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_speech_encoder_weights* w,
                               smi_speech_encoder** out) {
   if (!cfg || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");

@@ -14,7 +14,8 @@ from typing import Iterable, List, Optional, Sequence, Union
 
 import torch
 
-from ..speech_encoder import SonarSpeechEncoderModel, load_sonar_speech_encoder, waveform_to_fbank
+from ..speech_encoder import (SonarSpeechEncoderModel, load_sonar_speech_encoder, waveform_to_fbank,
+                              waveforms_to_fbank_batch)
 from ..text_encoder import PaddingMask, SequenceBatch
 from .utils import add_progress_bar
 
@@ -95,13 +96,12 @@ class SpeechToEmbeddingModelPipeline(torch.nn.Module):
             batches = add_progress_bar(batches, inputs=items, batch_size=batch_size)
         results: List[torch.Tensor] = []
         for chunk in batches:
-            feats = [waveform_to_fbank(self._decode_audio(x)) for x in chunk]
-            lens = [f.shape[0] for f in feats]
-            t = max(lens)
-            t += t % 2                                         # Collater(pad_to_multiple=2) (speech.py:444)
-            fb = torch.full((len(feats), t, 80), float(pad_idx), dtype=torch.float32, device=self.device)
-            for i, f in enumerate(feats):
-                fb[i, : f.shape[0]] = f
+            # fbank of the whole batch in one launch, collated as Collater(pad_to_multiple=2) (speech.py:444)
+            fb, lens = waveforms_to_fbank_batch([self._decode_audio(x) for x in chunk])
+            t = fb.shape[1]
+            if pad_idx != 0:
+                for i, l in enumerate(lens):
+                    fb[i, l:] = float(pad_idx)
             ragged = any(l != t for l in lens)
             mask = PaddingMask(torch.tensor(lens, dtype=torch.int32), t) if ragged else None
             results.append(self.model(SequenceBatch(fb, mask)).sentence_embeddings)

@@ -258,6 +258,33 @@ def waveform_to_fbank(waveform: torch.Tensor, waveform_scale: float = 2.0 ** 15,
     return out
 
 
+def waveforms_to_fbank_batch(waveforms: Sequence[torch.Tensor], waveform_scale: float = 2.0 ** 15,
+                             standardize: bool = True, pad_to_multiple: int = 2):
+    """The filterbank of a whole batch in one launch, collated as the reference's
+    `Collater(pad_value=0, pad_to_multiple=2)` does (speech.py:444).
+    waveforms: 1-D fp32 tensors on one HIP device.  Returns (fbank fp32 [n, T, 80] zero-padded, frames per clip)."""
+    if not waveforms:
+        raise ValueError("empty batch")
+    dev = waveforms[0].device
+    if dev.type != "cuda":
+        raise RuntimeError("waveforms_to_fbank_batch runs on a HIP device only (no CPU path)")
+    flat = [w.reshape(-1).to(dev, torch.float32) for w in waveforms]
+    lib = _lib.load()
+    lens = [int(lib.smi_fbank_num_frames(w.numel())) for w in flat]
+    t = max(max(lens), 1)
+    t = (t + pad_to_multiple - 1) // pad_to_multiple * pad_to_multiple
+    offs = [0]
+    for w in flat:
+        offs.append(offs[-1] + w.numel())
+    cat = torch.cat(flat) if len(flat) > 1 else flat[0].contiguous()
+    out = torch.empty((len(flat), t, 80), dtype=torch.float32, device=dev)
+    arr = (C.c_int64 * len(offs))(*offs)
+    with torch.cuda.device(dev):
+        _lib.check(lib.smi_fbank_batch(cat.data_ptr(), arr, len(flat), float(waveform_scale), 1 if standardize else 0,
+                                       out.data_ptr(), t, _lib.current_stream_ptr()))
+    return out, lens
+
+
 class SonarSpeechEncoderModel:
     """Drop-in for the object SpeechToEmbeddingModelPipeline calls as `model(batch)`
     (speech.py:452): SequenceBatch of fbank features -> SonarEncoderOutput."""

@@ -109,3 +109,20 @@ def test_speech_pipeline_end_to_end(tmp_path):
         fb[0, : f.shape[0]] = f
         _, ref = OS.speech_encoder_forward(params, ocfg, fb, torch.tensor([f.shape[0]]))
         assert _cos_err(out[i:i + 1], ref) <= 1e-3
+
+
+def test_batched_fbank_equals_per_clip_and_pads_with_zeros():
+    from sonar_amd.speech_encoder import waveform_to_fbank, waveforms_to_fbank_batch
+
+    g = torch.Generator().manual_seed(11)
+    clips = [torch.rand(n, generator=g) * 2 - 1 for n in (16000, 399, 24123, 400, 8000)]
+    fb, lens = waveforms_to_fbank_batch([c.cuda() for c in clips])
+    assert lens == [98, 0, 149, 1, 48] and fb.shape == (5, 150, 80)
+    for i, c in enumerate(clips):
+        if lens[i] >= 2:
+            one = waveform_to_fbank(c.cuda())
+            assert (fb[i, : lens[i]] - one).abs().max().item() <= 2e-4
+        assert (fb[i, lens[i]:] == 0).all()
+    raw, _ = waveforms_to_fbank_batch([c.cuda() for c in clips], standardize=False)
+    assert torch.equal(raw[3, :1], waveform_to_fbank(clips[3].cuda(), standardize=False))   # a single frame
+    assert torch.equal(raw[0, :98], waveform_to_fbank(clips[0].cuda(), standardize=False))

@@ -3,7 +3,7 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sonar_amd.speech_encoder import get_speech_encoder_config, SpeechEncoderEngine, waveform_to_fbank
+from sonar_amd.speech_encoder import get_speech_encoder_config, SpeechEncoderEngine, waveforms_to_fbank_batch
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -17,7 +17,7 @@ def main():
     del sd
     wavs = torch.rand(n, 160000, device=dev, generator=g) * 2 - 1
     def run():
-        feats = torch.stack([waveform_to_fbank(wavs[i]) for i in range(n)])      # [n, 998, 80]
+        feats, _ = waveforms_to_fbank_batch(list(wavs))                         # [n, 998, 80], one launch
         return eng.forward(feats, None, torch.float16), feats
     run(); torch.cuda.synchronize()
     t0 = time.time(); reps = 3
