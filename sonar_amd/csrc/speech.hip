@@ -782,7 +782,13 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const f16* __restri
   for (int i = 0; i < 8; ++i) qf[i] = *(const half8*)(qp + i * 8);
   const size_t ld = (size_t)2 * d;
   const f16* kb = kv + (size_t)start * ld + h * 64;
-  float m = -1e30f, l = 0.f, o = 0.f;
+  // P.V: lane (pg, c8) accumulates head dims c8*8..+7 over the positions j0 + 8 it + pg (16-B row pieces,
+  // the probability comes from the lane that scored that position), joined across pg at the end
+  const int pg = lane >> 3, c8 = lane & 7;
+  float m = -1e30f, l = 0.f;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
   for (int j0 = 0; j0 < len; j0 += 64) {
     const int j = j0 + lane;
     float s = -INFINITY;
@@ -801,15 +807,30 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const f16* __restri
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     const float p = __builtin_amdgcn_exp2f(s - m_new);
     l = l * alpha + wave_sum(p);
-    o *= alpha;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] *= alpha;
     m = m_new;
-    const int cnt = min(64, len - j0);
-    for (int t = 0; t < cnt; ++t) {
-      const float pt = __shfl(p, t, 64);
-      o += pt * (float)kb[(size_t)(j0 + t) * ld + d + lane];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int t = it * 8 + pg;
+      const float pt = __shfl(p, t, 64);  // 0 for positions past the clip
+      if (j0 + t < len) {
+        const half8 vv = *(const half8*)(kb + (size_t)(j0 + t) * ld + d + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += pt * (float)vv[e];
+      }
     }
   }
-  ctx[(size_t)c * d + h * 64 + lane] = (f16)(len > 0 ? o / l : 0.f);
+  half8 out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = o[e];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    out[e] = (f16)(len > 0 ? v / l : 0.f);
+  }
+  if (pg == 0) *(half8*)(ctx + (size_t)c * d + h * 64 + c8 * 8) = out;
 }
 
 hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu, f16* ctx, int n, int d, int heads,
