@@ -326,6 +326,79 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   XT* xr = x + (size_t)r * D;
+  if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
+    // fp16 stream: a lane owns 8 consecutive columns per 512-column block -> every access is 16 B
+    // (the stream read and write-back, and one whole 16-B chunk of the tile-major h)
+    constexpr int NH = NV / 2;
+    float u[NH][8];
+    float s8 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const half8 raw = *(const half8*)(xr + k * 512 + lane * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        u[k][i] = (float)raw[i];
+        s8 += u[k][i];
+      }
+    }
+    float mean8 = wave_sum(s8) * inv_d, q8 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NH; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        u[k][i] -= mean8;
+        q8 += u[k][i] * u[k][i];
+      }
+    float rstd8 = 1.0f / sqrtf(wave_sum(q8) * inv_d + eps);
+    s8 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      const float* wp = w1 + k * 512 + lane * 8;
+      const float* bp = b1 + k * 512 + lane * 8;
+      const f32x4 wa = *(const f32x4*)wp, wb = *(const f32x4*)(wp + 4), ba = *(const f32x4*)bp, bb = *(const f32x4*)(bp + 4);
+      half8 hv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float y = u[k][i] * rstd8 * (i < 4 ? wa[i] : wb[i - 4]) + (i < 4 ? ba[i] : bb[i - 4]);
+        hv[i] = (f16)y;
+        u[k][i] = (float)hv[i];  // the second LayerNorm sees what the stream holds
+        s8 += u[k][i];
+      }
+      *(half8*)(xr + k * 512 + lane * 8) = hv;
+    }
+    if (!h) return;
+    if (w2) {
+      mean8 = wave_sum(s8) * inv_d;
+      q8 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NH; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          u[k][i] -= mean8;
+          q8 += u[k][i] * u[k][i];
+        }
+      rstd8 = 1.0f / sqrtf(wave_sum(q8) * inv_d + eps);
+#pragma unroll
+      for (int k = 0; k < NH; ++k) {
+        const float* wp = w2 + k * 512 + lane * 8;
+        const float* bp = b2 + k * 512 + lane * 8;
+        const f32x4 wa = *(const f32x4*)wp, wb = *(const f32x4*)(wp + 4), ba = *(const f32x4*)bp, bb = *(const f32x4*)(bp + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[k][i] = u[k][i] * rstd8 * (i < 4 ? wa[i] : wb[i - 4]) + (i < 4 ? ba[i] : bb[i - 4]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NH; ++k) {
+      half8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (f16)u[k][i];
+      if constexpr (TM)
+        *(half8*)(h + tm_offset(r, k * 512 + lane * 8, D)) = o;  // one 16-B chunk of the tile-major operand
+      else
+        *(half8*)(h + (size_t)r * D + k * 512 + lane * 8) = o;
+    }
+    return;
+  }
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
