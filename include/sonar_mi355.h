@@ -119,6 +119,13 @@ int smi_text_encoder_forward(smi_text_encoder* enc, const int64_t* ids, const in
                              int32_t n, int32_t s, void* out_emb, void* out_encoded,
                              int32_t out_dtype, void* stream);
 
+/* Synchronises `stream` and reports what the device found while running the forward calls enqueued on
+ * it: SMI_ERR_INVALID_ARG if a batch held token ids outside [0, vocab_size) -- the reference's
+ * embedding lookup raises an IndexError there (tokenizer / model vocabulary mismatch); the engine never
+ * reads outside the table, flags the batch instead, and the flag is also returned by the next
+ * smi_text_encoder_forward on this handle.  predict() calls this before it returns embeddings. */
+int smi_text_encoder_status(smi_text_encoder* enc, void* stream);
+
 /* Bytes of device memory currently held by the handle (weights + workspace). */
 int64_t smi_text_encoder_device_bytes(const smi_text_encoder* enc);
 
@@ -208,6 +215,15 @@ int smi_text_decoder_logits(smi_text_decoder* dec, const void* emb, int32_t emb_
 int smi_text_decoder_generate(smi_text_decoder* dec, const void* emb, int32_t emb_dtype, int32_t n,
                               const int64_t* prompt, int32_t prompt_len, const smi_beam_search_params* params,
                               int32_t* out_tokens, int32_t* out_lens, float* out_scores, void* stream);
+
+/* Decision margins of the LAST smi_text_decoder_generate call on this handle: out_margins device fp32
+ * [n, 2].  [s][0] = the smallest gap, over all free decoding steps of sentence s, between neighbouring
+ * entries of the sorted beam x vocab candidate list among the candidates the beam rules consumed plus
+ * the first one they did not (log-prob units; for beam_size 1 this is the greedy top-1 / top-2 margin);
+ * [s][1] = normalised score of the returned hypothesis minus the runner-up's (+inf if there is none).
+ * "Exact token-id match for greedy decode" (BASELINE north_star) is tested as: every token equal to the
+ * fp32 CPU oracle's unless [s][0] is below the epsilon stated in the test. */
+int smi_text_decoder_last_margins(smi_text_decoder* dec, float* out_margins, int32_t n, void* stream);
 
 /* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
  * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).
@@ -394,6 +410,13 @@ int smi_host_collate_nllb(const int32_t* pieces, const int64_t* piece_offsets, c
                           int64_t first, int64_t n, const int64_t* prefix, int32_t n_prefix,
                           const int64_t* suffix, int32_t n_suffix, int32_t piece_shift, int64_t pad_value,
                           int64_t* out_ids, int32_t row_stride, int32_t num_threads);
+
+/* WAV decoding on the host (the reference: fairseq2n AudioDecoder over libsndfile,
+ * sonar/inference_pipelines/speech.py:292-308).  RIFF/WAVE with PCM 8/16/24/32-bit or IEEE float
+ * 32/64-bit samples (incl. WAVE_FORMAT_EXTENSIBLE).  `bytes` is the file image.  smi_host_wav_decode
+ * writes float32 [frames, channels] (channel-last, integer PCM scaled by 2^-(bits-1)). */
+int smi_host_wav_info(const uint8_t* bytes, int64_t nbytes, int32_t* channels, int32_t* sample_rate, int64_t* frames);
+int smi_host_wav_decode(const uint8_t* bytes, int64_t nbytes, float* out, int64_t frames, int32_t channels);
 
 /* Building blocks (exported for the parity tests and microbenchmarks) ------ */
 /* TILE-MAJOR operand layout (SMI_GEMM_IN_TM / SMI_GEMM_OUT_TM, `tile_major` arguments): a K-major

@@ -169,14 +169,19 @@ def beam_search(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, 
                 beam_size: int = 5, min_gen_len: int = 1, max_gen_len: Tuple[int, int] = (1, 128),
                 max_seq_len: Optional[int] = None, normalize_scores: bool = True, len_penalty: float = 1.0,
                 unk_penalty: float = 0.0, temperature: float = 1.0, pad_idx: int = 0, unk_idx: int = 1,
-                eos_idx: int = 3) -> List[List[Hypothesis]]:
+                eos_idx: int = 3, source_len: Optional[int] = None) -> List[List[Hypothesis]]:
     """fairseq2 BeamSearchSeq2SeqGenerator defaults for a batch of sentence
     embeddings; one independent beam per embedding (the reference processes the beams of a
     batch jointly, which is arithmetically the same).  Returns, per embedding, its finished
     hypotheses sorted best first (the pipeline decodes hypotheses[0].seq)."""
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
     plen = len(prompt)
-    gen_cap = int(max_gen_len[0] * 1 + max_gen_len[1])  # source length is 1 (the sentence vector)
+    # fairseq2: max_gen_len = a * max_source_len + b with max_source_len = source_seqs.size(1).  The
+    # vec2text pipeline passes the stacked embeddings [n, model_dim] as source_seqs (text.py:329-333),
+    # so the "source length" is model_dim there; text / speech sources pass their token / frame count.
+    if source_len is None:
+        source_len = cfg.model_dim
+    gen_cap = int(max_gen_len[0] * source_len + max_gen_len[1])
     max_len = min(plen + gen_cap, model_max)
     min_len = min(plen + min_gen_len, max_len)
     results: List[List[Hypothesis]] = []
@@ -353,12 +358,14 @@ def sampling_generate(params, cfg: OracleTextDecoderConfig, embeddings: torch.Te
                       sampler: Tuple[str, float], seed: int, min_gen_len: int = 1,
                       max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
                       normalize_scores: bool = True, len_penalty: float = 1.0, temperature: float = 1.0,
-                      pad_idx: int = 0, eos_idx: int = 3, row_offset: int = 0):
+                      pad_idx: int = 0, eos_idx: int = 3, row_offset: int = 0, source_len: Optional[int] = None):
     """SamplingSeq2SeqGenerator, one hypothesis per embedding; sampler = ("top_k", k) | ("top_p", p).
     Returns [(tokens after the prompt, score, step log-probs)] per embedding."""
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
     plen = len(prompt)
-    max_len = min(plen + int(max_gen_len[0] + max_gen_len[1]), model_max)
+    if source_len is None:
+        source_len = cfg.model_dim
+    max_len = min(plen + int(max_gen_len[0] * source_len + max_gen_len[1]), model_max)
     min_len = min(plen + min_gen_len, max_len)
     out = []
     for r, e in enumerate(embeddings):

@@ -213,6 +213,7 @@ SYMBOLS = {
                                           C.POINTER(_vp)]),
     "smi_text_encoder_destroy": (None, [_vp]),
     "smi_text_encoder_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "smi_text_encoder_status": (C.c_int, [_vp, _vp]),
     "smi_text_encoder_device_bytes": (_i64, [_vp]),
     "smi_text_encoder_set_profiling": (C.c_int, [_vp, _i32]),
     "smi_text_encoder_read_profile": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -222,6 +223,7 @@ SYMBOLS = {
     "smi_text_decoder_logits": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "smi_text_decoder_generate": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                             C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
+    "smi_text_decoder_last_margins": (C.c_int, [_vp, _vp, _i32, _vp]),
     "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                           C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
     "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp,
@@ -245,6 +247,8 @@ SYMBOLS = {
     "smi_host_token_lengths": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, C.POINTER(_i64)]),
     "smi_host_dynamic_bucket": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "smi_host_collate_nllb": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32]),
+    "smi_host_wav_info": (C.c_int, [_vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "smi_host_wav_decode": (C.c_int, [_vp, _i64, _vp, _i64, _i32]),
     "smi_pack_tile_major": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "smi_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

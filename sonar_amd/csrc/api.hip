@@ -91,6 +91,10 @@ struct smi_text_encoder {
   int64_t cu_cap = 0;
   int cu_next = 0;
   int64_t weight_bytes = 0;
+  // out-of-vocabulary token ids: the embedding kernel raises this flag (host-mapped, device-visible);
+  // it is reported by smi_text_encoder_status() and by the next forward call (sticky until then)
+  int32_t* bad_ids = nullptr;      // pinned host word
+  int32_t* bad_ids_dev = nullptr;  // its device address
   // every GEMM operand (weights, h, ctx, ffn) in the tile-major layout of common.hpp
   bool tile_major = false;
   bool x16 = false;  // SMI_ENC_FP16_RESIDUAL: the residual stream x is fp16
@@ -103,6 +107,7 @@ struct smi_text_encoder {
 
   ~smi_text_encoder() {
     for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
+    if (bad_ids) (void)hipHostFree(bad_ids);
     for (int i = 0; i < kCuRing; ++i) {
       if (h_cu[i]) (void)hipHostFree(h_cu[i]);
       if (cu_ev[i]) (void)hipEventDestroy(cu_ev[i]);
@@ -310,6 +315,16 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     return fail(SMI_ERR_INVALID_ARG, "seq_len %d exceeds max_seq_len %d of the encoder", s,
                 c.max_seq_len);
   hipStream_t stream = (hipStream_t)stream_v;
+  if (!e->bad_ids) {
+    HIP_TRY(hipHostMalloc((void**)&e->bad_ids, sizeof(int32_t), hipHostMallocMapped));
+    *e->bad_ids = 0;
+    HIP_TRY(hipHostGetDevicePointer((void**)&e->bad_ids_dev, e->bad_ids, 0));
+  }
+  if (*(volatile int32_t*)e->bad_ids) {
+    *e->bad_ids = 0;
+    return fail(SMI_ERR_INVALID_ARG, "an earlier batch held token ids outside [0, %lld) (vocabulary / tokenizer mismatch)",
+                (long long)c.vocab_size);
+  }
 
   if (int rc = ensure_cu(e, n)) return rc;
   const int slot = e->cu_next;
@@ -355,7 +370,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     HIP_TRY(hipMemsetAsync((char*)x + (size_t)total * d * xes, 0, (size_t)(rows - total) * d * xes, stream));
   { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
-                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream, x16)); }
+                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream, x16, e->bad_ids_dev)); }
   // x (residual stream, fp32 or fp16 with SMI_ENC_FP16_RESIDUAL) stays row-major; h, qkv, ctx, ffn and the weights are tile-major
   const int tm = e->tile_major;
   const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
@@ -383,6 +398,17 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
                          out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream, x16)); }
+  return SMI_OK;
+}
+
+int smi_text_encoder_status(smi_text_encoder* e, void* stream) {
+  if (!e) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  if (e->bad_ids && *(volatile int32_t*)e->bad_ids) {
+    *e->bad_ids = 0;
+    return fail(SMI_ERR_INVALID_ARG, "token ids outside [0, %lld) reached the encoder (vocabulary / tokenizer mismatch)",
+                (long long)e->cfg.vocab_size);
+  }
   return SMI_OK;
 }
 

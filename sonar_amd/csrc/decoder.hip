@@ -439,6 +439,7 @@ struct BeamState {
   int32_t* fin_len;    // [n][beam]
   float* fin_score;    // [n][beam]
   int32_t* fin_count;  // [n]
+  float* margins;      // [n][2] smallest decision gap so far: {step candidates (log-prob), final ranking}
 };
 
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logits,
@@ -650,6 +651,33 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
       }
       f_n = nf;
       st.fin_count[s] = cnt;
+      if (st.margins) {
+        // decision margin of this step: the smallest gap between neighbours of the sorted candidate
+        // list up to (and including) the first candidate that is NOT consumed.  For beam 1 this is
+        // the greedy top-1 / top-2 log-prob margin.  A parity test may excuse a token mismatch
+        // only where this measured margin is below its stated epsilon.
+        int last = nsel - 1;
+        if (finished_all) {  // nothing after the hypothesis that completed the beam matters
+          int c2 = f_base;
+          for (int i = 0; i < nsel && i < beam; ++i)
+            if (tt[i] == eos_idx && ++c2 == beam) {
+              last = i;
+              break;
+            }
+        } else {
+          int taken = 0;
+          for (int i = 0; i < nsel; ++i) {
+            if (tt[i] == eos_idx) continue;
+            if (++taken == beam) {
+              last = i;
+              break;
+            }
+          }
+        }
+        float g = st.margins[2 * s];
+        for (int i = 0; i <= last && i + 1 < nsel; ++i) g = fminf(g, tv[i] - tv[i + 1]);
+        st.margins[2 * s] = g;
+      }
       if (finished_all) {
         st.done[s] = 1;
         atomicAdd(st.ndone, 1);
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
 
 hipError_t launch_beam_step(const BeamStepArgs& a, hipStream_t stream) {
   BeamState st{a.tok, a.cum, a.nactive, a.done, a.ndone, a.parent, a.new_tok, a.new_cum,
-               a.hist, a.fin_tok, a.fin_len, a.fin_score, a.fin_count};
+               a.hist, a.fin_tok, a.fin_len, a.fin_score, a.fin_count, a.margins};
   hipLaunchKernelGGL(beam_step_kernel, dim3(a.n), dim3(256), 0, stream, st, a.logits, a.ldl, a.pmax,
                      a.psum, a.pval, a.pidx, a.nchunks, a.beam, a.k2, a.pos, a.prompt_len, a.forced_tok,
                      a.max_len, a.inv_temp, a.len_penalty, a.normalize, a.eos_idx, a.hist_stride);
@@ -743,7 +771,7 @@ hipError_t launch_beam_reorder(const int32_t* parent, const int32_t* new_tok, co
 // ------------------------------------------------------------------------- small helpers
 __global__ void beam_init_kernel(int32_t* tok, float* cum, int32_t* nactive, int32_t* done,
                                  int32_t* ndone, int32_t* fin_count, int32_t* hist, int32_t* anc,
-                                 int rows, int n, int stride, int first_tok) {
+                                 float* margins, int rows, int n, int stride, int first_tok) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < rows) {
     tok[i] = first_tok;
@@ -755,16 +783,17 @@ __global__ void beam_init_kernel(int32_t* tok, float* cum, int32_t* nactive, int
     nactive[i] = 1;
     done[i] = 0;
     fin_count[i] = 0;
+    if (margins) margins[2 * i] = margins[2 * i + 1] = INFINITY;
   }
   if (i == 0) *ndone = 0;
 }
 
 hipError_t launch_beam_init(int32_t* tok, float* cum, int32_t* nactive, int32_t* done, int32_t* ndone,
-                            int32_t* fin_count, int32_t* hist, int32_t* anc, int rows, int n, int stride,
-                            int first_tok, hipStream_t stream) {
+                            int32_t* fin_count, int32_t* hist, int32_t* anc, float* margins, int rows, int n,
+                            int stride, int first_tok, hipStream_t stream) {
   const int total = rows > n ? rows : n;
   hipLaunchKernelGGL(beam_init_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, tok, cum, nactive,
-                     done, ndone, fin_count, hist, anc, rows, n, stride, first_tok);
+                     done, ndone, fin_count, hist, anc, margins, rows, n, stride, first_tok);
   return hipGetLastError();
 }
 
@@ -772,7 +801,8 @@ hipError_t launch_beam_init(int32_t* tok, float* cum, int32_t* nactive, int32_t*
 __global__ void beam_output_kernel(const int32_t* __restrict__ fin_tok, const int32_t* __restrict__ fin_len,
                                    const float* __restrict__ fin_score, const int32_t* __restrict__ fin_count,
                                    int beam, int stride, int out_stride, int32_t* __restrict__ out_tok,
-                                   int32_t* __restrict__ out_len, float* __restrict__ out_score) {
+                                   int32_t* __restrict__ out_len, float* __restrict__ out_score,
+                                   float* __restrict__ margins) {
   __shared__ int order[8];
   const int s = blockIdx.x;
   const int cnt = fin_count[s];
@@ -784,6 +814,8 @@ __global__ void beam_output_kernel(const int32_t* __restrict__ fin_tok, const in
         order[b] = order[b - 1];
         order[b - 1] = t;
       }
+    // gap between the returned hypothesis and the runner-up (normalised-score units)
+    if (margins && cnt >= 2) margins[2 * s + 1] = fin_score[s * beam + order[0]] - fin_score[s * beam + order[1]];
   }
   __syncthreads();
   for (int h = 0; h < beam; ++h) {
@@ -809,9 +841,10 @@ __global__ void beam_output_kernel(const int32_t* __restrict__ fin_tok, const in
 
 hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, const float* fin_score,
                               const int32_t* fin_count, int n, int beam, int stride, int out_stride,
-                              int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream) {
+                              int32_t* out_tok, int32_t* out_len, float* out_score, float* margins,
+                              hipStream_t stream) {
   hipLaunchKernelGGL(beam_output_kernel, dim3(n), dim3(128), 0, stream, fin_tok, fin_len, fin_score,
-                     fin_count, beam, stride, out_stride, out_tok, out_len, out_score);
+                     fin_count, beam, stride, out_stride, out_tok, out_len, out_score, margins);
   return hipGetLastError();
 }
 

@@ -35,6 +35,8 @@ struct smi_text_decoder {
   DevBuf pmax, psum, pval, pidx;
   DevBuf tile_max, tile_sum;  // logits-GEMM tile statistics [rows_pad][vocab_pad / 256]
   DevBuf zero_cc;
+  DevBuf margins;       // [n][2] decision margins of the last generate() call
+  int margins_n = 0;
   int64_t weight_bytes = 0;
   int kv_positions = 0;  // positions per layer in the current kv allocation
   int ffn_tile_major = 0;  // FFN weights stored tile-major (d, f multiples of 256)
@@ -138,9 +140,20 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * 2));
   HIP_TRY(D->logits.reserve((size_t)rows_pad * D->vocab_pad * 4));
   HIP_TRY(D->parts.reserve((size_t)8 * rows_pad * d * 4));
-  // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM)
-  HIP_TRY(D->kv.reserve((size_t)c.num_layers * positions * rows_pad * 3 * d * 2));
-  D->kv_positions = positions;
+  // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM).
+  // `positions` may be smaller than the generation cap: grow_kv() extends the cache when a call
+  // actually decodes that far (the cap is max_seq_len = 512 for sentence vectors, fairseq2's
+  // a * source_len + b rule; typical outputs stop after a few dozen tokens).
+  {
+    const size_t per_pos = (size_t)c.num_layers * rows_pad * 3 * d * 2;
+    const int have = per_pos ? (int)std::min<size_t>(D->kv.bytes / per_pos, (size_t)c.max_seq_len) : 0;
+    if (have >= positions) {
+      D->kv_positions = have;
+    } else {
+      HIP_TRY(D->kv.reserve(per_pos * positions));
+      D->kv_positions = positions;
+    }
+  }
   if (D->x.bytes + D->h.bytes + D->ctx.bytes + D->ffn.bytes != before) {
     // tile-padding rows are read by the GEMMs: keep them finite
     HIP_TRY(hipMemset(D->x.p, 0, D->x.bytes));
@@ -150,6 +163,26 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   }
   return SMI_OK;
 }
+
+// the decode loop reached the end of the kv allocation: move the slabs written so far into a cache
+// with room for `positions` positions per layer (layout [layer][position][rows_pad][3d])
+int grow_kv(smi_text_decoder* D, int rows_pad, int positions, hipStream_t stream) {
+  const smi_text_decoder_config& c = D->cfg;
+  const size_t slab = (size_t)rows_pad * 3 * c.model_dim * 2;  // bytes per (layer, position)
+  const int old_p = D->kv_positions;
+  if (positions <= old_p) return SMI_OK;
+  DevBuf bigger;
+  HIP_TRY(bigger.alloc((size_t)c.num_layers * positions * slab));
+  for (int l = 0; l < c.num_layers; ++l)
+    HIP_TRY(hipMemcpyAsync((char*)bigger.p + (size_t)l * positions * slab, (char*)D->kv.p + (size_t)l * old_p * slab,
+                           (size_t)old_p * slab, hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  D->kv = std::move(bigger);
+  D->kv_positions = positions;
+  return SMI_OK;
+}
+
+constexpr int kKvInitialPositions = 160;
 
 }  // namespace
 
@@ -298,7 +331,7 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   const int rows_pad = (int)round_up(rows, 256), n_pad = (int)round_up(n, 256);
   const int stride = c.max_seq_len + 1;
   const int k2 = 2 * beam;
-  if (int rc = ensure_step_workspace(D, rows_pad, max_len)) return rc;
+  if (int rc = ensure_step_workspace(D, rows_pad, std::min(max_len, kKvInitialPositions))) return rc;
   HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
   HIP_TRY(D->cum.reserve((size_t)rows * 4));
   HIP_TRY(D->parent.reserve((size_t)rows * 4));
@@ -308,6 +341,8 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   HIP_TRY(D->done.reserve((size_t)n * 4));
   HIP_TRY(D->ndone.reserve(4));
   HIP_TRY(D->fin_count.reserve((size_t)n * 4));
+  HIP_TRY(D->margins.reserve((size_t)n * 2 * 4));
+  D->margins_n = n;
   HIP_TRY(D->fin_len.reserve((size_t)rows * 4));
   HIP_TRY(D->fin_score.reserve((size_t)rows * 4));
   HIP_TRY(D->fin_tok.reserve((size_t)rows * stride * 4));
@@ -326,7 +361,8 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   if (int rc = compute_cross_constants(D, emb, emb_dtype, n, n_pad, stream)) return rc;
   HIP_TRY(launch_beam_init(D->tok.as<int32_t>(), D->cum.as<float>(), D->nactive.as<int32_t>(),
                            D->done.as<int32_t>(), D->ndone.as<int32_t>(), D->fin_count.as<int32_t>(),
-                           D->hist[0].as<int32_t>(), D->anc[0].as<int32_t>(), rows, n, stride, (int)prompt[0], stream));
+                           D->hist[0].as<int32_t>(), D->anc[0].as<int32_t>(), D->margins.as<float>(), rows, n, stride,
+                           (int)prompt[0], stream));
   const float inv_temp = 1.0f / bp->temperature;
 
   // everything one decode step enqueues (position pos; ancestry/history buffer pos & 1)
@@ -349,6 +385,7 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
     a.parent = D->parent.as<int32_t>(); a.new_tok = D->new_tok.as<int32_t>(); a.new_cum = D->new_cum.as<float>();
     a.hist = D->hist[cur].as<int32_t>(); a.fin_tok = D->fin_tok.as<int32_t>(); a.fin_len = D->fin_len.as<int32_t>();
     a.fin_score = D->fin_score.as<float>(); a.fin_count = D->fin_count.as<int32_t>();
+    a.margins = D->margins.as<float>();
     a.logits = D->logits.as<float>(); a.ldl = (int)D->vocab_pad;
     a.pmax = D->pmax.as<float>(); a.psum = D->psum.as<float>(); a.pval = D->pval.as<float>(); a.pidx = D->pidx.as<int>();
     a.nchunks = 1; a.n = n; a.beam = beam; a.k2 = k2; a.pos = pos; a.prompt_len = prompt_len;
@@ -369,6 +406,8 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   // launch cost, so plain launches stay; fewer, fatter kernels are the lever.  DESIGN.md 3.4.)
   for (int pos = 0; pos + 1 < max_len; ++pos) {
     const int step_nr = pos + 1;
+    if (pos >= D->kv_positions)
+      if (int rc = grow_kv(D, rows_pad, std::min(max_len, 2 * D->kv_positions), stream)) return rc;
     if (int rc = enqueue_step(pos, stream)) return rc;
     // every 8 steps: has every sentence collected its `beam` hypotheses?
     const bool force_eos = step_nr >= prompt_len && step_nr == max_len - 1;
@@ -381,7 +420,15 @@ int smi_text_decoder_generate(smi_text_decoder* D, const void* emb, int32_t emb_
   }
   HIP_TRY(launch_beam_output(D->fin_tok.as<int32_t>(), D->fin_len.as<int32_t>(), D->fin_score.as<float>(),
                              D->fin_count.as<int32_t>(), n, beam, stride, max_len, out_tokens, out_lens, out_scores,
-                             stream));
+                             D->margins.as<float>(), stream));
+  return SMI_OK;
+}
+
+int smi_text_decoder_last_margins(smi_text_decoder* D, float* out_margins, int32_t n, void* stream_v) {
+  if (!D || !out_margins) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (n <= 0 || n != D->margins_n || !D->margins.p)
+    return fail(SMI_ERR_INVALID_ARG, "n=%d does not match the last generate() call (%d sentences)", n, D->margins_n);
+  HIP_TRY(hipMemcpyAsync(out_margins, D->margins.p, (size_t)n * 2 * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream_v));
   return SMI_OK;
 }
 
@@ -414,7 +461,7 @@ int smi_text_decoder_sample(smi_text_decoder* D, const void* emb, int32_t emb_dt
   // one hypothesis per sentence (fairseq2 num_gens = 1): rows = sentences, identity ancestry
   const int rows_pad = (int)round_up(n, 256), n_pad = rows_pad;
   const int stride = c.max_seq_len + 1;
-  if (int rc = ensure_step_workspace(D, rows_pad, max_len)) return rc;
+  if (int rc = ensure_step_workspace(D, rows_pad, std::min(max_len, kKvInitialPositions))) return rc;
   HIP_TRY(D->tok.reserve((size_t)rows_pad * 4));
   HIP_TRY(D->cum.reserve((size_t)n * 4));
   HIP_TRY(D->done.reserve((size_t)n * 4));
@@ -440,6 +487,8 @@ int smi_text_decoder_sample(smi_text_decoder* D, const void* emb, int32_t emb_dt
 
   for (int pos = 0; pos + 1 < max_len; ++pos) {
     const int step_nr = pos + 1;
+    if (pos >= D->kv_positions)
+      if (int rc = grow_kv(D, rows_pad, std::min(max_len, 2 * D->kv_positions), stream)) return rc;
     if (int rc = decoder_step(D, n, rows_pad, 1, n_pad, pos, D->anc[0].as<int32_t>(), stride, stream)) return rc;
     const bool forced_prompt = step_nr < prompt_len;
     const bool force_eos = !forced_prompt && step_nr == max_len - 1;

@@ -457,12 +457,12 @@ extern "C" int smi_debug_gemm_trace(unsigned long long* host_out) {
 #endif
 
 static int num_cus() {
-  static int n = 0;
+  static std::atomic<int> cached[64];
+  const int dev = DeviceOnce::dev();
+  int n = cached[dev].load(std::memory_order_relaxed);
   if (n == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
   }
   return n;
 }
@@ -471,12 +471,12 @@ template <int EPI, int LAYOUT>
 static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
                                 int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr,
                                 int ksplit = 1, size_t part_stride = 0) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G2_KERNEL_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.set();
   }
   const int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
@@ -488,12 +488,12 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
 template <int EPI, int LAYOUT = 0>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI, LAYOUT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.set();
   }
   const int grid = (M / GT_BM) * (N / GT_BN);
   hipLaunchKernelGGL((gemm_tn_kernel<EPI, LAYOUT>), dim3(grid, ksplit), dim3(GT_THREADS), GT_LDS_BYTES,

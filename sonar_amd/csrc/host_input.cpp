@@ -117,4 +117,102 @@ int smi_host_collate_nllb(const int32_t* pieces, const int64_t* piece_offsets, c
   return SMI_OK;
 }
 
+// ---- RIFF / WAVE decoding (the reference decodes audio with fairseq2n's libsndfile AudioDecoder,
+// sonar/inference_pipelines/speech.py:292-308; this covers the WAV container: PCM 8/16/24/32-bit,
+// IEEE float 32/64, WAVE_FORMAT_EXTENSIBLE, any channel count).  Pure byte work on the host.
+namespace {
+struct WavFmt {
+  int format = 0, channels = 0, bits = 0, block_align = 0;
+  int64_t rate = 0, data_off = -1, data_bytes = 0;
+};
+inline uint32_t rd32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+int parse_wav(const uint8_t* b, int64_t n, WavFmt& f) {
+  if (n < 12 || memcmp(b, "RIFF", 4) || memcmp(b + 8, "WAVE", 4)) return fail(SMI_ERR_INVALID_ARG, "not a RIFF/WAVE file");
+  int64_t p = 12;
+  bool have_fmt = false;
+  while (p + 8 <= n) {
+    const uint32_t sz = rd32(b + p + 4);
+    const uint8_t* c = b + p + 8;
+    if (!memcmp(b + p, "fmt ", 4)) {
+      if (sz < 16 || p + 8 + 16 > n) return fail(SMI_ERR_INVALID_ARG, "truncated fmt chunk");
+      f.format = rd16(c);
+      f.channels = rd16(c + 2);
+      f.rate = rd32(c + 4);
+      f.block_align = rd16(c + 12);
+      f.bits = rd16(c + 14);
+      if (f.format == 0xFFFE) {  // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the real tag
+        if (sz < 40 || p + 8 + 40 > n) return fail(SMI_ERR_INVALID_ARG, "truncated extensible fmt chunk");
+        f.format = rd16(c + 24);
+      }
+      have_fmt = true;
+    } else if (!memcmp(b + p, "data", 4)) {
+      f.data_off = p + 8;
+      f.data_bytes = std::min<int64_t>(sz, n - (p + 8));  // streamed files may carry a bogus size
+      break;
+    }
+    p += 8 + (int64_t)sz + (sz & 1);
+  }
+  if (!have_fmt || f.data_off < 0) return fail(SMI_ERR_INVALID_ARG, "WAV file without fmt/data chunk");
+  if (f.channels <= 0 || f.bits <= 0 || f.bits % 8) return fail(SMI_ERR_UNSUPPORTED, "WAV: %d channels, %d bits", f.channels, f.bits);
+  const bool pcm = f.format == 1 && (f.bits == 8 || f.bits == 16 || f.bits == 24 || f.bits == 32);
+  const bool flt = f.format == 3 && (f.bits == 32 || f.bits == 64);
+  if (!pcm && !flt) return fail(SMI_ERR_UNSUPPORTED, "WAV format tag %d with %d bits is not covered (PCM / IEEE float only)", f.format, f.bits);
+  const int frame_bytes = f.channels * (f.bits / 8);
+  if (f.block_align < frame_bytes) f.block_align = frame_bytes;
+  return SMI_OK;
+}
+}  // namespace
+
+// channels / sample_rate / frames of a WAV file image
+int smi_host_wav_info(const uint8_t* bytes, int64_t nbytes, int32_t* channels, int32_t* sample_rate, int64_t* frames) {
+  if (!bytes || !channels || !sample_rate || !frames) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  WavFmt f;
+  if (int rc = parse_wav(bytes, nbytes, f)) return rc;
+  *channels = f.channels;
+  *sample_rate = (int32_t)f.rate;
+  *frames = f.data_bytes / f.block_align;
+  return SMI_OK;
+}
+
+// out: float32 [frames, channels] (file order, channel-last as fairseq2's AudioDecoder returns it),
+// integer PCM scaled to [-1, 1) by 2^-(bits-1) as libsndfile does for float reads.
+int smi_host_wav_decode(const uint8_t* bytes, int64_t nbytes, float* out, int64_t frames, int32_t channels) {
+  if (!bytes || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  WavFmt f;
+  if (int rc = parse_wav(bytes, nbytes, f)) return rc;
+  if (channels != f.channels || frames != f.data_bytes / f.block_align)
+    return fail(SMI_ERR_INVALID_ARG, "frames/channels do not match smi_host_wav_info");
+  const int bps = f.bits / 8;
+  const uint8_t* d = bytes + f.data_off;
+  for (int64_t i = 0; i < frames; ++i) {
+    const uint8_t* fr = d + i * f.block_align;
+    for (int c = 0; c < channels; ++c) {
+      const uint8_t* s = fr + c * bps;
+      float v;
+      if (f.format == 3) {
+        if (bps == 4) {
+          memcpy(&v, s, 4);
+        } else {
+          double dv;
+          memcpy(&dv, s, 8);
+          v = (float)dv;
+        }
+      } else if (bps == 1) {
+        v = ((int)s[0] - 128) * (1.0f / 128.0f);
+      } else if (bps == 2) {
+        v = (int16_t)rd16(s) * (1.0f / 32768.0f);
+      } else if (bps == 3) {
+        const int32_t x = (int32_t)((uint32_t)s[0] << 8 | (uint32_t)s[1] << 16 | (uint32_t)s[2] << 24) >> 8;
+        v = x * (1.0f / 8388608.0f);
+      } else {
+        v = (float)((double)(int32_t)rd32(s) * (1.0 / 2147483648.0));
+      }
+      out[i * channels + c] = v;
+    }
+  }
+  return SMI_OK;
+}
+
 }  // extern "C"

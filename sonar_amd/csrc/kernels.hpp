@@ -4,6 +4,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+namespace smi {
+// one-time per-DEVICE initialisation flag (function attributes, device-resident constants): a process
+// may drive several GPUs, so a plain `static bool` would skip the set-up on every device but the first
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  static int dev() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+  }
+  bool done() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1ull; }
+  void set() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
+};
+}  // namespace smi
+
 namespace smi {
 
 typedef _Float16 f16;
@@ -41,7 +58,8 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
 // x_f16: the residual stream x is fp16 (SMI_ENC_FP16_RESIDUAL) instead of fp32
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu_seqlens, const f16* table,
                              const float* pos_table, float scale, int pos_offset, void* x, int N,
-                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16 = 0);
+                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16 = 0,
+                             int32_t* bad = nullptr);
 
 // h[r,:] = f16(LN(x[r,:]) * w + b)
 // out_tm: h is written tile-major (rows rounded up to 256 must be allocated)
@@ -95,6 +113,7 @@ struct BeamStepArgs {
   int32_t* tok; float* cum; int32_t* nactive; int32_t* done; int32_t* ndone;
   int32_t* parent; int32_t* new_tok; float* new_cum;
   const int32_t* hist; int32_t* fin_tok; int32_t* fin_len; float* fin_score; int32_t* fin_count;
+  float* margins;  // [n][2] or null
   const float* logits; int ldl;
   const float* pmax; const float* psum; const float* pval; const int* pidx; int nchunks;
   int n, beam, k2, pos, prompt_len, forced_tok, max_len;
@@ -106,11 +125,12 @@ hipError_t launch_beam_reorder(const int32_t* parent, const int32_t* new_tok, co
                                int32_t* tok, float* cum, int rows, int stride, int pos,
                                hipStream_t stream);
 hipError_t launch_beam_init(int32_t* tok, float* cum, int32_t* nactive, int32_t* done, int32_t* ndone,
-                            int32_t* fin_count, int32_t* hist, int32_t* anc, int rows, int n, int stride,
-                            int first_tok, hipStream_t stream);
+                            int32_t* fin_count, int32_t* hist, int32_t* anc, float* margins, int rows, int n,
+                            int stride, int first_tok, hipStream_t stream);
 hipError_t launch_beam_output(const int32_t* fin_tok, const int32_t* fin_len, const float* fin_score,
                               const int32_t* fin_count, int n, int beam, int stride, int out_stride,
-                              int32_t* out_tok, int32_t* out_len, float* out_score, hipStream_t stream);
+                              int32_t* out_tok, int32_t* out_len, float* out_score, float* margins,
+                              hipStream_t stream);
 hipError_t launch_gather_tokens(const int64_t* src, int src_stride, int col, int32_t* tok, int rows,
                                 hipStream_t stream);
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
                                                          const float* __restrict__ pos_table,
                                                          float scale, int pos_offset,
                                                          XT* __restrict__ x, int S, int d,
-                                                         int64_t vocab) {
+                                                         int64_t vocab, int32_t* __restrict__ bad) {
   const int n = blockIdx.x;
   const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -33,7 +33,10 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
   const int len = cu[n + 1] - start;
   if (p >= len) return;
   int64_t tok = ids[(size_t)n * S + p];
-  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);  // never read out of the table
+  if (tok < 0 || tok >= vocab) {  // the reference's embedding lookup raises: report, never read out of the table
+    if (bad && lane == 0) *bad = 1;
+    tok = tok < 0 ? 0 : vocab - 1;
+  }
   const f16* e = table + (size_t)tok * d;
   const float* pe = pos_table + (size_t)(p + pos_offset) * d;
   XT* o = x + (size_t)(start + p) * d;
@@ -65,15 +68,16 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
 
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* table,
                              const float* pos_table, float scale, int pos_offset, void* x, int N,
-                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16) {
+                             int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16,
+                             int32_t* bad) {
   if (d % 8 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(N, (max_len + 3) / 4);
   if (x_f16)
     hipLaunchKernelGGL(embed_pack_kernel<f16>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (f16*)x, S, d, vocab);
+                       pos_offset, (f16*)x, S, d, vocab, bad);
   else
     hipLaunchKernelGGL(embed_pack_kernel<float>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (float*)x, S, d, vocab);
+                       pos_offset, (float*)x, S, d, vocab, bad);
   return hipGetLastError();
 }
 

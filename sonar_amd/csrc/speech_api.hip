@@ -5,6 +5,7 @@
 // semantics per SURVEY a27-a29 (fairseq2 ~=0.4).
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "api_common.hpp"
@@ -73,12 +74,15 @@ struct FbankConsts {
   DevBuf window, mel_w, mel_range;
   bool ready = false;
 };
+// one set per device (a process may run engines on several GPUs); creation is serialised
+std::mutex g_fbank_mu;
 FbankConsts& fbank_consts() {
-  static FbankConsts c;
-  return c;
+  static FbankConsts c[64];
+  return c[DeviceOnce::dev()];
 }
 
 int ensure_fbank_consts() {
+  std::lock_guard<std::mutex> lock(g_fbank_mu);
   FbankConsts& c = fbank_consts();
   if (c.ready) return SMI_OK;
   const int N = 400, NB = 80, NF = 256;

@@ -413,24 +413,24 @@ template <int K>
 static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
                            int64_t ny_pad, int d, int k, int64_t y_off, int32_t* idx, float* score,
                            void* ws, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)xsim_tile_kernel<K>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_done.set();
   }
   float* ps = (float*)ws;
   hipError_t e;
   int nchunks;
   if constexpr (K <= 4) {
     // 256x256 tiles, continuous slice stream
-    static bool attr256_done = false;
-    if (!attr256_done) {
+    static DeviceOnce attr256_done;
+    if (!attr256_done.done()) {
       e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
       if (e != hipSuccess) return e;
-      attr256_done = true;
+      attr256_done.set();
     }
     const int ntx = (int)(nx_pad / G2_BM), nty = (int)(ny_pad / G2_BN);
     nchunks = xsim_chunks(nty);

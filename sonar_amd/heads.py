@@ -84,6 +84,9 @@ class _MlpHead:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
+        # an index-less "cuda" means the CURRENT device (as the text / speech engines resolve it)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
         self.input_dim = input_dim
         self.out_dim = int(layers[-1][0].shape[0])
         n = len(layers)
@@ -98,7 +101,7 @@ class _MlpHead:
         cfg = _lib.smi_mlp_head_config(input_dim, n, hidden_act, out_act)
         self._handle = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.smi_init(self.device.index or 0))
+            _lib.check(self.lib.smi_init(self.device.index))
             _lib.check(self.lib.smi_mlp_head_create(C.byref(cfg), arr, C.byref(self._handle)))
 
     def __del__(self):
@@ -138,7 +141,10 @@ class _MlpHead:
 
 def _unwrap(checkpoint) -> Mapping[str, torch.Tensor]:
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        from .cards import resolve_checkpoint
+
+        path, _ = resolve_checkpoint(checkpoint, "")  # card names resolve under $SONAR_CHECKPOINT_DIR
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
     if "model" in checkpoint and isinstance(checkpoint["model"], Mapping):  # blaser/handler.py:40-45
         return checkpoint["model"]
     return checkpoint
@@ -195,6 +201,8 @@ class MutoxClassifier(torch.nn.Module):
 
 def load_blaser_model(checkpoint, arch: str = "basic_ref", device="cuda:0",
                       config: Optional[BlaserConfig] = None) -> BlaserModel:
+    if isinstance(checkpoint, str) and checkpoint in ("blaser_2_0_ref", "blaser_2_0_qe"):
+        arch = "basic_ref" if checkpoint.endswith("ref") else "basic_qe"
     return BlaserModel(config or get_blaser_config(arch), checkpoint, device)
 
 

@@ -95,13 +95,19 @@ def iter_text_batches(texts: Sequence[str], order: Sequence[int], encoder, *, ma
                                              _ptr(suffix), len(suffix), 1, pad_idx, C.c_void_p(stage.data_ptr()),
                                              s_max, threads))
         seqs = stage.view(nb, s_max).to(device, non_blocking=True)
+        ready = None
         if device.type != "cuda":
             seqs = seqs.clone()  # the staging slot is reused
+        else:
+            # this runs on the prefetch thread (its own current stream); the consumer's stream waits for
+            # the copy through this event before the model reads `seqs`
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
         ring.copied(slot)
         bl = torch.from_numpy(lens[b0:b1].copy())
         if bool((bl != s_max).any()):
-            return SequenceBatch(seqs, PaddingMask(bl, s_max))
-        return SequenceBatch(seqs, None)
+            return SequenceBatch(seqs, PaddingMask(bl, s_max), ready)
+        return SequenceBatch(seqs, None, ready)
 
     order = list(order)
     for c0 in range(0, len(order), chunk):

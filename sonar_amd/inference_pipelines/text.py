@@ -117,7 +117,9 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
             encoder = load_sonar_text_encoder(str(encoder), device=device, dtype=dtype or torch.float16)
         if isinstance(tokenizer, (str, Path)):
-            tokenizer = NllbTokenizer(tokenizer)
+            from ..cards import resolve_tokenizer
+
+            tokenizer = NllbTokenizer(resolve_tokenizer(tokenizer))
         self.tokenizer = tokenizer
         self.model = encoder.eval()
         self.device = getattr(encoder, "device", device)
@@ -141,6 +143,11 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
             raise ValueError("`batch_size` should be strictly positive")
 
         tokenizer_encoder = self.tokenizer.create_encoder(lang=source_lang)
+        model_vocab = getattr(getattr(getattr(self.model, "config", None), "vocab_info", None), "size", None)
+        tok_vocab = getattr(getattr(self.tokenizer, "vocab_info", None), "size", None)
+        if model_vocab is not None and tok_vocab is not None and tok_vocab > model_vocab:
+            raise ValueError(f"the tokenizer's vocabulary ({tok_vocab}) is larger than the encoder's embedding "
+                             f"table ({model_vocab}): tokenizer and model do not belong together")
         model_max_len = self.model.encoder_frontend.pos_encoder.max_seq_len
         if max_seq_len is None:
             max_seq_len = model_max_len
@@ -196,6 +203,9 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
                 out = self.model(batch)
                 results.append(out.sentence_embeddings.to(target_device or self.device))
 
+        engine = getattr(self.model, "engine", None)
+        if engine is not None and hasattr(engine, "check"):
+            engine.check()  # out-of-vocabulary ids raise IndexError here, as the reference's embedding does
         n_truncated += stats["n_truncated"]
         if n_truncated:
             warnings.warn(f"For {n_truncated} input tensors for SONAR text encoder, "
@@ -226,7 +236,9 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
             decoder = load_sonar_text_decoder(str(decoder), device=device, dtype=dtype or torch.float16)
         if isinstance(tokenizer, (str, Path)):
-            tokenizer = NllbTokenizer(tokenizer)
+            from ..cards import resolve_tokenizer
+
+            tokenizer = NllbTokenizer(resolve_tokenizer(tokenizer))
         self.tokenizer = tokenizer
         self.model = decoder.eval()
         self.device = getattr(decoder, "device", device)
@@ -283,7 +295,16 @@ class TextToTextModelPipeline(torch.nn.Module):
         batches: Iterable = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
         if progress_bar:
             batches = add_progress_bar(batches, inputs=texts, batch_size=batch_size)
+        enc = self.tokenizer.create_encoder(lang=source_lang)
         for chunk in batches:
             emb = self.t2vec.predict(chunk, source_lang=source_lang, batch_size=len(chunk))
-            out.extend(self.vec2t.predict(emb, target_lang=target_lang, batch_size=len(chunk), **generator_kwargs))
+            # fairseq2's generator caps the output at a * max_source_len + b tokens, the source length
+            # being the longest tokenised source of the batch the translator built (text.py:109-120)
+            if hasattr(enc, "encode_batch"):
+                src_len = max(len(t) for t in enc.encode_batch(chunk))
+            else:
+                src_len = max(len(enc(t)) for t in chunk)
+            src_len = min(src_len, self.t2vec.model.encoder_frontend.pos_encoder.max_seq_len)
+            out.extend(self.vec2t.predict(emb, target_lang=target_lang, batch_size=len(chunk),
+                                          source_len=src_len, **generator_kwargs))
         return out

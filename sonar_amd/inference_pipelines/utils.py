@@ -12,9 +12,13 @@ def extract_sequence_batch(x: dict, device) -> SequenceBatch:
     """dict{seqs [N,S], seq_lens [N], is_ragged} -> SequenceBatch on `device`;
     the padding mask is None when the batch is not ragged (utils.py:18-21)."""
     seqs = x["seqs"].to(device, non_blocking=True)
+    ready = None
+    if seqs.is_cuda:  # called on the prefetch thread: let the consumer's stream wait for the copy
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(seqs.device))
     if not x["is_ragged"]:
-        return SequenceBatch(seqs, None)
-    return SequenceBatch(seqs, PaddingMask(x["seq_lens"], seqs.shape[1]))
+        return SequenceBatch(seqs, None, ready)
+    return SequenceBatch(seqs, PaddingMask(x["seq_lens"], seqs.shape[1]), ready)
 
 
 def add_progress_bar(sequence: Iterable, inputs: Optional[Sequence] = None,

@@ -258,6 +258,27 @@ def waveform_to_fbank(waveform: torch.Tensor, waveform_scale: float = 2.0 ** 15,
     return out
 
 
+def fbank_batch_flat(cat: torch.Tensor, offsets: Sequence[int], waveform_scale: float = 2.0 ** 15,
+                     standardize: bool = True, pad_to_multiple: int = 2):
+    """`smi_fbank_batch` on clips that are already concatenated on the device: `cat` fp32 1-D, clip i =
+    cat[offsets[i]:offsets[i+1]].  Returns (fbank fp32 [n, T, 80] zero-padded, frames per clip)."""
+    if cat.device.type != "cuda":
+        raise RuntimeError("the filterbank runs on a HIP device only (no CPU path)")
+    n = len(offsets) - 1
+    if n <= 0:
+        raise ValueError("empty batch")
+    lib = _lib.load()
+    lens = [int(lib.smi_fbank_num_frames(int(offsets[i + 1] - offsets[i]))) for i in range(n)]
+    t = max(max(lens), 1)
+    t = (t + pad_to_multiple - 1) // pad_to_multiple * pad_to_multiple
+    out = torch.empty((n, t, 80), dtype=torch.float32, device=cat.device)
+    arr = (C.c_int64 * (n + 1))(*[int(o) for o in offsets])
+    with torch.cuda.device(cat.device):
+        _lib.check(lib.smi_fbank_batch(cat.data_ptr(), arr, n, float(waveform_scale), 1 if standardize else 0,
+                                       out.data_ptr(), t, _lib.current_stream_ptr()))
+    return out, lens
+
+
 def waveforms_to_fbank_batch(waveforms: Sequence[torch.Tensor], waveform_scale: float = 2.0 ** 15,
                              standardize: bool = True, pad_to_multiple: int = 2):
     """The filterbank of a whole batch in one launch, collated as the reference's
@@ -269,20 +290,11 @@ def waveforms_to_fbank_batch(waveforms: Sequence[torch.Tensor], waveform_scale: 
     if dev.type != "cuda":
         raise RuntimeError("waveforms_to_fbank_batch runs on a HIP device only (no CPU path)")
     flat = [w.reshape(-1).to(dev, torch.float32) for w in waveforms]
-    lib = _lib.load()
-    lens = [int(lib.smi_fbank_num_frames(w.numel())) for w in flat]
-    t = max(max(lens), 1)
-    t = (t + pad_to_multiple - 1) // pad_to_multiple * pad_to_multiple
     offs = [0]
     for w in flat:
         offs.append(offs[-1] + w.numel())
     cat = torch.cat(flat) if len(flat) > 1 else flat[0].contiguous()
-    out = torch.empty((len(flat), t, 80), dtype=torch.float32, device=dev)
-    arr = (C.c_int64 * len(offs))(*offs)
-    with torch.cuda.device(dev):
-        _lib.check(lib.smi_fbank_batch(cat.data_ptr(), arr, len(flat), float(waveform_scale), 1 if standardize else 0,
-                                       out.data_ptr(), t, _lib.current_stream_ptr()))
-    return out, lens
+    return fbank_batch_flat(cat, offs, waveform_scale, standardize, pad_to_multiple)
 
 
 class SonarSpeechEncoderModel:
@@ -318,6 +330,10 @@ def load_sonar_speech_encoder(checkpoint: Union[str, Mapping], arch: str = "engl
                               device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
                               config: Optional[SonarSpeechEncoderConfig] = None) -> SonarSpeechEncoderModel:
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        from .cards import resolve_checkpoint
+
+        # a card name ("sonar_speech_encoder_eng", ...) resolves under $SONAR_CHECKPOINT_DIR
+        path, arch = resolve_checkpoint(checkpoint, arch)
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
     cfg = config or get_speech_encoder_config(arch)
     return SonarSpeechEncoderModel(cfg, convert_sonar_speech_checkpoint(checkpoint), device, dtype)

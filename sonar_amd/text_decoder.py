@@ -229,22 +229,49 @@ class TextDecoderEngine:
                 prev.data_ptr(), t, out.data_ptr(), _lib.current_stream_ptr()))
         return out
 
-    def generate(self, embeddings: torch.Tensor, prompt: Sequence[int], beam_size: int = 5, min_gen_len: int = 1,
-                 max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
-                 normalize_scores: bool = True, len_penalty: float = 1.0, unk_penalty: float = 0.0,
-                 temperature: float = 1.0):
-        """Beam search with fairseq2's BeamSearchSeq2SeqGenerator defaults.
-        Returns (tokens int32 [n, beam, L] (-1 padded), lens int32 [n, beam], scores fp32 [n, beam]),
-        hypotheses best first; tokens are the generated part (after the prompt) incl. the final EOS."""
-        e = self._emb(embeddings)
-        n = e.shape[0]
-        plen = len(prompt)
+    def _length_limits(self, plen: int, min_gen_len: int, max_gen_len: Tuple[int, int],
+                       max_seq_len: Optional[int], source_len: Optional[int]) -> Tuple[int, int]:
+        """fairseq2's Seq2SeqGenerator length rule: max_gen_len = a * max_source_len + b, where
+        max_source_len is `source_seqs.size(1)` (no padding mask) or the longest source in the batch.
+        EmbeddingToTextModelPipeline hands the generator `torch.stack(embeddings)` [n, model_dim] as
+        `source_seqs` (text.py:329-333), so there the "source length" is model_dim and the cap is in
+        practice the decoder's max_seq_len; TextToText / SpeechToText pass their token / frame count."""
         model_max = max_seq_len if max_seq_len is not None else self.cfg.max_seq_len
         if model_max > self.cfg.max_seq_len:
             raise ValueError(f"max_seq_len cannot be larger than the decoder's {self.cfg.max_seq_len}")
-        gen_cap = int(max_gen_len[0] * 1 + max_gen_len[1])  # source length is 1 (one sentence vector)
+        if source_len is None:
+            source_len = self.cfg.model_dim
+        gen_cap = int(max_gen_len[0] * int(source_len) + max_gen_len[1])
+        if gen_cap < 1:
+            raise ValueError("`max_gen_len` must be greater than or equal to 1 for the given source length")
+        if min_gen_len > gen_cap:
+            raise ValueError(f"`min_gen_len` must be less than or equal to `max_gen_len` ({gen_cap}), "
+                             f"but is {min_gen_len} instead")
         max_len = min(plen + gen_cap, model_max)
-        min_len = min(plen + min_gen_len, max_len)
+        if max_len <= plen:
+            raise ValueError("`max_seq_len` leaves no room for generation after the prompt")
+        return max_len, min(plen + min_gen_len, max_len)
+
+    def last_margins(self, n: int) -> torch.Tensor:
+        """Decision margins fp32 [n, 2] of the last generate() call (smi_text_decoder_last_margins)."""
+        out = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.smi_text_decoder_last_margins(self._handle, out.data_ptr(), n,
+                                                              _lib.current_stream_ptr()))
+        return out
+
+    def generate(self, embeddings: torch.Tensor, prompt: Sequence[int], beam_size: int = 5, min_gen_len: int = 1,
+                 max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
+                 normalize_scores: bool = True, len_penalty: float = 1.0, unk_penalty: float = 0.0,
+                 temperature: float = 1.0, source_len: Optional[int] = None):
+        """Beam search with fairseq2's BeamSearchSeq2SeqGenerator defaults.
+        Returns (tokens int32 [n, beam, L] (-1 padded), lens int32 [n, beam], scores fp32 [n, beam]),
+        hypotheses best first; tokens are the generated part (after the prompt) incl. the final EOS.
+        `source_len`: see `_length_limits` (None = the sentence-vector case)."""
+        e = self._emb(embeddings)
+        n = e.shape[0]
+        plen = len(prompt)
+        max_len, min_len = self._length_limits(plen, min_gen_len, max_gen_len, max_seq_len, source_len)
         bp = _lib.smi_beam_search_params(beam_size=beam_size, max_seq_len=max_len, min_seq_len=min_len,
                                          normalize_scores=1 if normalize_scores else 0, len_penalty=len_penalty,
                                          unk_penalty=unk_penalty, temperature=temperature, reserved=0)
@@ -262,7 +289,8 @@ class TextDecoderEngine:
     def sample(self, embeddings: torch.Tensor, prompt: Sequence[int], sampler, min_gen_len: int = 1,
                max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
                normalize_scores: bool = True, len_penalty: float = 1.0, unk_penalty: float = 0.0,
-               temperature: float = 1.0, seed: Optional[int] = None, sentence_offset: int = 0):
+               temperature: float = 1.0, seed: Optional[int] = None, sentence_offset: int = 0,
+               source_len: Optional[int] = None):
         """fairseq2's SamplingSeq2SeqGenerator (one hypothesis per sentence) with a TopKSampler /
         TopPSampler (sonar_amd.generation).  Returns (tokens int32 [n, L] (-1 padded), lens int32 [n],
         scores fp32 [n]).  `seed` None draws one from torch's global CPU generator, so
@@ -276,12 +304,7 @@ class TextDecoderEngine:
         e = self._emb(embeddings)
         n = e.shape[0]
         plen = len(prompt)
-        model_max = max_seq_len if max_seq_len is not None else self.cfg.max_seq_len
-        if model_max > self.cfg.max_seq_len:
-            raise ValueError(f"max_seq_len cannot be larger than the decoder's {self.cfg.max_seq_len}")
-        gen_cap = int(max_gen_len[0] * 1 + max_gen_len[1])
-        max_len = min(plen + gen_cap, model_max)
-        min_len = min(plen + min_gen_len, max_len)
+        max_len, min_len = self._length_limits(plen, min_gen_len, max_gen_len, max_seq_len, source_len)
         if seed is None:
             seed = int(torch.randint(0, 2**62, (1,)).item())
         seed = (int(seed) + 0x9E3779B97F4A7C15 * 65536 * int(sentence_offset)) & 0xFFFFFFFFFFFFFFFF
@@ -322,6 +345,10 @@ def load_sonar_text_decoder(checkpoint: Union[str, Mapping], arch: str = "basic"
                             device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
                             config: Optional[SonarTextDecoderConfig] = None) -> ConditionalTransformerDecoderModel:
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        from .cards import resolve_checkpoint
+
+        # a card name ("text_sonar_basic_decoder", ...) resolves under $SONAR_CHECKPOINT_DIR
+        path, arch = resolve_checkpoint(checkpoint, arch)
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
     cfg = config or get_text_decoder_config(arch)
     return ConditionalTransformerDecoderModel(cfg, convert_sonar_text_decoder_checkpoint(checkpoint), device, dtype)

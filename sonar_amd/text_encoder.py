@@ -255,6 +255,14 @@ class TextEncoderEngine:
     def device_bytes(self) -> int:
         return int(self.lib.smi_text_encoder_device_bytes(self._handle))
 
+    def check(self) -> None:
+        """Synchronise the current stream and raise IndexError if a batch held out-of-vocabulary token
+        ids (the reference's embedding lookup raises there; smi_text_encoder_status)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.smi_text_encoder_status(self._handle, _lib.current_stream_ptr())
+        if rc != _lib.SMI_OK:
+            raise IndexError(self.lib.smi_last_error().decode("utf-8", "replace"))
+
     def set_profiling(self, enable: bool) -> None:
         _lib.check(self.lib.smi_text_encoder_set_profiling(self._handle, 1 if enable else 0))
 
@@ -319,6 +327,9 @@ class SequenceBatch:
 
     seqs: torch.Tensor
     padding_mask: Optional[PaddingMask]
+    # recorded after the H2D copy that produced `seqs` when that copy ran on another thread / stream;
+    # the model makes its stream wait for it before reading `seqs`
+    ready: Optional["torch.cuda.Event"] = None
 
 
 class _PosEncoderInfo:
@@ -363,6 +374,8 @@ class SonarTextTransformerEncoderModel:
     @torch.inference_mode()
     def forward(self, batch: SequenceBatch) -> SonarEncoderOutput:
         lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else None
+        if getattr(batch, "ready", None) is not None:
+            torch.cuda.current_stream(self.device).wait_event(batch.ready)
         emb, enc = self.engine.forward(batch.seqs, lens, self.dtype, self.return_encoded_seqs)
         return SonarEncoderOutput(encoded_seqs=enc, sentence_embeddings=emb, padding_mask=batch.padding_mask)
 
@@ -374,7 +387,11 @@ def load_sonar_text_encoder(checkpoint: Union[str, Mapping], arch: str = "basic"
     """hub.load() equivalent for a local checkpoint file or an in-memory dict
     (reference: sonar/inference_pipelines/text.py:161-162)."""
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        from .cards import resolve_checkpoint
+
+        # a card name ("text_sonar_basic_encoder", ...) resolves under $SONAR_CHECKPOINT_DIR
+        path, arch = resolve_checkpoint(checkpoint, arch)
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
     cfg = config or get_text_encoder_config(arch)
     sd = convert_sonar_text_encoder_checkpoint(checkpoint)
     return SonarTextTransformerEncoderModel(cfg, sd, device=device, dtype=dtype)

@@ -75,7 +75,11 @@ class NllbTokenizer:
     def decode(self, ids: Union[torch.Tensor, Sequence[int]]) -> str:
         if isinstance(ids, torch.Tensor):
             ids = ids.tolist()
-        pieces = [i - 1 for i in ids if 4 <= i < self.lang_base]  # drop control symbols
+        # control symbols (pad, bos, eos, language tokens) are dropped; <unk> (id 1 = SentencePiece
+        # piece 0) is kept: SentencePiece renders it with its unk surface (" \u2047 "), as fairseq2's
+        # decoder does
+        unk = self.vocab_info.unk_idx
+        pieces = [i - 1 for i in ids if 4 <= i < self.lang_base or i == unk]
         return self.sp.decode(pieces)
 
 

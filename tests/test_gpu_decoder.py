@@ -61,7 +61,7 @@ def test_beam_search_vs_oracle(setup, beam):
     n = 7
     emb = torch.randn(n, ocfg.model_dim, generator=g) * 0.3
     prompt = [3, 700]
-    kw = dict(beam_size=beam, max_gen_len=(1, 12))
+    kw = dict(beam_size=beam, max_gen_len=(0, 13))
     ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
     toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
     torch.cuda.synchronize()
@@ -91,10 +91,10 @@ def test_generate_is_repeatable_across_calls(setup):
     the same request gives the same hypotheses after other requests ran in between."""
     OD, ocfg, params, eng = setup
     emb = (torch.randn(6, ocfg.model_dim, generator=torch.Generator().manual_seed(77)) * 0.3).cuda()
-    kw = dict(beam_size=3, max_gen_len=(1, 10))
+    kw = dict(beam_size=3, max_gen_len=(0, 11))
     first = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
     other = [t.cpu() for t in eng.generate(emb, [3, 703], **kw)]
-    eng.generate(emb[:2], [3, 702], beam_size=5, max_gen_len=(1, 20))
+    eng.generate(emb[:2], [3, 702], beam_size=5, max_gen_len=(0, 21))
     again = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
     for a, b in zip(first, again):
         assert torch.equal(a, b)
@@ -104,7 +104,7 @@ def test_generate_is_repeatable_across_calls(setup):
 def test_beam_search_forced_eos_and_min_len(setup):
     OD, ocfg, params, eng = setup
     emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3
-    toks, lens, scores = eng.generate(emb.cuda(), [3, 701], beam_size=2, max_gen_len=(1, 3), min_gen_len=2)
+    toks, lens, scores = eng.generate(emb.cuda(), [3, 701], beam_size=2, max_gen_len=(0, 4), min_gen_len=2)
     lens = lens.cpu()
     toks = toks.cpu()
     assert toks.shape[2] == 2 + 4
@@ -139,10 +139,10 @@ def test_embedding_to_text_pipeline(setup, tmp_path):
     model = ConditionalTransformerDecoderModel(cfg, params, device="cuda:0")
     pipe = EmbeddingToTextModelPipeline(model, tok, device=torch.device("cuda:0"))
     emb = torch.randn(6, ocfg.model_dim, generator=torch.Generator().manual_seed(9)) * 0.3
-    texts = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8))
+    texts = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(0, 9))
     assert len(texts) == 6 and all(isinstance(t, str) for t in texts)
     prompt = tok.create_encoder(lang="fra_Latn", mode="target").prefix
-    ref = OD.beam_search(params, ocfg, emb, prompt, beam_size=5, max_gen_len=(1, 8))
+    ref = OD.beam_search(params, ocfg, emb, prompt, beam_size=5, max_gen_len=(0, 9))
     same = sum(texts[i] == tok.decode(ref[i][0].seq) for i in range(6))
     assert same >= 5
     with pytest.raises(NotImplementedError):
@@ -152,9 +152,9 @@ def test_embedding_to_text_pipeline(setup, tmp_path):
     from sonar_amd.generation import TopPSampler
 
     torch.manual_seed(4)
-    s1 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8), sampler=TopPSampler(0.9))
+    s1 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(0, 9), sampler=TopPSampler(0.9))
     torch.manual_seed(4)
-    s2 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(1, 8), sampler=TopPSampler(0.9))
+    s2 = pipe.predict(emb, target_lang="fra_Latn", batch_size=4, max_gen_len=(0, 9), sampler=TopPSampler(0.9))
     assert s1 == s2 and len(s1) == 6 and all(isinstance(t, str) for t in s1)
 
 
@@ -194,9 +194,9 @@ def test_text_to_text_and_speech_to_text_chain(setup, tmp_path):
     dev = torch.device("cuda:0")
     texts = ["hello world", "my name is paul", "bonjour monde"]
     t2t = TextToTextModelPipeline(enc, dec, tok, device=dev)
-    got = t2t.predict(texts, source_lang="eng_Latn", target_lang="fra_Latn", batch_size=2, max_gen_len=(1, 6))
+    got = t2t.predict(texts, source_lang="eng_Latn", target_lang="fra_Latn", batch_size=2, max_gen_len=(0, 7))
     emb = TextToEmbeddingModelPipeline(enc, tok, device=dev).predict(texts, source_lang="eng_Latn")
-    want = EmbeddingToTextModelPipeline(dec, tok, device=dev).predict(emb, target_lang="fra_Latn", max_gen_len=(1, 6))
+    want = EmbeddingToTextModelPipeline(dec, tok, device=dev).predict(emb, target_lang="fra_Latn", max_gen_len=(0, 7))
     assert got == want and len(got) == 3
 
     so = OS.OracleSpeechEncoderConfig(model_dim=256, num_layers=1, num_heads=4, ffn_inner_dim=512, conv_kernel=7,
@@ -207,5 +207,5 @@ def test_text_to_text_and_speech_to_text_chain(setup, tmp_path):
     senc = SonarSpeechEncoderModel(scfg, OS.make_synthetic_params(so, seed=5, std=0.06), device="cuda:0")
     wavs = [torch.rand(1, 16000, generator=g) * 2 - 1, torch.rand(1, 20000, generator=g) * 2 - 1]
     s2t = SpeechToTextModelPipeline(senc, dec, tok, device=dev)
-    out = s2t.predict(wavs, target_lang="eng_Latn", max_gen_len=(1, 5))
+    out = s2t.predict(wavs, target_lang="eng_Latn", max_gen_len=(0, 6))
     assert len(out) == 2 and all(isinstance(t, str) for t in out)

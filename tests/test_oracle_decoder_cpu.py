@@ -55,7 +55,7 @@ def test_beam1_equals_greedy_and_scores_are_logprobs():
     params = OD.make_synthetic_params(cfg, seed=5, std=0.25)
     emb = torch.randn(3, 64, generator=torch.Generator().manual_seed(1))
     prompt = [3, 57]
-    hyps = OD.beam_search(params, cfg, emb, prompt, beam_size=1, max_gen_len=(1, 10))
+    hyps = OD.beam_search(params, cfg, emb, prompt, beam_size=1, max_gen_len=(0, 11))
     greedy = OD.greedy_decode(params, cfg, emb, prompt, max_new=11)
     for h, g, e in zip(hyps, greedy, emb):
         m = len(h[0].seq) - 1  # the last beam token may be the forced EOS at max length
@@ -73,7 +73,7 @@ def test_beam_search_properties():
                                      max_seq_len=64)
     params = OD.make_synthetic_params(cfg, seed=6, std=0.3)
     emb = torch.randn(2, 64, generator=torch.Generator().manual_seed(2))
-    hyps = OD.beam_search(params, cfg, emb, [3, 60], beam_size=4, max_gen_len=(1, 6))
+    hyps = OD.beam_search(params, cfg, emb, [3, 60], beam_size=4, max_gen_len=(0, 7))
     for hs in hyps:
         assert len(hs) == 4
         assert all(h.seq[-1].item() == 3 for h in hs)                    # every hypothesis ends with EOS
