@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Headline benchmark: sentences/s embedded by text_sonar_basic_encoder
 (fp16, batch 1024, seq_len 128 -- BASELINE.json configs[1]) on N MI355X, plus
-xsim pairs/s, the roofline of the dominant kernel and the CPU oracle baseline.
+xsim pairs/s at BASELINE configs[2] scale (1M x 1M x 1024), the roofline of the
+dominant kernel and the CPU oracle baseline timed on the same box in the same run.
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -12,6 +13,16 @@ LayerNorm -> mean-pool) over one synthetic 1024 x 128 batch per GPU, inputs resi
 HBM; for N > 1 each rank encodes its own batch (weak scaling, sentences are independent:
 SURVEY 8(e)) and the step ends with the RCCL all-gather that assembles the embedding
 matrix.  Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
+
+Extra objects in the same line (N = 1): `varlen` (C2(b): lengths randint(16,129)), `c1`
+(BASELINE configs[0]: 32 sentences <= 64 tokens -- GPU time, CPU-oracle time and the
+1 - cos between the two on identical weights and inputs), `xsim` (+ its own
+`cpu_baseline`), `decoder` (C5), `speech` (C4).
+
+SONAR_BENCH_DRYRUN=1 swaps the engine for a CPU stub and RCCL for gloo: it exists so
+that the N > 1 control flow (process group, the all-gathers inside the timed step, the
+max-over-ranks timing, the sharded xsim leg) is executed by tests/test_bench_dryrun_cpu.py
+without GPUs.  A dry run prints "data": "dry-run stub" and is never a measurement.
 """
 from __future__ import annotations
 
@@ -29,17 +40,20 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355
 # algorithmic flops: per token per layer 8 d^2 + 4 d F + 4 S d
 FLOPS_PER_SENTENCE = SEQ * L * (8 * D * D + 4 * D * F + 4 * SEQ * D)
 FFN1_FLOPS_PER_LAUNCH = 2.0 * BATCH * SEQ * F * D  # one launch = the whole 131072-token batch
+DRYRUN = os.environ.get("SONAR_BENCH_DRYRUN") == "1"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(n_sent=96):
-    """Reference-equivalent op sequence (the oracle, kind 'port') on the host cores."""
-    import torch
+def flops_of_lengths(lens) -> float:
+    """sum_i L_i * 24 * (8 d^2 + 4 d F + 4 L_i d)."""
+    return float(sum(int(n) * L * (8 * D * D + 4 * D * F + 4 * int(n) * D) for n in lens))
 
-    from oracle import text_encoder as O
+
+def cpu_threads() -> int:
+    import torch
 
     # measured on the MI355X box's host (2 x EPYC 9575F, 256 hw threads, shared): the torch CPU
     # oracle peaks at 16 threads (6.3 sent/s) and degrades with more (1.4 sent/s at 128)
@@ -48,17 +62,58 @@ def cpu_baseline(n_sent=96):
     except AttributeError:
         avail = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(16, avail)))
+    return torch.get_num_threads()
+
+
+def best_of(fn, reps=3):
+    """warm-up 1 + best of `reps`; returns (best seconds, all timed seconds)."""
+    fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return min(ts), ts
+
+
+def cpu_baseline(params, n_sent, c1_ids, c1_lens):
+    """Reference-equivalent op sequence (the oracle, kind 'port') on the host cores, on the SAME weights
+    the GPU engine holds: a slice of the C2 batch (n_sent x 128) and the whole C1 batch."""
+    from oracle import text_encoder as O
+
+    cores = cpu_threads()
     cfg = O.OracleTextEncoderConfig()
-    t0 = time.time()
-    params = O.make_synthetic_params(cfg, seed=1234)
-    log(f"[cpu_baseline] built fp32 oracle weights in {time.time() - t0:.1f}s")
     ids, _ = O.synthetic_batch(n_sent, SEQ, SEQ, cfg.vocab_size, seed=0)
-    O.text_encoder_forward(params, cfg, ids[:2], None)  # warm-up
-    t0 = time.time()
-    O.text_encoder_forward(params, cfg, ids, None)
-    dt = time.time() - t0
-    return {"value": n_sent / dt, "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_sent} sentences x {SEQ} tokens, full 24-layer fp32 model, torch CPU oracle, 1 timed pass ({dt:.1f} s)"}
+    best, ts = best_of(lambda: O.text_encoder_forward(params, cfg, ids, None))
+    c1_out = {}
+
+    def run_c1():
+        c1_out["emb"] = O.text_encoder_forward(params, cfg, c1_ids, c1_lens)[1]
+
+    c1_best, c1_ts = best_of(run_c1)
+    return ({"value": n_sent / best, "unit": "sentences/s", "cores": cores, "kind": "port",
+             "sample": f"{n_sent} sentences x {SEQ} tokens (a slice of the C2 batch), full 24-layer fp32 model, torch CPU "
+                       f"oracle, warm-up 1 + best of 3 ({', '.join(f'{t:.1f}' for t in ts)} s)",
+             "c1": {"value": c1_ids.shape[0] / c1_best, "unit": "sentences/s", "seconds": c1_best,
+                    "sample": f"BASELINE configs[0]: {c1_ids.shape[0]} sentences, lengths randint(8,65) seed 0 "
+                              f"({int(c1_lens.sum())} tokens), fp32, warm-up 1 + best of 3"}},
+            c1_out["emb"])
+
+
+def xsim_cpu_baseline(nx=16384, ny=65536):
+    """Blocked fp32 normalise + matmul + top-1 on the host (the oracle's cosine_topk), extrapolated per pair."""
+    import torch
+
+    from oracle import xsim as OX
+
+    cores = cpu_threads()
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(ny, D, generator=g)
+    x = y[torch.randint(0, ny, (nx,), generator=g)] + 0.3 * torch.randn(nx, D, generator=g)
+    best, ts = best_of(lambda: OX.cosine_topk(x, y, 1), reps=2)
+    return {"value": nx * ny / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{nx} x {ny} x {D} fp32 slice, torch CPU blocked matmul + top-1 (oracle/xsim.py), warm-up 1 + "
+                      f"best of 2 ({', '.join(f'{t:.1f}' for t in ts)} s), extrapolated per pair"}
 
 
 def decoder_leg(dev, n=256, steps=64):
@@ -78,9 +133,11 @@ def decoder_leg(dev, n=256, steps=64):
     eng.generate(emb, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    flop_step = n * 5 * (L * (16 * D * D + 4 * D * F) + 2 * D * V)
     return {"workload": f"text_sonar_basic_decoder beam 5 fp16, batch {n}, {steps + 1} decode steps (EOS blocked), eng_Latn prompt",
             "ms": dt * 1e3, "ms_per_step": dt * 1e3 / (steps + 1), "sentences_per_s": n / dt,
-            "tokens_per_s": n * (steps + 1) / dt}
+            "tokens_per_s": n * (steps + 1) / dt,
+            "frac_of_mfma_peak": flop_step * (steps + 1) / dt / 1e12 / MFMA_PEAK_TFLOPS}
 
 
 def speech_leg(dev, n=64):
@@ -110,6 +167,53 @@ def speech_leg(dev, n=64):
             "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt}
 
 
+# ---------------------------------------------------------------------- dry-run stubs (CPU, gloo)
+class _StubEngine:
+    device_bytes = 0
+
+    def set_profiling(self, on):
+        pass
+
+    def read_profile(self):
+        return {"gemm_ffn1": {"ms": 1.0, "launches": 1}}
+
+
+class _StubModel:
+    """Stands in for SonarTextTransformerEncoderModel in a dry run: right shapes, no arithmetic."""
+
+    def __init__(self, dev):
+        self.engine = _StubEngine()
+        self.dev = dev
+
+    def __call__(self, batch):
+        import torch
+
+        from sonar_amd.text_encoder import SonarEncoderOutput
+
+        n = batch.seqs.shape[0]
+        return SonarEncoderOutput(None, torch.ones((n, D), dtype=torch.float16, device=self.dev), batch.padding_mask)
+
+
+class _StubXsim:
+    """normalize_rows / topk_normalized of sonar_amd.xsim with torch on the CPU (dry run only)."""
+
+    @staticmethod
+    def padded(n):
+        return (n + 255) // 256 * 256
+
+    def normalize_rows(self, t):
+        import torch
+
+        out = torch.zeros((self.padded(t.shape[0]), t.shape[1]), dtype=torch.float16)
+        out[: t.shape[0]] = torch.nn.functional.normalize(t.float(), dim=-1).half()
+        return out
+
+    def topk_normalized(self, xn, nx, yn, ny, k, y_index_offset=0):
+        s = xn[:nx].float() @ yn[:ny].float().T
+        v, i = s.topk(k, dim=1)
+        return v, (i + y_index_offset).int()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,10 +221,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-xsim", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the decoder (C5) and speech (C4) legs")
-    ap.add_argument("--xsim-nx", type=int, default=65536, help="X rows per rank")
-    ap.add_argument("--xsim-ny", type=int, default=1 << 20, help="total Y rows (sharded over ranks)")
-    ap.add_argument("--cpu-sentences", type=int, default=96)
+    ap.add_argument("--no-extras", action="store_true", help="skip the varlen / C1 / decoder (C5) / speech (C4) legs")
+    ap.add_argument("--xsim-n", type=int, default=1 << 20,
+                    help="rows of X and of Y IN TOTAL (BASELINE configs[2]: 1M x 1M); both are sharded over the ranks")
+    ap.add_argument("--cpu-sentences", type=int, default=32)
     ap.add_argument("--fp32-residual", action="store_true",
                     help="keep the encoder's residual stream in fp32 (default: fp16, as the reference's fp16 model)")
     args = ap.parse_args()
@@ -128,130 +232,187 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from sonar_amd import xsim
-    from sonar_amd.text_encoder import SequenceBatch, SonarTextTransformerEncoderModel, get_text_encoder_config
+    from sonar_amd.text_encoder import PaddingMask, SequenceBatch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+    batch_n, seq = (BATCH, SEQ) if not DRYRUN else (8, 16)
+    if DRYRUN:
+        dev = torch.device("cpu")
+        sync = lambda: None
+        if world > 1:
+            dist.init_process_group("gloo")
+        xs_mod = _StubXsim()
+        padded_rows = xs_mod.padded
+    else:
+        from sonar_amd import xsim as xs_mod
+
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=dev)
+        padded_rows = lambda n: int(xs_mod._lib.load().smi_xsim_padded_rows(n))
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    cfg = get_text_encoder_config("basic")
+    def max_over_ranks(seconds: float) -> float:
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, steps, warmup):
+        """`warmup` untimed calls, then exactly `steps` calls between barrier + synchronize pairs; max over ranks."""
+        for _ in range(warmup):
+            fn()
+        sync()
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        barrier()
+        sync()
+        return max_over_ranks(time.perf_counter() - t0)
+
     t0 = time.time()
-    sd = text_encoder_state_dict(dev)
-    model = SonarTextTransformerEncoderModel(cfg, sd, device=dev, dtype=torch.float16, max_tokens_hint=BATCH * SEQ,
-                                             fp16_residual=not args.fp32_residual)
-    del sd
-    torch.cuda.empty_cache()
+    if DRYRUN:
+        model, sd_cpu = _StubModel(dev), None
+    else:
+        from sonar_amd.text_encoder import SonarTextTransformerEncoderModel, get_text_encoder_config
+
+        sd = text_encoder_state_dict(dev)
+        model = SonarTextTransformerEncoderModel(get_text_encoder_config("basic"), sd, device=dev, dtype=torch.float16,
+                                                 max_tokens_hint=BATCH * SEQ, fp16_residual=not args.fp32_residual)
+        want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+        # the CPU baseline runs the SAME weights (fp16-representable values, fp32 arithmetic)
+        sd_cpu = {k: v.float().cpu() for k, v in sd.items()} if want_cpu else None
+        del sd
+        torch.cuda.empty_cache()
     log(f"[rank {rank}] engine ready in {time.time() - t0:.1f}s, {model.engine.device_bytes / 1e9:.2f} GB in HBM")
 
     g = torch.Generator(device=dev).manual_seed(100 + rank)
-    ids = torch.randint(4, 256001, (BATCH, SEQ), device=dev, generator=g)
+    ids = torch.randint(4, 256001, (batch_n, seq), device=dev, generator=g)
     ids[:, 0] = 256047  # __eng_Latn__
     ids[:, -1] = 3      # </s>
     batch = SequenceBatch(ids, None)
-    gathered = torch.empty((world * BATCH, D), dtype=torch.float16, device=dev) if world > 1 else None
+    gathered = torch.empty((world * batch_n, D), dtype=torch.float16, device=dev) if world > 1 else None
 
     def step():
         emb = model(batch).sentence_embeddings
         if world > 1:
-            dist.all_gather_into_tensor(gathered, emb)
+            dist.all_gather_into_tensor(gathered, emb)  # assemble the embedding matrix over RCCL / xGMI
         return emb
 
     for _ in range(args.warmup):
         step()
     model.engine.set_profiling(True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(step, args.steps, 0)
     model.engine.set_profiling(False)
     prof = model.engine.read_profile()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * BATCH * args.steps / elapsed
+    value = world * batch_n * args.steps / elapsed
     ffn1 = prof["gemm_ffn1"]
     ffn1_ms = ffn1["ms"] / max(ffn1["launches"], 1)
     achieved = FFN1_FLOPS_PER_LAUNCH / (ffn1_ms * 1e-3) / 1e12 if ffn1_ms > 0 else None
-    traffic = None
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("gemm_ffn1_hbm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("gemm_ffn1_hbm_bytes_per_launch")
+            traffic_src = "profiles/traffic.json (STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " + \
+                          str(tj.get("state", "r01m")) + ", not measured in this run)"
         except Exception:
             traffic = None
     roofline = {"bound": "mfma", "kernel": "gemm_tn256_kernel<EPI_RELU_F16> (FFN inner projection, M=131072 N=8192 K=1024)",
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None, "traffic": traffic,
-                "avg_launch_ms": ffn1_ms, "launches": ffn1["launches"],
+                "traffic_source": traffic_src, "avg_launch_ms": ffn1_ms, "launches": ffn1["launches"],
                 "flops_per_launch": FFN1_FLOPS_PER_LAUNCH}
     kernels = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}
 
-    # ------------------------------------------------------------ xsim leg
+    # ------------------------------------------------------------ C2(b) varlen + C1 (N = 1 only)
+    extra = {}
+    c1_gpu = None
+    if world == 1 and not args.no_extras and not DRYRUN:
+        lens = torch.randint(16, SEQ + 1, (BATCH,), generator=torch.Generator().manual_seed(0))
+        vids = ids.clone()
+        for i, n in enumerate(lens.tolist()):
+            vids[i, n - 1] = 3
+            vids[i, n:] = 0
+        vbatch = SequenceBatch(vids, PaddingMask(lens.to(torch.int32), SEQ))
+        vt = timed(lambda: model(vbatch).sentence_embeddings, args.steps, 1)
+        vflop = flops_of_lengths(lens.tolist())
+        extra["varlen"] = {"workload": "C2(b): 1024 sentences, lengths randint(16,129) seed 0, right-padded to 128 (packed on device)",
+                           "tokens": int(lens.sum()), "ms_per_step": vt / args.steps * 1e3,
+                           "sentences_per_s": BATCH * args.steps / vt, "tokens_per_s": int(lens.sum()) * args.steps / vt,
+                           "frac_of_mfma_peak": vflop * args.steps / vt / 1e12 / MFMA_PEAK_TFLOPS}
+        from oracle import text_encoder as O
+
+        c1_ids, c1_lens = O.synthetic_batch(32, 8, 64, V, seed=0)
+        c1_batch = SequenceBatch(c1_ids.to(dev), PaddingMask(c1_lens, c1_ids.shape[1]))
+        c1_t = timed(lambda: model(c1_batch).sentence_embeddings, 20, 3)
+        c1_gpu = model(c1_batch).sentence_embeddings.float().cpu()
+        extra["c1"] = {"workload": "BASELINE configs[0] on the GPU engine: 32 sentences, lengths randint(8,65) seed 0, fp16",
+                       "tokens": int(c1_lens.sum()), "ms": c1_t / 20 * 1e3, "sentences_per_s": 32 * 20 / c1_t}
+
+    # ------------------------------------------------------------ xsim leg (BASELINE configs[2])
     xs = None
     if not args.no_xsim:
-        nx = args.xsim_nx
-        ny_local = args.xsim_ny // world
+        n_total = args.xsim_n if not DRYRUN else 512 * world
+        if n_total % world:
+            raise SystemExit(f"--xsim-n {n_total} must divide over {world} ranks")
+        nloc = n_total // world
         gx = torch.Generator(device=dev).manual_seed(2 + rank)
-        y_local = torch.randn(ny_local, D, device=dev, generator=gx, dtype=torch.float32).half()
-        x_local = (y_local[torch.randint(0, ny_local, (nx,), device=dev, generator=gx)].float()
-                   + 0.3 * torch.randn(nx, D, device=dev, generator=gx)).half()
-        yn_all = torch.empty((world * int(xsim._lib.load().smi_xsim_padded_rows(ny_local)), D), dtype=torch.float16, device=dev) if world > 1 else None
+        y_local = torch.randn(nloc, D, device=dev, generator=gx, dtype=torch.float32).half()
+        x_local = (y_local[torch.randint(0, nloc, (nloc,), device=dev, generator=gx)].float()
+                   + 0.3 * torch.randn(nloc, D, device=dev, generator=gx)).half()
+        dense = nloc == padded_rows(nloc)   # equal shards of whole 256-row tiles gather into a dense layout
+        yn_all = torch.empty((world * nloc, D), dtype=torch.float16, device=dev) if world > 1 and dense else None
 
         def mine():
-            xn = xsim.normalize_rows(x_local)
-            yn = xsim.normalize_rows(y_local)
-            if world > 1:
-                dist.all_gather_into_tensor(yn_all, yn)  # assemble Y over RCCL/xGMI
-                # shards are padded to 128 rows each; equal sizes keep the gathered layout dense
-                return xsim.topk_normalized(xn, nx, yn_all, yn_all.shape[0], 1)
-            return xsim.topk_normalized(xn, nx, yn, ny_local, 1)
+            xn = xs_mod.normalize_rows(x_local)
+            yn = xs_mod.normalize_rows(y_local)
+            if world == 1:
+                return xs_mod.topk_normalized(xn, nloc, yn, nloc, 1)
+            if dense:
+                dist.all_gather_into_tensor(yn_all, yn)  # assemble Y over RCCL / xGMI (2 KB per row)
+                return xs_mod.topk_normalized(xn, nloc, yn_all, n_total, 1)
+            from sonar_amd.distributed import all_gather_rows
 
-        mine()
-        torch.cuda.synchronize()
-        barrier()
-        t1 = time.perf_counter()
+            ya, _ = all_gather_rows(yn[:nloc])
+            pad = padded_rows(n_total) - n_total
+            if pad:
+                ya = torch.cat([ya, ya.new_zeros((pad, D))])
+            return xs_mod.topk_normalized(xn, nloc, ya.contiguous(), n_total, 1)
+
         reps = 3
-        for _ in range(reps):
-            mine()
-        torch.cuda.synchronize()
-        barrier()
-        xt = (time.perf_counter() - t1) / reps
-        if world > 1:
-            t = torch.tensor([xt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            xt = float(t.item())
-        ny_total = ny_local * world
-        pairs = float(world) * nx * ny_total
-        xs = {"pairs_per_s": pairs / xt, "ms": xt * 1e3, "nx_per_gpu": nx, "ny_total": ny_total, "d": D, "k": 1,
-              "tflops": pairs * 2 * D / xt / 1e12,
+        xt = timed(mine, reps, 1) / reps
+        pairs = float(n_total) * n_total
+        xs = {"workload": f"xsim cosine mining, {n_total} x {n_total} x {D} fp16 (BASELINE configs[2]), top-1, X and Y "
+                          f"row-sharded over {world} rank(s), Y all-gathered",
+              "pairs_per_s": pairs / xt, "ms": xt * 1e3, "nx_per_gpu": nloc, "nx_total": n_total, "ny_total": n_total,
+              "d": D, "k": 1, "tflops": pairs * 2 * D / xt / 1e12,
               "frac_of_mfma_peak": pairs * 2 * D / xt / 1e12 / (MFMA_PEAK_TFLOPS * world),
-              "includes": "row normalisation, Y all-gather (N>1), top-1 mining"}
+              "includes": "row normalisation of X and Y, Y all-gather (N>1), top-1 mining + chunk merge",
+              "scaling": "strong (the 1M x 1M problem is fixed, X rows are split over the ranks)"}
         del x_local, y_local, yn_all
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
+            xs["cpu_baseline"] = xsim_cpu_baseline()
 
     # ------------------------------------------------- secondary configs (BASELINE C4 / C5), N = 1 only
-    extra = {}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not DRYRUN:
         del model
         torch.cuda.empty_cache()
         try:
@@ -265,18 +426,28 @@ def main():
         model = None
 
     cb = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if sd_cpu is not None:
         model = None
         torch.cuda.empty_cache()
-        cb = cpu_baseline(args.cpu_sentences)
+        from oracle import text_encoder as O
+
+        if c1_gpu is None:
+            c1_ids, c1_lens = O.synthetic_batch(32, 8, 64, V, seed=0)
+        cb, c1_cpu = cpu_baseline(sd_cpu, args.cpu_sentences, c1_ids, c1_lens)
+        if c1_gpu is not None:
+            cos = torch.nn.functional.cosine_similarity(c1_gpu, c1_cpu, dim=-1)
+            extra["c1"]["max_1_minus_cos_vs_cpu_oracle"] = float((1 - cos).max())
+            extra["c1"]["cpu_sentences_per_s"] = cb["c1"]["value"]
+            extra["c1"]["speedup_vs_cpu"] = extra["c1"]["sentences_per_s"] / cb["c1"]["value"]
 
     if rank == 0:
         out = {
             "metric": "sentences/sec embedded (seq128 b1024)", "value": value, "unit": "sentences/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic" if not DRYRUN else "dry-run stub",
             "config": {"workload": "text_sonar_basic_encoder fp16, batch 1024 x seq_len 128 per GPU, eng_Latn (BASELINE configs[1])",
-                       "global_batch": world * BATCH, "seq_len": SEQ, "parallelism": f"dp{world}",
+                       "global_batch": world * batch_n, "seq_len": seq, "parallelism": f"dp{world}",
                        "weights": "random-init basic arch (24L, d=1024, F=8192, V=256206)"},
             "roofline": roofline, "cpu_baseline": cb,
             "encoder_tflops": value * FLOPS_PER_SENTENCE / 1e12,

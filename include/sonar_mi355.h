@@ -364,6 +364,27 @@ int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny
                   int32_t k, int64_t y_index_offset, int32_t* idx, float* score, void* workspace,
                   void* stream);
 
+/* k-way merge of `parts` per-shard top-k lists (device fp32 / int32 [parts, n, k], each sorted as
+ * smi_xsim_topk returns them) into the k best of their union, same total order (score desc, index asc).
+ * Folds the per-rank partial y-side neighbour lists of the sharded margin scoring; part_idx /
+ * out_idx may be NULL when only the scores are needed (the margin uses the neighbour MEAN). */
+int smi_xsim_merge_topk(const float* part_scores, const int32_t* part_idx, int32_t parts, int64_t n, int32_t k,
+                        float* out_scores, int32_t* out_idx, void* stream);
+
+/* Margin re-scoring of the k-NN candidates, LASER's xsim (facebookresearch/LASER source/xsim.py,
+ * _score_margin / _score_knn; un-vendored, restated in oracle/xsim.py):
+ *   score(i, j) = margin(cos(x_i, y_j), (mean_k cos(x_i, NN_k(x_i)) + mean_k cos(y_j, NN_k(y_j))) / 2)
+ * fwd_scores / fwd_idx: device [nx, k] from smi_xsim_topk(X, Y, k) (indices into the rows of bwd_scores);
+ * bwd_scores: device [ny, k] from smi_xsim_topk(Y, X, k) (or its cross-rank merge).  pred_idx[i] = the
+ * candidate with the best score (first on ties), pred_margin[i] (nullable) its score; err_count (nullable,
+ * device int32, ACCUMULATED) += #rows with pred_idx[i] != i + x_index_offset (aligned pairs). */
+#define SMI_MARGIN_RATIO 0    /* a / b */
+#define SMI_MARGIN_DISTANCE 1 /* a - b */
+#define SMI_MARGIN_COSINE 2   /* a (bwd_scores unused) */
+int smi_xsim_margin_select(const float* fwd_scores, const int32_t* fwd_idx, int64_t nx, int32_t k,
+                           const float* bwd_scores, int64_t ny, int32_t margin, int64_t x_index_offset,
+                           int32_t* pred_idx, float* pred_margin, int32_t* err_count, void* stream);
+
 /* Embedding heads: BLASER / MuTox ---------------------------------------------
  * A small MLP over (features of) sentence embeddings.  Replaces
  *   BlaserModel.forward = F.normalize -> featurize_input -> mlp   sonar/models/blaser/model.py:82-125

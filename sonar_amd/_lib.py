@@ -15,6 +15,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
 SMI_OK = 0
 SMI_F32, SMI_F16 = 0, 1
 SMI_POOL = {"mean": 0, "max": 1, "last": 2}
+SMI_MARGIN = {"ratio": 0, "distance": 1, "cosine": 2}
 SMI_GEMM_IN_TM, SMI_GEMM_OUT_TM = 1 << 12, 1 << 13
 SMI_ENC_FP16_RESIDUAL = 1
 PROF_SLOTS = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_ffn1", "gemm_ffn2", "ln_pool"]
@@ -239,6 +240,8 @@ SYMBOLS = {
     "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "smi_xsim_merge_topk": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "smi_xsim_margin_select": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "smi_mlp_head_create": (C.c_int, [C.POINTER(smi_mlp_head_config), C.POINTER(smi_mlp_head_layer), C.POINTER(_vp)]),
     "smi_mlp_head_destroy": (None, [_vp]),

@@ -461,6 +461,33 @@ int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_
   return SMI_OK;
 }
 
+int smi_xsim_merge_topk(const float* part_scores, const int32_t* part_idx, int32_t parts, int64_t n, int32_t k,
+                        float* out_scores, int32_t* out_idx, void* stream) {
+  if (!part_scores || !out_scores) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (parts < 1 || parts > 64) return fail(SMI_ERR_UNSUPPORTED, "parts=%d outside [1,64]", parts);
+  if (k < 1 || k > 8) return fail(SMI_ERR_UNSUPPORTED, "k=%d outside [1,8]", k);
+  if (n <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (out_idx && !part_idx) return fail(SMI_ERR_INVALID_ARG, "out_idx needs part_idx");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_topk_merge(part_scores, part_idx, parts, n, k, out_scores, out_idx, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+int smi_xsim_margin_select(const float* fwd_scores, const int32_t* fwd_idx, int64_t nx, int32_t k,
+                           const float* bwd_scores, int64_t ny, int32_t margin, int64_t x_index_offset,
+                           int32_t* pred_idx, float* pred_margin, int32_t* err_count, void* stream) {
+  if (!fwd_scores || !fwd_idx || !pred_idx) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (k < 1 || k > 8) return fail(SMI_ERR_UNSUPPORTED, "k=%d outside [1,8]", k);
+  if (margin < SMI_MARGIN_RATIO || margin > SMI_MARGIN_COSINE) return fail(SMI_ERR_INVALID_ARG, "unknown margin %d", margin);
+  if (nx <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (margin != SMI_MARGIN_COSINE && (!bwd_scores || ny <= 0))
+    return fail(SMI_ERR_INVALID_ARG, "margin scoring needs the backward (y-side) neighbour scores");
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_margin_select(fwd_scores, fwd_idx, nx, k, bwd_scores, ny, margin, x_index_offset, pred_idx,
+                               pred_margin, err_count, (hipStream_t)stream));
+  return SMI_OK;
+}
+
 // -------------------------------------------------------- building blocks
 int smi_pack_tile_major(const void* src, void* dst, int32_t rows, int32_t k, int32_t inverse,
                         void* stream) {

@@ -91,6 +91,11 @@ size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k);
 hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
                             int64_t ny_pad, int d, int k, int64_t y_index_offset, int32_t* idx,
                             float* score, void* workspace, hipStream_t stream);
+hipError_t launch_topk_merge(const float* part_scores, const int32_t* part_idx, int parts, int64_t n, int k,
+                             float* out_scores, int32_t* out_idx, hipStream_t stream);
+hipError_t launch_margin_select(const float* fwd_scores, const int32_t* fwd_idx, int64_t nx, int k,
+                                const float* bwd_scores, int64_t ny, int kind, int64_t x_off, int32_t* pred,
+                                float* pred_margin, int32_t* err_count, hipStream_t stream);
 
 // ---- decoder / beam search (decoder.hip) ----
 hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* pe_row, float scale,

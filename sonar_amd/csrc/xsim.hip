@@ -401,6 +401,102 @@ hipError_t launch_l2_normalize(const void* src, int src_is_f32, f16* dst, int64_
   return hipGetLastError();
 }
 
+// ------------------------------------------------- k-way merge of per-shard top-k lists
+// part_score / part_idx: [parts][n][k], every list sorted (score desc, index asc) -- what smi_xsim_topk
+// returns.  out: the k best of the union in the same total order.  One thread per row; used to fold the
+// per-rank partial y-side neighbour lists of the sharded margin scoring.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ ps, const int32_t* __restrict__ pi,
+                                                         int parts, int64_t n, int k, float* __restrict__ os,
+                                                         int32_t* __restrict__ oi) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  int head[64];
+  for (int p = 0; p < parts; ++p) head[p] = 0;
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff, bp = -1;
+    for (int p = 0; p < parts; ++p) {
+      if (head[p] >= k) continue;
+      const size_t o = ((size_t)p * n + r) * k + head[p];
+      const float v = ps[o];
+      const int id = pi ? pi[o] : p * k + head[p];
+      if (bp < 0 || v > bv || (v == bv && id < bi)) {
+        bv = v;
+        bi = id;
+        bp = p;
+      }
+    }
+    if (bp >= 0) ++head[bp];
+    os[r * k + j] = bv;
+    if (oi) oi[r * k + j] = bp >= 0 && pi ? bi : -1;
+  }
+}
+
+hipError_t launch_topk_merge(const float* ps, const int32_t* pi, int parts, int64_t n, int k, float* os, int32_t* oi,
+                             hipStream_t stream) {
+  if (parts < 1 || parts > 64 || k < 1 || k > 8 || n <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ps, pi, parts, n, k,
+                     os, oi);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------- margin re-scoring of the k-NN candidates
+// LASER xsim (source/xsim.py: _score_margin / _score_knn): for x_i and its k nearest y candidates,
+//   score(i, j) = margin(cos(x_i, y_j), (mean_kNN(x_i) + mean_kNN(y_j)) / 2),
+// margin = ratio a / b, distance a - b, or (kind 2) the plain cosine a; the prediction is the candidate
+// with the best score (first one on ties, as numpy's argmax).  mean_kNN(x_i) is the mean of x_i's own k
+// forward scores, mean_kNN(y_j) the mean of y_j's k backward scores bwd[j][:].
+// err_count (nullable) accumulates the rows whose prediction is not the aligned index i + x_off.
+__global__ __launch_bounds__(256) void margin_select_kernel(const float* __restrict__ fs, const int32_t* __restrict__ fi,
+                                                            int64_t nx, int k, const float* __restrict__ bwd,
+                                                            int64_t ny, int kind, int64_t x_off,
+                                                            int32_t* __restrict__ pred, float* __restrict__ pm,
+                                                            int32_t* __restrict__ err_count) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int wrong = 0;
+  if (r < nx) {
+    float xm = 0.f;
+    for (int j = 0; j < k; ++j) xm += fs[r * k + j];
+    xm /= (float)k;
+    float best = -INFINITY;
+    int bj = 0;
+    for (int j = 0; j < k; ++j) {
+      const float a = fs[r * k + j];
+      const int64_t y = fi[r * k + j];
+      float m = a;
+      if (kind != 2) {
+        float ym = 0.f;
+        if (y >= 0 && y < ny)
+          for (int q = 0; q < k; ++q) ym += bwd[y * k + q];
+        ym /= (float)k;
+        const float b = 0.5f * (xm + ym);
+        m = kind == 0 ? a / b : a - b;
+      }
+      if (j == 0 || m > best) {
+        best = m;
+        bj = j;
+      }
+    }
+    const int p = fi[r * k + bj];
+    pred[r] = p;
+    if (pm) pm[r] = best;
+    wrong = (int64_t)p != r + x_off;
+  }
+  if (err_count) {
+    const unsigned long long bal = __ballot(wrong);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(err_count, (int)__popcll(bal));
+  }
+}
+
+hipError_t launch_margin_select(const float* fs, const int32_t* fi, int64_t nx, int k, const float* bwd, int64_t ny,
+                                int kind, int64_t x_off, int32_t* pred, float* pm, int32_t* err_count,
+                                hipStream_t stream) {
+  if (nx <= 0 || k < 1 || k > 8 || kind < 0 || kind > 2 || (kind != 2 && (!bwd || ny <= 0))) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(margin_select_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, fs, fi, nx, k, bwd,
+                     ny, kind, x_off, pred, pm, err_count);
+  return hipGetLastError();
+}
+
 static int xsim_chunks(int64_t nty) { return (int)(nty < 8 ? nty : 8); }
 static int round_k(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8)); }
 

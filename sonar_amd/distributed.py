@@ -83,20 +83,113 @@ def sharded_encode(encode_fn: Callable[[List[str]], torch.Tensor], texts: Sequen
     return out
 
 
-def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1):
-    """Rows of X and Y are sharded over ranks (rank order = row order).  Returns, for the
-    local X rows, (scores [n_local,k], global Y indices [n_local,k])."""
-    from . import xsim
+class EngineXsimBackend:
+    """The xsim primitives the sharded mining is written against -- here the MI355X engine
+    (sonar_amd.xsim).  The CPU multi-process tests substitute a torch stand-in with the same five
+    methods so that the collective plumbing (uneven shards, global index offsets, merge, error
+    reduction) runs under gloo without a GPU."""
 
+    def normalize(self, t: torch.Tensor) -> torch.Tensor:
+        """L2-normalised rows of t (engine layout may pad rows; only the first len(t) are meaningful)."""
+        from . import xsim
+
+        return xsim.normalize_rows(t)
+
+    def pad_rows(self, tn: torch.Tensor, n: int) -> torch.Tensor:
+        """Re-pad a gathered [n, d] matrix of normalised rows to the engine's row multiple."""
+        from . import xsim
+
+        pad = int(xsim._lib.load().smi_xsim_padded_rows(n)) - tn.shape[0]
+        if pad > 0:
+            tn = torch.cat([tn, tn.new_zeros((pad, tn.shape[1]))])
+        return tn.contiguous()
+
+    def topk(self, xn, nx: int, yn, ny: int, k: int, y_index_offset: int = 0):
+        from . import xsim
+
+        return xsim.topk_normalized(xn, nx, yn, ny, k, y_index_offset)
+
+    def merge_topk(self, part_scores, part_idx=None):
+        from . import xsim
+
+        return xsim.merge_topk(part_scores, part_idx)
+
+    def margin_select(self, fs, fi, bs, margin: str, x_index_offset: int, err_count):
+        from . import xsim
+
+        return xsim.margin_select(fs, fi, bs, margin, x_index_offset, err_count)
+
+
+def _row_offsets(counts: Sequence[int]) -> List[int]:
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + int(c))
+    return offs
+
+
+def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, backend=None):
+    """Rows of X and Y are sharded over ranks (rank order = row order).  Returns, for the
+    local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k])."""
+    be = backend or EngineXsimBackend()
     rank, ws = world()
-    xn = xsim.normalize_rows(x_local)
+    xn = be.normalize(x_local)
     if ws == 1:
-        return xsim.topk_normalized(xn, x_local.shape[0], xsim.normalize_rows(y_local), y_local.shape[0], k)
+        return be.topk(xn, x_local.shape[0], be.normalize(y_local), y_local.shape[0], k)
     # normalise locally (fp16), gather the unpadded rows, then re-pad once
-    yn_local = xsim.normalize_rows(y_local)[: y_local.shape[0]]
+    yn_local = be.normalize(y_local)[: y_local.shape[0]]
     yn_all, counts = all_gather_rows(yn_local)
-    ny = yn_all.shape[0]
-    pad = int(xsim._lib.load().smi_xsim_padded_rows(ny)) - ny
-    if pad:
-        yn_all = torch.cat([yn_all, yn_all.new_zeros((pad, yn_all.shape[1]))])
-    return xsim.topk_normalized(xn, x_local.shape[0], yn_all.contiguous(), ny, k)
+    ny = sum(counts)
+    return be.topk(xn, x_local.shape[0], be.pad_rows(yn_all, ny), ny, k)
+
+
+def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str = "ratio", k: int = 4,
+                       backend=None):
+    """xsim error rate of aligned pairs x[i] <-> y[i] whose rows are sharded over ranks in rank order
+    (SURVEY 8(e)); every rank returns (global error rate, predicted GLOBAL y index of its local x rows).
+
+    Exchange steps (everything else is local mining):
+      1. all-gather of the normalised Y shards (2 KB per row)              -> every rank holds Y;
+      2. margin only: each rank mines, for EVERY y, its k best neighbours among the LOCAL x rows; the
+         [Ny, k] partial score lists are all-gathered (Ny * k * 4 B per rank, 16 MB at 1 M x k = 4) and
+         k-way merged, which gives mean_kNN(y_j) over all of X on every rank;
+      3. one scalar all-reduce of the per-rank error counts."""
+    be = backend or EngineXsimBackend()
+    rank, ws = world()
+    nx_local, ny_local = x_local.shape[0], y_local.shape[0]
+    dev = x_local.device
+    xn = be.normalize(x_local)
+    yn_local = be.normalize(y_local)
+    if ws > 1:
+        yn_all, y_counts = all_gather_rows(yn_local[:ny_local])
+        ny = sum(y_counts)
+        yn = be.pad_rows(yn_all, ny)
+        xc = torch.tensor([nx_local], dtype=torch.int64, device=dev)
+        xcs = [torch.zeros_like(xc) for _ in range(ws)]
+        dist.all_gather(xcs, xc)
+        x_counts = [int(c.item()) for c in xcs]
+    else:
+        yn, ny, x_counts = yn_local, ny_local, [nx_local]
+    nx = sum(x_counts)
+    if nx != ny:
+        raise ValueError(f"xsim expects aligned x and y ({nx} vs {ny} rows in total)")
+    x_off = _row_offsets(x_counts)[rank]
+    errs = torch.zeros(1, dtype=torch.int32, device=dev)
+    if margin == "cosine":
+        fs, fi = be.topk(xn, nx_local, yn, ny, 1)
+        pred, _ = be.margin_select(fs, fi, None, "cosine", x_off, errs)
+    else:
+        kk = min(k, ny, min(x_counts))
+        fs, fi = be.topk(xn, nx_local, yn, ny, kk)
+        # y-side neighbourhoods: partial lists over the local x shard, for all y
+        bs_part, _ = be.topk(yn, ny, xn, nx_local, kk, x_off)
+        if ws > 1:
+            parts = bs_part.new_empty((ws * bs_part.shape[0], bs_part.shape[1]))
+            dist.all_gather_into_tensor(parts, bs_part.contiguous())
+            bs, _ = be.merge_topk(parts.view(ws, bs_part.shape[0], bs_part.shape[1]), None)
+        else:
+            bs = bs_part
+        pred, _ = be.margin_select(fs, fi, bs, margin, x_off, errs)
+    total = errs.to(torch.int64)
+    if ws > 1:
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+    return int(total.item()) / nx, pred

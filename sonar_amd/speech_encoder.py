@@ -328,12 +328,17 @@ class SonarSpeechEncoderModel:
 
 def load_sonar_speech_encoder(checkpoint: Union[str, Mapping], arch: str = "english",
                               device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
-                              config: Optional[SonarSpeechEncoderConfig] = None) -> SonarSpeechEncoderModel:
+                              config: Optional[SonarSpeechEncoderConfig] = None,
+                              load_stats: Optional[dict] = None) -> SonarSpeechEncoderModel:
+    """Card name / checkpoint file (through the packed cache) / in-memory dict -> speech encoder model."""
+    cfg_arch = arch
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
         from .cards import resolve_checkpoint
+        from .packed_cache import load_converted
 
-        # a card name ("sonar_speech_encoder_eng", ...) resolves under $SONAR_CHECKPOINT_DIR
-        path, arch = resolve_checkpoint(checkpoint, arch)
-        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
-    cfg = config or get_speech_encoder_config(arch)
-    return SonarSpeechEncoderModel(cfg, convert_sonar_speech_checkpoint(checkpoint), device, dtype)
+        path, cfg_arch = resolve_checkpoint(checkpoint, arch)
+        sd = load_converted(path, convert_sonar_speech_checkpoint, "speech_encoder", load_stats)
+    else:
+        sd = convert_sonar_speech_checkpoint(checkpoint)
+    cfg = config or get_speech_encoder_config(cfg_arch)
+    return SonarSpeechEncoderModel(cfg, sd, device, dtype)

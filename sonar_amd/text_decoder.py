@@ -343,12 +343,17 @@ class ConditionalTransformerDecoderModel:
 
 def load_sonar_text_decoder(checkpoint: Union[str, Mapping], arch: str = "basic",
                             device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
-                            config: Optional[SonarTextDecoderConfig] = None) -> ConditionalTransformerDecoderModel:
+                            config: Optional[SonarTextDecoderConfig] = None,
+                            load_stats: Optional[dict] = None) -> ConditionalTransformerDecoderModel:
+    """Card name / checkpoint file (through the packed cache) / in-memory dict -> decoder model."""
+    cfg_arch = arch
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
         from .cards import resolve_checkpoint
+        from .packed_cache import load_converted
 
-        # a card name ("text_sonar_basic_decoder", ...) resolves under $SONAR_CHECKPOINT_DIR
-        path, arch = resolve_checkpoint(checkpoint, arch)
-        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
-    cfg = config or get_text_decoder_config(arch)
-    return ConditionalTransformerDecoderModel(cfg, convert_sonar_text_decoder_checkpoint(checkpoint), device, dtype)
+        path, cfg_arch = resolve_checkpoint(checkpoint, arch)
+        sd = load_converted(path, convert_sonar_text_decoder_checkpoint, "text_decoder", load_stats)
+    else:
+        sd = convert_sonar_text_decoder_checkpoint(checkpoint)
+    cfg = config or get_text_decoder_config(cfg_arch)
+    return ConditionalTransformerDecoderModel(cfg, sd, device, dtype)

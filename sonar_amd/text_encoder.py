@@ -383,15 +383,20 @@ class SonarTextTransformerEncoderModel:
 def load_sonar_text_encoder(checkpoint: Union[str, Mapping], arch: str = "basic",
                             device: Union[str, torch.device] = "cuda:0",
                             dtype: torch.dtype = torch.float16,
-                            config: Optional[SonarTextEncoderConfig] = None) -> SonarTextTransformerEncoderModel:
-    """hub.load() equivalent for a local checkpoint file or an in-memory dict
-    (reference: sonar/inference_pipelines/text.py:161-162)."""
+                            config: Optional[SonarTextEncoderConfig] = None,
+                            load_stats: Optional[dict] = None) -> SonarTextTransformerEncoderModel:
+    """hub.load() equivalent for a card name (resolved under $SONAR_CHECKPOINT_DIR, sonar_amd/cards.py), a
+    local checkpoint file, or an in-memory dict (reference: sonar/inference_pipelines/text.py:161-162).
+    Files go through the packed cache (sonar_amd/packed_cache.py): the second load of a file skips the
+    unpickling, the key conversion and the fp32 -> fp16 conversion."""
+    cfg_arch = arch
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
         from .cards import resolve_checkpoint
+        from .packed_cache import load_converted
 
-        # a card name ("text_sonar_basic_encoder", ...) resolves under $SONAR_CHECKPOINT_DIR
-        path, arch = resolve_checkpoint(checkpoint, arch)
-        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
-    cfg = config or get_text_encoder_config(arch)
-    sd = convert_sonar_text_encoder_checkpoint(checkpoint)
+        path, cfg_arch = resolve_checkpoint(checkpoint, arch)
+        sd = load_converted(path, convert_sonar_text_encoder_checkpoint, "text_encoder", load_stats)
+    else:
+        sd = convert_sonar_text_encoder_checkpoint(checkpoint)
+    cfg = config or get_text_encoder_config(cfg_arch)
     return SonarTextTransformerEncoderModel(cfg, sd, device=device, dtype=dtype)

@@ -72,31 +72,59 @@ def topk(x: torch.Tensor, y: torch.Tensor, k: int = 1) -> Tuple[torch.Tensor, to
     return topk_normalized(xn, x.shape[0], yn, y.shape[0], k)
 
 
-def margin_scores(fwd_scores: torch.Tensor, fwd_idx: torch.Tensor, x_knn_mean: torch.Tensor,
-                  y_knn_mean: torch.Tensor, margin: str = "ratio") -> torch.Tensor:
-    """LASER margin over the k-NN candidates: s(x,y) / (0.5 * (mean_kNN(x) + mean_kNN(y)))."""
-    denom = 0.5 * (x_knn_mean.unsqueeze(1) + y_knn_mean[fwd_idx.long().clamp_min(0)])
-    if margin == "ratio":
-        return fwd_scores / denom
-    if margin == "distance":
-        return fwd_scores - denom
-    raise ValueError(margin)
+def merge_topk(part_scores: torch.Tensor, part_idx: Optional[torch.Tensor] = None):
+    """k-way merge of per-shard top-k lists [parts, n, k] (smi_xsim_merge_topk) -> (scores [n,k], idx [n,k] | None)."""
+    lib = _lib.load()
+    ps = part_scores.to(torch.float32).contiguous()
+    parts, n, k = ps.shape
+    pi = part_idx.to(torch.int32).contiguous() if part_idx is not None else None
+    out_s = torch.empty((n, k), dtype=torch.float32, device=ps.device)
+    out_i = torch.empty((n, k), dtype=torch.int32, device=ps.device) if pi is not None else None
+    with torch.cuda.device(ps.device):
+        _lib.check(lib.smi_xsim_merge_topk(ps.data_ptr(), pi.data_ptr() if pi is not None else None, parts, n, k,
+                                           out_s.data_ptr(), out_i.data_ptr() if out_i is not None else None,
+                                           _lib.current_stream_ptr()))
+    return out_s, out_i
+
+
+def margin_select(fwd_scores: torch.Tensor, fwd_idx: torch.Tensor, bwd_scores: Optional[torch.Tensor],
+                  margin: str = "ratio", x_index_offset: int = 0, err_count: Optional[torch.Tensor] = None):
+    """LASER margin re-scoring of the k-NN candidates on the device (smi_xsim_margin_select).
+    Returns (predicted y index per x row int32 [nx], its margin score fp32 [nx]); `err_count` (device
+    int32 [1]) is incremented by the number of rows whose prediction is not row index + x_index_offset."""
+    if margin not in _lib.SMI_MARGIN:
+        raise ValueError(margin)
+    lib = _lib.load()
+    fs = fwd_scores.to(torch.float32).contiguous()
+    fi = fwd_idx.to(torch.int32).contiguous()
+    nx, k = fs.shape
+    bs = bwd_scores.to(torch.float32).contiguous() if bwd_scores is not None else None
+    if bs is not None and bs.shape[1] != k:
+        raise ValueError("forward and backward neighbour lists must have the same k")
+    pred = torch.empty((nx,), dtype=torch.int32, device=fs.device)
+    pm = torch.empty((nx,), dtype=torch.float32, device=fs.device)
+    with torch.cuda.device(fs.device):
+        _lib.check(lib.smi_xsim_margin_select(
+            fs.data_ptr(), fi.data_ptr(), nx, k, bs.data_ptr() if bs is not None else None,
+            bs.shape[0] if bs is not None else 0, _lib.SMI_MARGIN[margin], x_index_offset, pred.data_ptr(),
+            pm.data_ptr(), err_count.data_ptr() if err_count is not None else None, _lib.current_stream_ptr()))
+    return pred, pm
 
 
 def xsim_error(x: torch.Tensor, y: torch.Tensor, margin: str = "cosine", k: int = 4) -> Tuple[float, torch.Tensor]:
-    """xsim error rate for aligned x[i] <-> y[i]; returns (error rate, predicted index per x row)."""
+    """xsim error rate for aligned x[i] <-> y[i] (LASER source/xsim.py); returns (error rate, predicted
+    index per x row).  margin: "cosine" | "ratio" | "distance" (k nearest neighbours, LASER default 4)."""
     if x.shape[0] != y.shape[0]:
         raise ValueError("xsim expects aligned x and y")
     xn, yn = normalize_rows(x), normalize_rows(y)
     n = x.shape[0]
+    errs = torch.zeros(1, dtype=torch.int32, device=xn.device)
     if margin == "cosine":
-        _, idx = topk_normalized(xn, n, yn, n, 1)
-        pred = idx[:, 0].long()
+        fs, fi = topk_normalized(xn, n, yn, n, 1)
+        pred, _ = margin_select(fs, fi, None, "cosine", 0, errs)
     else:
         kk = min(k, n)
         fs, fi = topk_normalized(xn, n, yn, n, kk)
         bs, _ = topk_normalized(yn, n, xn, n, kk)
-        m = margin_scores(fs, fi, fs.mean(dim=1), bs.mean(dim=1), margin)
-        pred = fi.long().gather(1, m.argmax(dim=1, keepdim=True)).squeeze(1)
-    err = (pred != torch.arange(n, device=pred.device)).float().mean().item()
-    return err, pred
+        pred, _ = margin_select(fs, fi, bs, margin, 0, errs)
+    return int(errs.item()) / n, pred.long()

@@ -72,3 +72,90 @@ def test_all_gather_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+# ------------------------------------------------------------------ sharded xsim (round 2)
+class TorchXsimBackend:
+    """CPU stand-in for the engine's xsim primitives (same five methods as
+    sonar_amd.distributed.EngineXsimBackend), so the sharded mining runs under gloo."""
+
+    def normalize(self, t):
+        return torch.nn.functional.normalize(t.float(), dim=-1)
+
+    def pad_rows(self, tn, n):
+        return tn
+
+    def topk(self, xn, nx, yn, ny, k, y_index_offset=0):
+        s = xn[:nx] @ yn[:ny].T
+        o = torch.sort(s, dim=1, descending=True, stable=True)
+        return o.values[:, :k].contiguous(), (o.indices[:, :k] + y_index_offset).to(torch.int32).contiguous()
+
+    def merge_topk(self, part_scores, part_idx=None):
+        p, n, k = part_scores.shape
+        flat = part_scores.permute(1, 0, 2).reshape(n, p * k)
+        o = torch.sort(flat, dim=1, descending=True, stable=True)
+        return o.values[:, :k].contiguous(), None
+
+    def margin_select(self, fs, fi, bs, margin, x_index_offset, err_count):
+        if margin == "cosine":
+            m = fs
+        else:
+            b = 0.5 * (fs.mean(dim=1, keepdim=True) + bs.mean(dim=1)[fi.long()])
+            m = fs / b if margin == "ratio" else fs - b
+        best = m.argmax(dim=1, keepdim=True)
+        pred = fi.gather(1, best).squeeze(1)
+        rows = torch.arange(fs.shape[0]) + x_index_offset
+        err_count += int((pred.long() != rows).sum())
+        return pred, m.gather(1, best).squeeze(1)
+
+
+def _xsim_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import xsim as OX
+        from sonar_amd.distributed import shard_range, sharded_xsim_error, sharded_xsim_topk
+
+        fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "xsim_margin_twin.pt"))
+        x, y = fx["x"], fx["y"]
+        n = x.shape[0]
+        # UNEVEN shards, and X / Y cut differently: rank order = row order is all that is assumed
+        xb, xe = shard_range(n - 3, rank, world)
+        if rank == world - 1:
+            xe = n
+        yb, ye = shard_range(n, world - 1 - rank, world)      # reversed sizes ...
+        ycuts = [shard_range(n, world - 1 - r, world) for r in range(world)]
+        yb = sum(e - b for b, e in ycuts[:rank])               # ... but contiguous in rank order
+        ye = yb + (ycuts[rank][1] - ycuts[rank][0])
+        be = TorchXsimBackend()
+        s, idx = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be)
+        rs, ri = OX.cosine_topk(x, y, 3)
+        assert torch.equal(idx.long(), ri[xb:xe]) and torch.allclose(s, rs[xb:xe], atol=1e-6)
+        for m in ("cosine", "ratio", "distance"):
+            err, pred = sharded_xsim_error(x[xb:xe], y[yb:ye], margin=m, k=4, backend=be)
+            assert abs(err - fx[m + "_err"] / n) < 1e-12, (m, err, fx[m + "_err"])
+            assert torch.equal(pred.long(), fx[m + "_pred"][xb:xe]), m
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_margin_xsim_gloo(world):
+    """per-rank partial y-side k-NN -> all-gather + k-way merge, scalar all-reduce of the error
+    count -- on uneven shards, against the LASER-formula golden."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xsim_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -54,19 +54,34 @@ def _rescored(OD, params, ocfg, e, prompt, seq):
     return lp[0, torch.arange(full.shape[1] - 1), full[0, 1:]].sum().item()
 
 
+# "Exact token-id match for greedy decode" (BASELINE north_star), stated honestly: every token of every
+# best hypothesis equals the fp32 CPU oracle's, EXCEPT for a sentence whose decision margin -- measured
+# by the engine itself during the run (smi_text_decoder_last_margins) -- is below EPS_REL of the logit
+# range, i.e. where two candidates are closer than fp16 arithmetic can separate.  Such a sentence must
+# still return a hypothesis whose oracle score equals the oracle's best within the same epsilon.
+EPS_REL = 1e-3
+
+
+def _logit_range(OD, params, ocfg, emb, prompt):
+    lg = OD.decoder_logits(params, ocfg, emb, torch.tensor([list(prompt)] * emb.shape[0]))
+    return (lg.max() - lg.min()).item()
+
+
 @pytest.mark.parametrize("beam", [1, 3, 5])
 def test_beam_search_vs_oracle(setup, beam):
     OD, ocfg, params, eng = setup
     g = torch.Generator().manual_seed(10 + beam)
-    n = 7
+    n = 24
     emb = torch.randn(n, ocfg.model_dim, generator=g) * 0.3
     prompt = [3, 700]
     kw = dict(beam_size=beam, max_gen_len=(0, 13))
     ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
     toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
+    margins = eng.last_margins(n).cpu()
     torch.cuda.synchronize()
     toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
-    exact = 0
+    eps = EPS_REL * _logit_range(OD, params, ocfg, emb, prompt)
+    excused = []
     for i in range(n):
         L = int(lens[i, 0])
         seq = toks[i, 0, :L].tolist()
@@ -75,15 +90,71 @@ def test_beam_search_vs_oracle(setup, beam):
         # the engine's best hypothesis is a valid hypothesis with the score the oracle assigns to it
         total = _rescored(OD, params, ocfg, emb[i], prompt, seq)
         norm = total / (len(prompt) + L - 1)
-        assert abs(norm - scores[i, 0].item()) <= 2e-2, (norm, scores[i, 0].item())
-        # and it is as good as the oracle's best (identical unless two candidates tie within fp16 noise)
-        assert scores[i, 0].item() >= ref[i][0].score - 2e-2
-        exact += int(seq == ref[i][0].seq.tolist())
+        assert abs(norm - scores[i, 0].item()) <= 5e-3, (norm, scores[i, 0].item())
         # hypotheses come out best first
         k = int((lens[i] > 0).sum())
         assert k == beam
         assert all(scores[i, j] >= scores[i, j + 1] - 1e-6 for j in range(k - 1))
-    assert exact >= n - 1, f"only {exact}/{n} best hypotheses identical to the oracle"
+        assert margins[i, 0] >= 0 and (beam == 1 or margins[i, 1] >= 0)
+        if seq != ref[i][0].seq.tolist():
+            step_gap, final_gap = margins[i, 0].item(), margins[i, 1].item()
+            assert step_gap < eps or final_gap < eps, (
+                f"sentence {i}: tokens differ from the oracle although every decision margin the engine "
+                f"measured (step {step_gap:.3e}, final {final_gap:.3e}) is above eps {eps:.3e}")
+            # a measured near-tie: the returned hypothesis must be as good as the oracle's best
+            assert abs(norm - ref[i][0].score) <= 2 * eps, (norm, ref[i][0].score)
+            excused.append((i, step_gap, final_gap))
+    print(f"beam {beam}: {n - len(excused)}/{n} best hypotheses token-identical to the oracle; "
+          f"measured near-ties (< {eps:.2e}): {excused}")
+    # near-ties are rare events, not a blanket excuse
+    assert len(excused) <= max(1, n // 8), excused
+
+
+def test_greedy_margins_are_the_top2_logprob_gaps(setup):
+    """The margin the exactness test relies on is itself checked against the oracle: for beam 1 it must
+    equal the smallest top-1 / top-2 log-prob gap along the oracle's greedy path."""
+    OD, ocfg, params, eng = setup
+    emb = torch.randn(6, ocfg.model_dim, generator=torch.Generator().manual_seed(21)) * 0.3
+    prompt = [3, 700]
+    toks, lens, _ = eng.generate(emb.cuda(), prompt, beam_size=1, max_gen_len=(0, 9))
+    margins = eng.last_margins(6).cpu()
+    toks, lens = toks.cpu(), lens.cpu()
+    for i in range(6):
+        seq = toks[i, 0, : int(lens[i, 0])].tolist()
+        full = torch.tensor([prompt + seq])
+        lp = torch.log_softmax(OD.decoder_logits(params, ocfg, emb[i:i + 1], full[:, :-1]), dim=-1)[0]
+        lp[:, 0] = -torch.inf                      # PAD is never a candidate
+        gaps = []
+        for t in range(len(prompt) - 1, full.shape[1] - 1):
+            row = lp[t].clone()
+            if t == len(prompt) - 1:               # min_gen_len = 1: EOS blocked on the first free step
+                row[3] = -torch.inf
+            if t == len(prompt) - 1 + 8:           # forced EOS at the cap: no decision
+                continue
+            top2 = row.topk(2).values
+            gaps.append((top2[0] - top2[1]).item())
+        assert abs(min(gaps) - margins[i, 0].item()) <= 2e-2, (min(gaps), margins[i, 0].item())
+        assert margins[i, 1].item() == float("inf")
+
+
+def test_generation_cap_follows_source_length(setup):
+    """fairseq2: max_gen_len = a * source_len + b.  A sentence vector handed to the generator as
+    `source_seqs` [n, model_dim] has "source length" model_dim, so the default (1, 128) cap is the
+    decoder's max_seq_len, not 129 tokens; text / speech sources pass their own length."""
+    OD, ocfg, params, eng = setup
+    emb = (torch.randn(2, ocfg.model_dim, generator=torch.Generator().manual_seed(31)) * 0.3).cuda()
+    prompt = [3, 700]
+    # EOS blocked for the whole run: the output length is the cap itself
+    toks, lens, _ = eng.generate(emb, prompt, beam_size=1, min_gen_len=1000 if False else 40, max_gen_len=(1, 8),
+                                 source_len=32)
+    assert int(lens.max()) == 40 and toks.shape[2] == 2 + 40           # 1 * 32 + 8
+    toks, lens, _ = eng.generate(emb, prompt, beam_size=1, min_gen_len=60, max_gen_len=(1, 8))
+    assert toks.shape[2] == ocfg.max_seq_len and int(lens.max()) == ocfg.max_seq_len - 2   # capped by the model
+    with pytest.raises(ValueError):
+        eng.generate(emb, prompt, beam_size=1, max_gen_len=(0, 0))
+    ref = OD.beam_search(params, ocfg, emb.cpu().float(), prompt, beam_size=1, min_gen_len=40, max_gen_len=(1, 8),
+                         source_len=32)
+    assert len(ref[0][0].seq) == 40
 
 
 def test_generate_is_repeatable_across_calls(setup):

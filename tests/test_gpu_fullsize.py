@@ -37,8 +37,12 @@ def test_encoder_full_width_vs_oracle(fp16_residual):
                                              fp16_residual=fp16_residual)
     emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
     assert torch.isfinite(emb).all()
-    print(f"fp16_residual={fp16_residual}: max (1 - cos) vs oracle = {_cos_err(emb, ref):.2e}")
+    rel = (emb.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"fp16_residual={fp16_residual}: max (1 - cos) vs oracle = {_cos_err(emb, ref):.2e}, max |diff| / max |ref| = {rel:.2e}")
     assert _cos_err(emb, ref) <= 1e-3          # north_star tolerance
+    # measured (r02): 1 - cos <= 3e-5; hold the stack to ~10x that and to an elementwise bound, so that a
+    # regression inside the north_star tolerance is still caught
+    assert _cos_err(emb, ref) <= 3e-4 and rel <= 3e-2
     # a small slice of the same sentences goes through the 128x128 engine: same vectors
     sub = model(SequenceBatch(ids[:3].cuda(), PaddingMask(lens[:3], ids.shape[1]))).sentence_embeddings
     assert _cos_err(sub, emb[:3]) <= 2e-5
@@ -218,6 +222,123 @@ def test_encoder_full_depth_vs_oracle(fp16_residual):
         model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=dt, fp16_residual=fp16_residual)
         emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
         err = _cos_err(emb, ref)
-        print(f"24 layers, fp16_residual={fp16_residual}, out {dt}: max (1 - cos) vs fp32 oracle = {err:.2e}")
+        rel = (emb.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"24 layers, fp16_residual={fp16_residual}, out {dt}: max (1 - cos) vs fp32 oracle = {err:.2e}, "
+              f"max |diff| / max |ref| = {rel:.2e}")
         assert torch.isfinite(emb).all() and err <= 1e-3
+        assert err <= 3e-4 and rel <= 3e-2      # ~10x the measured error (2e-7 ... 3e-5), elementwise too
         del model
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE configs[4] / configs[3] at FULL size against the fp32 CPU oracle (round 2: VERDICT item 1b)
+def _cpu_fp32(sd):
+    return {k: v.detach().float().cpu() for k, v in sd.items()}
+
+
+@pytest.fixture(scope="module")
+def basic_decoder():
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import text_decoder as OD
+    from sonar_amd.text_decoder import TextDecoderEngine, get_text_decoder_config
+    from tools.synth import text_decoder_state_dict
+
+    dev = torch.device("cuda:0")
+    sd = text_decoder_state_dict(dev)
+    eng = TextDecoderEngine(get_text_decoder_config("basic"), sd, device=dev)
+    params = _cpu_fp32(sd)          # the same (fp16-representable) values, fp32 arithmetic on the host
+    del sd
+    torch.cuda.empty_cache()
+    ocfg = OD.OracleTextDecoderConfig(model_dim=1024, num_layers=24, num_heads=16, ffn_inner_dim=8192,
+                                      vocab_size=256206, max_seq_len=512)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    return OD, ocfg, params, eng
+
+
+def test_basic_decoder_logits_vs_oracle_full_size(basic_decoder):
+    """text_sonar_basic_decoder (24 layers, d 1024, F 8192, V 256206): teacher-forced logits of 4 sentences x 9
+    positions against the fp32 oracle (the reference's own logits check has this shape, test_text_sonar.py:61-105)."""
+    OD, ocfg, params, eng = basic_decoder
+    g = torch.Generator().manual_seed(41)
+    emb = F.normalize(torch.randn(4, 1024, generator=g), dim=-1) * 0.2
+    prev = torch.randint(4, 256000, (4, 9), generator=g)
+    prev[:, 0] = 3
+    prev[:, 1] = 256047
+    ref = OD.decoder_logits(params, ocfg, emb, prev)
+    got = eng.logits(emb.cuda(), prev.cuda()).cpu()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    print(f"basic decoder logits: max |diff| {err:.3e} on scale {scale:.3f} ({err / scale:.2e} relative)")
+    assert got.shape == ref.shape == (4, 9, 256206)
+    assert err <= 5e-3 * scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+
+
+@pytest.mark.parametrize("beam", [1, 5])
+def test_basic_decoder_tokens_vs_oracle_full_size(basic_decoder, beam):
+    """Exact token ids at full size: every best hypothesis equals the fp32 oracle's unless the engine's own
+    measured decision margin is below 1e-3 of the logit range (see tests/test_gpu_decoder.py)."""
+    OD, ocfg, params, eng = basic_decoder
+    g = torch.Generator().manual_seed(43 + beam)
+    n, steps = 4, 9
+    emb = F.normalize(torch.randn(n, 1024, generator=g), dim=-1) * 0.2
+    prompt = [3, 256047]
+    kw = dict(beam_size=beam, max_gen_len=(0, steps))
+    ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
+    toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
+    margins = eng.last_margins(n).cpu()
+    toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
+    lg = OD.decoder_logits(params, ocfg, emb, torch.tensor([prompt] * n))
+    eps = 1e-3 * (lg.max() - lg.min()).item()
+    excused = 0
+    for i in range(n):
+        seq = toks[i, 0, : int(lens[i, 0])].tolist()
+        want = ref[i][0].seq.tolist()
+        assert abs(scores[i, 0].item() - ref[i][0].score) <= 5e-3 or seq != want
+        if seq != want:
+            assert margins[i, 0].item() < eps or margins[i, 1].item() < eps, (i, seq, want, margins[i].tolist(), eps)
+            excused += 1
+    print(f"basic decoder beam {beam}: {n - excused}/{n} token-identical to the oracle, eps {eps:.2e}, "
+          f"margins {margins.tolist()}")
+    assert excused <= 1
+
+
+def test_speech_encoder_english_vs_oracle_full_size():
+    """sonar_speech_encoder_eng (24 conformer blocks, d 1024, 3-layer pooler) on 3 clips of 1.0 / 1.6 / 2.0 s,
+    waveform -> embedding, against the fp32 oracle (filterbank included), both residual precisions."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveforms_to_fbank_batch
+    from tools.synth import speech_encoder_state_dict
+
+    dev = torch.device("cuda:0")
+    sd = speech_encoder_state_dict(dev)
+    params = _cpu_fp32(sd)
+    so = OS.OracleSpeechEncoderConfig(model_dim=1024, num_layers=24, num_heads=16, ffn_inner_dim=4096, conv_kernel=31,
+                                      pooler_layers=3, pooler_heads=16, pooler_ffn_dim=4096, pooler_vocab=1024)
+    g = torch.Generator().manual_seed(17)
+    wavs = [(torch.rand(n, generator=g) * 2 - 1) * 0.5 + 0.2 * torch.sin(torch.arange(n) * 0.03) for n in (16000, 25600, 32000)]
+    feats = [OS.kaldi_fbank(w) for w in wavs]
+    lens = torch.tensor([f.shape[0] for f in feats])
+    t = int(lens.max()) + int(lens.max()) % 2
+    fb = torch.zeros(3, t, 80)
+    for i, f in enumerate(feats):
+        fb[i, : f.shape[0]] = f
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    _, ref = OS.speech_encoder_forward(params, so, fb, lens)
+    for fp16_residual in (False, True):
+        eng = SpeechEncoderEngine(get_speech_encoder_config("english"), sd, device=dev, fp16_residual=fp16_residual)
+        gfb, glens = waveforms_to_fbank_batch([w.to(dev) for w in wavs])
+        assert glens == lens.tolist()
+        out = eng.forward(gfb, glens, torch.float32).cpu()
+        err = _cos_err(out, ref)
+        rel = (out - ref).abs().max().item() / ref.abs().max().item()
+        print(f"english speech encoder, fp16_residual={fp16_residual}: max (1 - cos) {err:.2e}, max |diff| / max |ref| {rel:.2e}")
+        assert err <= 1e-3 and rel <= 5e-2
+        del eng

@@ -125,3 +125,17 @@ def test_xsim_cosine_topk_matches_sklearn_twin():
     scores, idx = OX.cosine_topk(fx["x"], fx["y"], 4)
     assert torch.equal(idx, fx["idx"])
     assert (scores.double() - fx["cosine"]).abs().max().item() < 1e-5
+
+
+def test_xsim_margin_matches_laser_formula_twin():
+    """oracle/xsim.py: laser_xsim against LASER's published `_score_knn` / `_score_margin`, written loop for
+    loop over scikit-learn neighbours (tests/golden/make_golden_xsim_margin.py)."""
+    import os
+
+    from oracle import xsim as OX
+
+    fx = torch.load(os.path.join(os.path.dirname(__file__), "golden", "xsim_margin_twin.pt"))
+    for m in ("cosine", "ratio", "distance"):
+        err, pred = OX.laser_xsim(fx["x"], fx["y"], m, fx["k"])
+        assert err == fx[m + "_err"] and torch.equal(pred, fx[m + "_pred"]), m
+    assert fx["ratio_err"] != fx["cosine_err"]        # the fixture does separate the variants
