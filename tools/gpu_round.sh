@@ -22,5 +22,16 @@ if [ "$2" == "pmc" ]; then
   # raw per-dispatch CSVs are large; keep only the summaries
   rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 fi
+if [ "$2" == "pmc" ]; then
+  # MFMA utilisation / hardware-counted flops / effective clock of the GEMM stack (SQ + GRBM counters only,
+  # one pass per SQ counter so that an unknown counter name cannot void the other)
+  cd /tmp
+  for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16; do
+    rocprofv3 --pmc $C GRBM_GUI_ACTIVE --kernel-trace -d $OUT/${TAG}_pmc_$C -o ${TAG} --output-format csv -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --xsim-n 131072 > /dev/null 2> $OUT/${TAG}_pmc_$C.err
+  done
+  cd $OLDPWD
+  python tools/summarize_mfma.py $OUT/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/${TAG}_pmc_SQ_INSTS_VALU_MFMA_MOPS_F16 > $OUT/${TAG}_mfma_util.txt 2>&1
+  rm -rf $OUT/${TAG}_pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/${TAG}_pmc_SQ_INSTS_VALU_MFMA_MOPS_F16
+fi
 find $OUT/${TAG}_prof -name "*kernel_trace*" -delete 2>/dev/null
 tail -5 $OUT/${TAG}_pytest_gpu.log; cat $OUT/${TAG}_smoke.log | tail -3; cat $OUT/${TAG}_bench.json; head -30 $OUT/${TAG}_kernel_stats.txt
