@@ -7,10 +7,13 @@ the library itself fails with SMI_ERR_NO_DEVICE when no MI355X is visible.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 from typing import Optional
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
+# SMI_LIB: development override -- load a variant build of the library (tools/README.md) instead of the in-tree one
+LIB_PATH = Path(os.environ["SMI_LIB"]).resolve() if os.environ.get("SMI_LIB") else \
+    Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
 
 SMI_OK = 0
 SMI_F32, SMI_F16 = 0, 1
