@@ -387,10 +387,122 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const XT* __restrict__ x,
   }
 }
 
+// Fast path of the headline configuration (d = 1024, fp16 residual stream, no `encoded_seqs` output): the
+// kernel is a pure HBM read (2 KB per token in, 2-4 KB per SENTENCE out), so all that matters is bytes in
+// flight: a lane owns 8 consecutive columns of each 512-column half (16-B loads), and the 8 loads of a
+// wave's 4 rows are issued before the first reduction (the generic kernel above walks one row at a time with
+// 8-B loads: 3.9 TB/s; this one: see DESIGN.md 3).
+template <typename OutT>
+__global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, float eps,
+                                                              const int32_t* __restrict__ cu, OutT* __restrict__ out,
+                                                              int pooling) {
+  constexpr int D = 1024;
+  constexpr int NW = 8;  // waves per sentence
+  __shared__ __attribute__((aligned(16))) float red[NW][D];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int start = cu[n];
+  const int len = cu[n + 1] - start;
+  float wr[2][8], br[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 w0 = *(const f32x4*)(w + h * 512 + lane * 8), w1 = *(const f32x4*)(w + h * 512 + lane * 8 + 4);
+    const f32x4 b0 = *(const f32x4*)(b + h * 512 + lane * 8), b1 = *(const f32x4*)(b + h * 512 + lane * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      wr[h][e] = w0[e];
+      wr[h][4 + e] = w1[e];
+      br[h][e] = b0[e];
+      br[h][4 + e] = b1[e];
+    }
+  }
+  const float init = pooling == 1 ? -INFINITY : 0.f;
+  float acc[2][8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[h][e] = init;
+  // wave wv owns rows wv*4 + 4*NW*i + (0..3)
+  for (int p0 = wv * 4; p0 < len; p0 += 4 * NW) {
+    half8 v[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = min(p0 + r, len - 1);  // clamped rows are loaded (cached) but not accumulated
+      const f16* xr = x + (size_t)(start + p) * D + lane * 8;
+      v[r][0] = *(const half8*)xr;
+      v[r][1] = *(const half8*)(xr + 512);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float f[2][8];
+      float sum = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[h][e] = (float)v[r][h][e];
+          sum += f[h][e];
+        }
+      const float mean = wave_sum(sum) * (1.0f / D);
+      float q = 0.f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[h][e] -= mean;
+          q += f[h][e] * f[h][e];
+        }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+      const bool live = p0 + r < len;
+      const bool last = p0 + r == len - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float y = f[h][e] * rstd * wr[h][e] + br[h][e];
+          if (pooling == 0)
+            acc[h][e] += live ? y : 0.f;
+          else if (pooling == 1)
+            acc[h][e] = live ? fmaxf(acc[h][e], y) : acc[h][e];
+          else if (last)
+            acc[h][e] = y;
+        }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wv][h * 512 + lane * 8 + e] = acc[h][e];
+  __syncthreads();
+  // reference (model.py:115-124): weights = 1/(seq_len + 1e-7), in fp32 here
+  const float wgt = 1.0f / ((float)len + 1e-7f);
+  for (int c = threadIdx.x; c < D; c += 64 * NW) {
+    float v;
+    if (pooling == 1)
+      v = fmaxf(fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c])),
+                fmaxf(fmaxf(red[4][c], red[5][c]), fmaxf(red[6][c], red[7][c])));
+    else
+      v = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
+    if (pooling == 0) v *= wgt;
+    if (len <= 0) v = 0.f;
+    out[(size_t)n * D + c] = (OutT)v;
+  }
+}
+
 hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float eps,
                           const int32_t* cu, void* out, int out_is_f32, void* encoded, int N, int S,
                           int d, int pooling, hipStream_t stream, int x_f16) {
   if (N <= 0 || pooling < 0 || pooling > 2) return hipErrorInvalidValue;
+  if (d == 1024 && x_f16 && !encoded) {
+    if (out_is_f32)
+      hipLaunchKernelGGL(ln_pool1024_f16_kernel<float>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
+                         (float*)out, pooling);
+    else
+      hipLaunchKernelGGL(ln_pool1024_f16_kernel<f16>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
+                         (f16*)out, pooling);
+    return hipGetLastError();
+  }
 #define SMI_LP_LAUNCH(NV, OutT, XT)                                                                               \
   hipLaunchKernelGGL((ln_pool_kernel<NV, OutT, XT>), dim3(N), dim3(256), 0, stream, (const XT*)x, w, b, eps, cu, \
                      (OutT*)out, (OutT*)encoded, S, pooling);

@@ -220,11 +220,22 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
       SMI_LGKM0_BARRIER();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+      if (k == 0) {
+        // first slice of a y tile: C = 0 is an operand of the instruction, the 128 accumulator registers
+        // are never cleared by hand
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-          acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], acc.v[ni][mi], 0, 0, 0);
+          for (int mi = 0; mi < 8; ++mi)
+            acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], z, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 8; ++mi)
+            acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], acc.v[ni][mi], 0, 0, 0);
+      }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       SMI_BARRIER();
@@ -246,8 +257,6 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
                 if (n < ny) best[mi].push(acc.v[ni][mi][r], n);
               }
           }
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc.v[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         n0 += G2_BN;
       }
