@@ -6,6 +6,8 @@
 // with the epilogues fused.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
                                                                 const float* __restrict__ bias,
                                                                 void* __restrict__ out_, int M, int N,
                                                                 int K, int ldo, GemmTileStats stats, int ksplit,
-                                                                size_t part_stride) {
+                                                                size_t part_stride, int raster) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool TM = LAYOUT > 0;
   // work unit = (tile, K part kz): split-K (EPI_STORE_F32 only) gives each part its own fp32 output slab
@@ -205,12 +207,40 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     return v;
   };
 
-  int tile = xcd_remap(blockIdx.x, gridDim.x);
-  if (tile >= ntiles) return;
   // unit id = kz * (ntm * ntn) + output tile: neighbouring ids share operand panels of one K part
   const int nout = ntm * ntn;
-  int tile_m, tile_n, kz = tile / nout;
-  g2_tile_coords_of(tile % nout, ntm, ntn, tile_m, tile_n);
+  // raster 0: grouped 8(m) x ntn super-tiles in id order (gemm_tile256.hpp).
+  // raster 2 (full 256-workgroup grids, N >= 4 n-quads): XCD c OWNS the m-groups c, c + 8, ... (8 X panels each) and
+  // walks the n-quads of a group in consecutive rounds, in an order rotated by c.  With raster 0 and N = 8192 the
+  // 8 XCDs work on the SAME 8 X panels in every round (each on its own 4 W panels): every X panel is pulled across
+  // the fabric by all 8 XCDs at the same moment (PMC: 3.2 GB fetched per launch for 0.29 GB of operands).  With
+  // XCD-owned m-groups an X panel is fetched by one XCD only, and the rotation keeps the XCDs on different W panels.
+  // Measured (profiles/r02_experiments.txt, experiments 6-7): FFN inner 1.82-1.87 -> 1.75-1.76 ms
+  // (1175-1210 -> 1249-1260 TFLOP/s), 44.0 -> 41.9 ms per C2 step; no effect at N = 3072 (X is shared by 3 XCDs
+  // there), so it is used from 16 n tiles up.  (raster 1 = the same without the rotation.)
+  // Virtual ids t = 256 q + 32 c + j (round q, XCD c, slot j); the last m-group may be partial: its surplus slots,
+  // and XCDs that own one group fewer, skip the id.
+  const int nq = ntn / 4;
+  const int nvirt = raster ? ((ntm + 63) / 64) * nq * 256 : ntiles;
+  auto coords = [&](int t, int& tm_, int& tn_) -> bool {
+    if (raster == 0) {
+      g2_tile_coords_of(t % nout, ntm, ntn, tm_, tn_);
+      return true;
+    }
+    const int q = t / 256, c = (t % 256) / 32, j = t % 32;
+    tm_ = (c + 8 * (q / nq)) * 8 + j % 8;
+    tn_ = ((q + (raster == 2 ? c : 0)) % nq) * 4 + j / 8;
+    return tm_ < ntm;
+  };
+  int tile_m = 0, tile_n = 0;
+  // first valid id of this workgroup at or after t (stride = grid size)
+  auto seek = [&](int t) {
+    while (t < nvirt && !coords(t, tile_m, tile_n)) t += gridDim.x;
+    return t;
+  };
+  int tile = seek(xcd_remap(blockIdx.x, gridDim.x));
+  if (tile >= nvirt) return;
+  int kz = raster ? 0 : tile / nout;
   G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
   g2_prefetch(src, nt, smem);
   f32x4 bias_next = fetch_bias(tile_n * G2_BN, kz);
@@ -218,7 +248,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
 #ifdef SMI_GEMM_TRACE
   int trace_i = 0;
 #endif
-  for (; tile < ntiles; tile += gridDim.x) {
+  while (tile < nvirt) {
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
     const int tile_n_cur = tile_n;
     (void)tile_n_cur;
@@ -230,10 +260,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     G2_TRACE(1);
     g2_mainloop(acc, src, nt, smem);
     G2_TRACE(2);
-    if (tile + (int)gridDim.x < ntiles) {  // fill for the next tile, behind this tile's epilogue
-      const int next = tile + gridDim.x;
-      kz = next / nout;
-      g2_tile_coords_of(next % nout, ntm, ntn, tile_m, tile_n);
+    tile = seek(tile + (int)gridDim.x);  // (tile_m, tile_n) now name the NEXT tile; m0 / n0 keep this one
+    if (tile < nvirt) {  // fill for the next tile, behind this tile's epilogue
+      kz = raster ? 0 : tile / nout;
       src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
       g2_prefetch(src, nt, smem);
       bias_next = fetch_bias(tile_n * G2_BN, kz);
@@ -479,9 +508,18 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
     attr_done.set();
   }
   const int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
+  static const int want_raster = [] {  // SMI_G2_RASTER=0 restores the id-order raster everywhere (A/B measurements)
+    const char* e = getenv("SMI_G2_RASTER");
+    return e ? atoi(e) : 2;
+  }();
+  const int ntm = M / G2_BM, ntn = N / G2_BN;
+  // XCD-owned m-groups (see the kernel): whole chip, >= 4 n-quads, and a number of m-groups (8 row tiles each) that
+  // deals evenly to the 8 XCDs -- otherwise the id-order raster balances better
+  const int raster = (want_raster && ksplit == 1 && grid == 256 && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0)
+                         ? want_raster : 0;
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
                      stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0}, ksplit,
-                     part_stride);
+                     part_stride, raster);
   return hipGetLastError();
 }
 
