@@ -579,6 +579,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       SMI_EPI_CASE(EPI_RESID_HALF_F32, 1)
       SMI_EPI_CASE(EPI_RESID_F16, 1)
       SMI_EPI_CASE(EPI_RESID_HALF_F16, 1)
+      SMI_EPI_CASE(EPI_GLU_F16, 1)
     }
     return hipErrorInvalidValue;
   }

@@ -296,6 +296,9 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     if (rc == SMI_OK) {
       const smi_tensor ws[3] = {s.q_w, s.k_w, s.v_w}, bs[3] = {s.q_b, s.k_b, s.v_b};
       rc = pack_fused(ws, bs, 3, d, d, L.w_qkv, L.b_qkv, "self_attn.qkv");
+      // the QKV and pointwise_conv1 GEMMs read a LayerNorm output: packed rows, no per-clip alignment in the
+      // way, so their INPUTS are tile-major too (their outputs feed per-clip kernels and stay row-major)
+      if (rc == SMI_OK && E->ffn_tile_major) rc = to_tile_major(L.w_qkv, (int)(3 * d), (int)d);
     }
     if (rc == SMI_OK) {  // pointwise_conv1 rows interleaved for the GLU epilogue
       DevBuf tmp;
@@ -307,6 +310,7 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
           he = hipDeviceSynchronize();
         }
         if (he != hipSuccess) rc = fail(SMI_ERR_HIP, "glu interleave: %s", hipGetErrorString(he));
+        if (rc == SMI_OK && E->ffn_tile_major) rc = to_tile_major(L.w_pw1, (int)(2 * d), (int)d);
       }
     }
     if (rc == SMI_OK) {  // BatchNorm (eval) folded to scale / shift
@@ -455,15 +459,15 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
     HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
                            stream));
     // x += RelPosMHA(LN(x))
-    HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream, 0, x16));
-    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
+    HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | ffn_in, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, pe_slice, L.w_r.as<f16>(), nullptr, E->rp.p, rp_m, d, d, d, stream));
     HIP_TRY(launch_relpos_attention(qkv, dcu, E->rp.as<f16>(), tm - 1, rp_m, L.u_bias.as<float>(), L.v_bias.as<float>(), ctx,
                                     n, tm, d, c.num_heads, stream));
     HIP_TRY(launch_gemm_tn(epi_res, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
     // x += Conv(LN(x)): pointwise(d->2d)+GLU, depthwise+BN+SiLU, pointwise(d->d)
-    HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, 0, x16));
-    HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8), h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
+    HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
+    HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | ffn_in, h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
     HIP_TRY(launch_dwconv_bn_silu(E->glu.as<f16>(), dcu, L.w_dw.as<float>(), L.bn_scale.as<float>(), L.bn_shift.as<float>(),
                                   E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream));
     HIP_TRY(launch_gemm_tn(epi_res, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
