@@ -197,14 +197,17 @@ class SpeechToEmbeddingModelPipeline(SpeechModelPipelineInterface):
         Args:
             encoder: a card name resolved under $SONAR_CHECKPOINT_DIR, a checkpoint path, or a model object
             device: the HIP device; this engine has no CPU path, so a CPU device raises.
-            fbank_dtype: kept for interface parity; features are fp32 on device.
+            fbank_dtype: as in the reference (speech.py:426-429): torch.float16 on a GPU runs the model in half
+                precision (fp16 residual stream and embeddings), the default float32 an fp32 model; the
+                filterbank features themselves are always fp32 on the device.
         """
         super().__init__()
         device = torch.device(device)
         if isinstance(encoder, (str, Path)):
             if device.type != "cuda":
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
-            encoder = load_sonar_speech_encoder(str(encoder), device=device)
+            encoder = load_sonar_speech_encoder(str(encoder), device=device,
+                                                dtype=torch.float16 if fbank_dtype == torch.float16 else torch.float32)
         self.model = encoder.eval()
         self.device = getattr(encoder, "device", device)
         self.fbank_dtype = fbank_dtype

@@ -104,18 +104,21 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
                  device: torch.device = CPU, dtype: Optional[torch.dtype] = None) -> None:
         """
         Args:
-            encoder: a checkpoint path (fairseq or fairseq2 layout, `basic` arch) or a model object
-            tokenizer: a SentencePiece model path or a tokenizer object
+            encoder: a card name (resolved under $SONAR_CHECKPOINT_DIR), a checkpoint path (fairseq or
+                fairseq2 layout, `basic` arch) or a model object
+            tokenizer: a card name, a SentencePiece model path or a tokenizer object
             device: the HIP device to run on.  The reference defaults to CPU; this engine has no
                 CPU path, so a CPU device raises here instead of silently running elsewhere.
-            dtype: dtype of the returned embeddings (float16 default, float32 supported).
+            dtype: as in the reference (`hub.load(name, device=device, dtype=dtype)`, text.py:161-162):
+                None loads an fp32 model -- fp32 embeddings and an fp32 residual stream (the GEMM operands
+                are fp16 on this engine either way); torch.float16 is the fast path BASELINE measures.
         """
         super().__init__()
         device = torch.device(device)
         if isinstance(encoder, (str, Path)):
             if device.type != "cuda":
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
-            encoder = load_sonar_text_encoder(str(encoder), device=device, dtype=dtype or torch.float16)
+            encoder = load_sonar_text_encoder(str(encoder), device=device, dtype=dtype or torch.float32)
         if isinstance(tokenizer, (str, Path)):
             from ..cards import resolve_tokenizer
 
@@ -234,7 +237,7 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
         if isinstance(decoder, (str, Path)):
             if device.type != "cuda":
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
-            decoder = load_sonar_text_decoder(str(decoder), device=device, dtype=dtype or torch.float16)
+            decoder = load_sonar_text_decoder(str(decoder), device=device, dtype=dtype or torch.float32)
         if isinstance(tokenizer, (str, Path)):
             from ..cards import resolve_tokenizer
 
