@@ -341,6 +341,21 @@ def main():
                 "traffic_source": traffic_src, "avg_launch_ms": ffn1_ms, "launches": ffn1["launches"],
                 "flops_per_launch": FFN1_FLOPS_PER_LAUNCH}
     kernels = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}
+    # HBM-bound kernels of the step: algorithmic bytes per launch (fp16 residual stream and operands,
+    # T = 131072 tokens, d = 1024) / mean HIP-event time of the launches inside the timed region
+    HBM_PEAK_GBS = 8000.0
+    tok = batch_n * seq
+    hbm_bytes = {"layernorm": tok * D * 2 * 2,                 # read x, write h
+                 "attention": tok * D * 2 * 4,                 # read q|k|v, write ctx
+                 "ln_pool": tok * D * 2 + batch_n * D * 2,     # read x, write one vector per sentence (the pooling kernel)
+                 "embed": tok * (8 + D * 2 + D * 2)}           # ids + gathered table row + x row (the fp32 position rows are L2 hits)
+    hbm_kernels = {}
+    for name, nbytes in hbm_bytes.items():
+        p_ = prof.get(name)
+        if p_ and p_["launches"] and p_["ms"] > 0:
+            us = p_["ms"] / p_["launches"] * 1e3
+            hbm_kernels[name] = {"bytes_per_launch": nbytes, "avg_launch_us": us, "achieved_GBs": nbytes / us / 1e3,
+                                 "frac_of_hbm_peak": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
     # ------------------------------------------------------------ C2(b) varlen + C1 (N = 1 only)
     extra = {}
@@ -399,6 +414,8 @@ def main():
 
         reps = 3
         xt = timed(mine, reps, 1) / reps
+        # the HBM-bound half of the leg on its own: L2 normalisation of one side (read fp16, write fp16)
+        nt_ = timed(lambda: xs_mod.normalize_rows(y_local), 3, 1) / 3
         pairs = float(n_total) * n_total
         xs = {"workload": f"xsim cosine mining, {n_total} x {n_total} x {D} fp16 (BASELINE configs[2]), top-1, X and Y "
                           f"row-sharded over {world} rank(s), Y all-gathered",
@@ -406,6 +423,8 @@ def main():
               "d": D, "k": 1, "tflops": pairs * 2 * D / xt / 1e12,
               "frac_of_mfma_peak": pairs * 2 * D / xt / 1e12 / (MFMA_PEAK_TFLOPS * world),
               "includes": "row normalisation of X and Y, Y all-gather (N>1), top-1 mining + chunk merge",
+              "normalise": {"ms": nt_ * 1e3, "bytes": nloc * D * 4, "achieved_GBs": nloc * D * 4 / nt_ / 1e9,
+                            "frac_of_hbm_peak": nloc * D * 4 / nt_ / 1e9 / 8000.0},
               "scaling": "strong (the 1M x 1M problem is fixed, X rows are split over the ranks)"}
         del x_local, y_local, yn_all
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
@@ -452,7 +471,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cb,
             "encoder_tflops": value * FLOPS_PER_SENTENCE / 1e12,
             "encoder_frac_of_mfma_peak": value * FLOPS_PER_SENTENCE / 1e12 / (MFMA_PEAK_TFLOPS * world),
-            "kernels": kernels, "xsim": xs, **extra,
+            "kernels": kernels, "hbm_kernels": hbm_kernels, "xsim": xs, **extra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

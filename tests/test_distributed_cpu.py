@@ -37,11 +37,14 @@ def _worker(rank, world, port, q):
         # uneven all-gather
         t = torch.full((rank + 2, 3), float(rank))
         g, counts = all_gather_rows(t)
-        assert counts == [2, 3] and g.shape == (5, 3)
-        assert torch.equal(g[:2], torch.zeros(2, 3)) and torch.equal(g[2:], torch.ones(3, 3))
+        assert counts == [r + 2 for r in range(world)] and g.shape == (sum(counts), 3)
+        off = 0
+        for r, c in enumerate(counts):
+            assert torch.equal(g[off:off + c], torch.full((c, 3), float(r)))
+            off += c
         # even all-gather keeps the dense fast path
         g2, c2 = all_gather_rows(torch.full((4, 2), float(rank)))
-        assert c2 == [4, 4] and g2.shape == (8, 2)
+        assert c2 == [4] * world and g2.shape == (4 * world, 2)
         # sharded encode restores the input order on every rank
         texts = ["a" * n for n in (5, 1, 9, 3, 3, 7, 2)]
         calls = []
@@ -52,7 +55,7 @@ def _worker(rank, world, port, q):
 
         out = sharded_encode(encode, texts)
         assert out[:, 0].tolist() == [5.0, 1.0, 9.0, 3.0, 3.0, 7.0, 2.0]
-        assert set(out[:, 1].tolist()) == {0.0, 1.0}  # both ranks contributed
+        assert set(out[:, 1].tolist()) == {float(r) for r in range(world)}  # every rank contributed
         assert calls and calls[0] < len(texts)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
@@ -61,17 +64,18 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_all_gather_world2_gloo():
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_gather_and_sharded_encode_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
 
 
 # ------------------------------------------------------------------ sharded xsim (round 2)

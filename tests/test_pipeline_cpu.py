@@ -129,6 +129,19 @@ def test_predict_order_bucketing_and_truncation(spm_model, tmp_path):
     f = tmp_path / "in.txt"
     f.write_text("\n".join(texts) + "\n")
     assert torch.equal(pipe.predict(f, source_lang="eng_Latn", batch_size=3), expect)
+    # CRLF files: the line ending is stripped, nothing else (fairseq2 read_text infers the ending, rtrim=False);
+    # a missing final newline and trailing spaces are kept as they are
+    g = tmp_path / "crlf.txt"
+    g.write_bytes("\r\n".join(texts).encode())
+    assert torch.equal(pipe.predict(g, source_lang="eng_Latn", batch_size=3), expect)
+    # empty input -> empty [0, d] matrix, no model call
+    n_before = len(stub.batches)
+    stub.model_dim, stub.dtype = 2, torch.float32
+    empty = pipe.predict([], source_lang="eng_Latn")
+    assert empty.shape[0] == 0 and len(stub.batches) == n_before
+    # an empty STRING is a sentence: [lang, </s>]
+    one = pipe.predict([""], source_lang="eng_Latn")
+    assert one.shape == (1, 2) and one[0, 1].item() == 2
     # truncation warns and clips to the model maximum (reference: test_text_sonar.py:55-59)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
