@@ -69,7 +69,7 @@ def test_pack_tile_major(lib, rows, k):
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (256, 512, 192), (512, 1024, 1024), (256, 256, 8192),
                                    (1024, 768, 256)])
-@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1), (8, 0)])
+@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1), (6, 0), (8, 0)])
 def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
     """Tile-major operands (and output) on both tile engines against the same fp32 reference."""
     from sonar_amd import _lib
@@ -93,19 +93,24 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
         elif epi == 3:
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
             want = ref
+        elif epi == 6:   # GLU (the conformer's pointwise_conv1 reads a tile-major LayerNorm output), row-major out
+            out = torch.full((m, n // 2), float("nan"), device="cuda", dtype=torch.float16)
+            r4 = ref.view(m, n // 64, 2, 32)
+            want = (r4[:, :, 0] * torch.sigmoid(r4[:, :, 1])).reshape(m, n // 2)
         else:
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
             want = torch.relu(ref) if epi == 1 else (torch.nn.functional.silu(ref) if epi == 5 else ref)
         _lib.check(lib.smi_gemm_tn(epi | (sel << 8) | flags, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(),
-                                   out.data_ptr(), m, n, k, n, _stream()))
+                                   out.data_ptr(), m, n, k, n // 2 if epi == 6 else n, _stream()))
         torch.cuda.synchronize()
         got = (from_tile_major(out.view(-1), m, n) if out_tm else out).float()
         assert torch.isfinite(got).all()
         err = (got - want).abs().max().item()
         scale = max(want.abs().max().item(), 1.0)
-        assert err <= (2e-3 if epi in (0, 1, 5, 8) else 2e-5) * scale, (sel, err, scale)
+        assert err <= (2e-3 if epi in (0, 1, 5, 6, 8) else 2e-5) * scale, (sel, err, scale)
     # unsupported combinations are refused, not mis-computed
-    assert lib.smi_gemm_tn(6 | flags, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n, _stream()) != 0
+    assert lib.smi_gemm_tn(6 | _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(),
+                           m, n, k, n, _stream()) != 0   # GLU has no tile-major OUTPUT
     assert lib.smi_gemm_tn(0 | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n,
                            _stream()) != 0
 
