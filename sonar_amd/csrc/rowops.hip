@@ -456,19 +456,35 @@ __global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restr
       const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
       const bool live = p0 + r < len;
       const bool last = p0 + r == len - 1;
+      if (pooling == 0) {
+        // mean pooling: sum_r LN(x_r) = w * sum_r (x_r - mean_r) * rstd_r + n * b -- the affine part is applied once
+        // per sentence after the row loop (one fma per element and row here; the kernel is VALU-bound otherwise)
+        const float sc = live ? rstd : 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float y = f[h][e] * rstd * wr[h][e] + br[h][e];
-          if (pooling == 0)
-            acc[h][e] += live ? y : 0.f;
-          else if (pooling == 1)
-            acc[h][e] = live ? fmaxf(acc[h][e], y) : acc[h][e];
-          else if (last)
-            acc[h][e] = y;
-        }
+          for (int e = 0; e < 8; ++e) acc[h][e] = __builtin_fmaf(f[h][e], sc, acc[h][e]);
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float y = f[h][e] * rstd * wr[h][e] + br[h][e];
+            if (pooling == 1)
+              acc[h][e] = live ? fmaxf(acc[h][e], y) : acc[h][e];
+            else if (last)
+              acc[h][e] = y;
+          }
+      }
     }
+  }
+  if (pooling == 0) {  // rows owned by this wave: p = wv*4 + 32*i + r < len
+    int nrows = 0;
+    for (int p0 = wv * 4; p0 < len; p0 += 4 * NW) nrows += min(4, len - p0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[h][e] = acc[h][e] * wr[h][e] + (float)nrows * br[h][e];
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
