@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -366,38 +367,51 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   f16* ctx = e->ctx.as<f16>();
   f16* ffn = e->ffn.as<f16>();
 
-  if (rows > total)
-    HIP_TRY(hipMemsetAsync((char*)x + (size_t)total * d * xes, 0, (size_t)(rows - total) * d * xes, stream));
+  // The fp16 residual stream itself is tile-major when everything that touches it has that path (d = 1024, no
+  // encoded_seqs output): the residual epilogues of the attention-output and FFN-output GEMMs then read-modify-write
+  // it straight from the accumulators instead of staging the tile through LDS in 8 barrier-separated passes.
+  static const bool x_tm_enabled = [] {  // SMI_ENC_X_TM=0: row-major residual stream (A/B measurements)
+    const char* v = getenv("SMI_ENC_X_TM");
+    return !(v && v[0] == '0');
+  }();
+  const int x_tm = x_tm_enabled && e->tile_major && x16 && d == 1024 && !out_encoded;
+  if (rows > total) {
+    if (x_tm)  // the rows of the last 256-row panel are interleaved: clear the whole panel, the embedding refills it
+      HIP_TRY(hipMemsetAsync((char*)x + (size_t)(rows - 256) * d * xes, 0, (size_t)256 * d * xes, stream));
+    else
+      HIP_TRY(hipMemsetAsync((char*)x + (size_t)total * d * xes, 0, (size_t)(rows - total) * d * xes, stream));
+  }
   { ProfScope ps(e, SMI_PROF_EMBED, stream);
   HIP_TRY(launch_embed_pack(ids, d_cu, e->embed.as<f16>(), e->pos.as<float>(), c.embed_scale,
-                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream, x16, e->bad_ids_dev)); }
+                            c.pos_offset, x, n, s, max_len, d, c.vocab_size, stream, x16, e->bad_ids_dev, x_tm)); }
   // x (residual stream, fp32 or fp16 with SMI_ENC_FP16_RESIDUAL) stays row-major; h, qkv, ctx, ffn and the weights are tile-major
   const int tm = e->tile_major;
   const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
+  const int x_out_tm = x_tm ? GEMM_OUT_TM : 0;
   for (int l = 0; l < c.num_layers; ++l) {
     Layer& L = e->layers[l];
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16)); }
+    HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16, x_tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
                            d, 3 * d, stream)); }
     { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
     HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
     { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
-    HIP_TRY(launch_gemm_tn(epi_resid | in_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
+    HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
                            stream)); }
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
-    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16)); }
+    HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16, x_tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f,
                            stream)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
-    HIP_TRY(launch_gemm_tn(epi_resid | in_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
+    HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
                            stream)); }
   }
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,
-                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream, x16)); }
+                         out_dtype == SMI_F32, out_encoded, n, s, d, c.pooling, stream, x16, x_tm)); }
   return SMI_OK;
 }
 
@@ -507,7 +521,7 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
   if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 9 || sel > 2 || m <= 0 || m % 128 ||
       n <= 0 || n % 128 || k <= 0 || k % 64 || ldo < (e == 6 ? n / 2 : n) || (sel == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
-  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5) : (e != 0 && e != 2 && e != 3 && e != 4 && e != 6 && e != 8 && e != 9))))
+  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5 && e != 8) : (e != 0 && e != 2 && e != 3 && e != 4 && e != 6 && e != 8 && e != 9))))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major gemm: m=%d n=%d epi=%d", m, n, epi);
   if (out_tm && (!in_tm || ldo != n))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n");

@@ -73,7 +73,9 @@ __device__ __forceinline__ half4 epi_act_pack(f32x4 v) {
 }
 
 // LAYOUT: 0 = row-major operands and output; 1 = tile-major X and W (common.hpp), row-major
-// output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N).
+// output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N);
+// 3 = tile-major X, W and a tile-major fp16 RESIDUAL STREAM that is read-modified-written
+// (EPI_RESID_F16 only: the text encoder's x, so that the residual epilogue needs no LDS staging).
 template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
             if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
             *(f32x4*)p = o + v;
           } else if constexpr (EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16) {
-            f16* p = (f16*)out + (size_t)m * ldo + n;
+            f16* p = LAYOUT == 3 ? (f16*)out + tm_offset(m, n, N) : (f16*)out + (size_t)m * ldo + n;
             const half4 o = *(const half4*)p;
             if constexpr (EPI == EPI_RESID_HALF_F16) v = v * 0.5f;
             half4 h;
@@ -324,6 +326,41 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
       }
     }
+    if constexpr (LAYOUT == 3) {
+      // fp16 residual stream in the tile-major layout: read-modify-write straight from the accumulators (no LDS
+      // staging, no barriers).  As in the LAYOUT == 2 store, a 32-column k-block is the accumulator-block pair
+      // A = 2j, B = 2j + 1 and v_permlane16_swap joins lane groups so that every lane owns one whole 16-B chunk --
+      // here on the fp32 values (4 swaps per pair instead of 2), because the residual add is one fp32 add rounded
+      // once.  The 16 old chunks of a wave are requested before the first add.
+      static_assert(EPI == EPI_RESID_F16, "tile-major residual: EPI_RESID_F16 only");
+      const int cidx = (kg & 1) * 2 + (kg >> 1);
+      const int sw = tm_swz(l15);
+      f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
+                   (wr * 128 + l15) * 32 + ((cidx ^ sw) << 3);
+      half8 oldv[8][2];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oldv[mi][j] = *(const half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32));
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 a = acc.v[2 * j][mi], b = acc.v[2 * j + 1][mi];
+          float c8[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const auto sp = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(b[i]), false, false);
+            c8[i] = __uint_as_float(sp[0]);
+            c8[4 + i] = __uint_as_float(sp[1]);
+          }
+          half8 o;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = (f16)((float)oldv[mi][j][i] + c8[i]);
+          *(half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = o;
+        }
+      }
+    } else
     if constexpr (F32_OUT) {
       // fp32 outputs: 8 sub-passes (row pass p, column half nh) of 64 rows x 128 columns (the waves'
       // blocks ni = 2nh, 2nh+1).  The residual values of sub-pass sp+1 are requested before the barrier
@@ -563,11 +600,12 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   case E:                                                                      \
     return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \
                   : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
-  if (out_tm) {  // fp16 outputs that feed the next GEMM
+  if (out_tm) {  // fp16 outputs that feed the next GEMM; EPI_RESID_F16: the tile-major residual stream
     switch (epi) {
       SMI_EPI_CASE(EPI_BIAS_F16, 2)
       SMI_EPI_CASE(EPI_RELU_F16, 2)
       SMI_EPI_CASE(EPI_SILU_F16, 2)
+      SMI_EPI_CASE(EPI_RESID_F16, 3)
     }
     return hipErrorInvalidValue;
   }

@@ -59,12 +59,14 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu_seqlens, const f16* table,
                              const float* pos_table, float scale, int pos_offset, void* x, int N,
                              int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16 = 0,
-                             int32_t* bad = nullptr);
+                             int32_t* bad = nullptr, int x_tm = 0);
 
 // h[r,:] = f16(LN(x[r,:]) * w + b)
 // out_tm: h is written tile-major (rows rounded up to 256 must be allocated)
 hipError_t launch_layernorm(const void* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0);
+                            int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0, int x_tm = 0);
+// x_tm (embed_pack, layernorm, ln_pool): the fp16 residual stream x is itself tile-major (common.hpp), so that
+// the residual GEMM epilogues can read-modify-write it straight from the accumulators (GEMM_OUT_TM + EPI_RESID_F16)
 // dst (tile-major) <- src (row-major [rows][K]), rows % 256 == 0, K % 32 == 0; and the inverse
 hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int inverse, hipStream_t stream);
 
@@ -72,7 +74,7 @@ hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int
 // out: [N, d] in fp16 or fp32; encoded (optional): [N, S, d] same dtype, pads zeroed.
 hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float eps,
                           const int32_t* cu_seqlens, void* out, int out_is_f32, void* encoded, int N,
-                          int S, int d, int pooling, hipStream_t stream, int x_f16 = 0);
+                          int S, int d, int pooling, hipStream_t stream, int x_f16 = 0, int x_tm = 0);
 
 // Self-attention over packed rows. qkv: [T, 3*d] (q | k | v), ctx: [T, d].  head_dim 64.
 // ctx_tm bit 0: ctx is written tile-major; bit 1: qkv is read tile-major (K = 3d).

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
                                                          const float* __restrict__ pos_table,
                                                          float scale, int pos_offset,
                                                          XT* __restrict__ x, int S, int d,
-                                                         int64_t vocab, int32_t* __restrict__ bad) {
+                                                         int64_t vocab, int32_t* __restrict__ bad, int x_tm) {
   const int n = blockIdx.x;
   const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -41,6 +41,8 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
   const float* pe = pos_table + (size_t)(p + pos_offset) * d;
   XT* o = x + (size_t)(start + p) * d;
   for (int c = lane * 8; c < d; c += 512) {
+    // x_tm: the fp16 residual stream is tile-major (common.hpp), a lane's 8 columns are one 16-B chunk
+    XT* oc = x_tm ? x + tm_offset(start + p, c, d) : o + c;
     const half8 ev = *(const half8*)(e + c);
     const f32x4 p0 = *(const f32x4*)(pe + c);
     const f32x4 p1 = *(const f32x4*)(pe + c + 4);
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
       o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
     }
     if constexpr (sizeof(XT) == 4) {
-      *(f32x4*)(o + c) = o0;
-      *(f32x4*)(o + c + 4) = o1;
+      *(f32x4*)(oc) = o0;
+      *(f32x4*)(oc + 4) = o1;
     } else {
       half8 h;
 #pragma unroll
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
         h[i] = (f16)o0[i];
         h[i + 4] = (f16)o1[i];
       }
-      *(half8*)(o + c) = h;
+      *(half8*)(oc) = h;
     }
   }
 }
@@ -69,15 +71,16 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* table,
                              const float* pos_table, float scale, int pos_offset, void* x, int N,
                              int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16,
-                             int32_t* bad) {
+                             int32_t* bad, int x_tm) {
+  if (x_tm && !x_f16) return hipErrorInvalidValue;
   if (d % 8 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(N, (max_len + 3) / 4);
   if (x_f16)
     hipLaunchKernelGGL(embed_pack_kernel<f16>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (f16*)x, S, d, vocab, bad);
+                       pos_offset, (f16*)x, S, d, vocab, bad, x_tm);
   else
     hipLaunchKernelGGL(embed_pack_kernel<float>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (float*)x, S, d, vocab, bad);
+                       pos_offset, (float*)x, S, d, vocab, bad, 0);
   return hipGetLastError();
 }
 
@@ -192,7 +195,7 @@ template <int NV, typename XT>
 __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps,
-                                                           f16* __restrict__ h, int rows) {
+                                                           f16* __restrict__ h, int rows, int x_tm) {
   constexpr int D = NV * 256;
   constexpr int RS = D * 2 + 16;  // LDS row stride in bytes (+16: the 16 rows of a read hit different banks)
   __shared__ __attribute__((aligned(16))) char tile[16 * RS];
@@ -209,7 +212,9 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
       for (int q = 0; q < 4; ++q) {
         const int row = min(r0 + wv + 4 * q, rows - 1);
 #pragma unroll
-        for (int k = 0; k < NH; ++k) raw[q][k] = *(const half8*)(x + (size_t)row * D + k * 512 + lane * 8);
+        for (int k = 0; k < NH; ++k)
+          raw[q][k] = *(const half8*)(x_tm ? x + tm_offset(row, k * 512 + lane * 8, D)
+                                           : x + (size_t)row * D + k * 512 + lane * 8);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -287,13 +292,14 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
 }
 
 hipError_t launch_layernorm(const void* x, const float* w, const float* b, float eps, f16* h,
-                            int rows, int d, hipStream_t stream, int out_tm, int x_f16) {
+                            int rows, int d, hipStream_t stream, int out_tm, int x_f16, int x_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
+  if (x_tm && !(out_tm && x_f16 && d % 512 == 0)) return hipErrorInvalidValue;  // tile-major x: fp16 stream, tile-major h
   const int blocks = out_tm ? min((rows + 15) / 16, 256 * 16) : min((rows + 3) / 4, 256 * 32);
 #define SMI_LN_LAUNCH(NV, XT)                                                                                      \
   if (out_tm)                                                                                                      \
     hipLaunchKernelGGL((layernorm_tm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, \
-                       h, rows);                                                                                   \
+                       h, rows, x_tm);                                                                             \
   else                                                                                                             \
     hipLaunchKernelGGL((layernorm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, h, \
                        rows);
@@ -396,7 +402,7 @@ template <typename OutT>
 __global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, float eps,
                                                               const int32_t* __restrict__ cu, OutT* __restrict__ out,
-                                                              int pooling) {
+                                                              int pooling, int x_tm) {
   constexpr int D = 1024;
   constexpr int NW = 8;  // waves per sentence
   __shared__ __attribute__((aligned(16))) float red[NW][D];
@@ -429,9 +435,14 @@ __global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p = min(p0 + r, len - 1);  // clamped rows are loaded (cached) but not accumulated
-      const f16* xr = x + (size_t)(start + p) * D + lane * 8;
-      v[r][0] = *(const half8*)xr;
-      v[r][1] = *(const half8*)(xr + 512);
+      if (x_tm) {
+        v[r][0] = *(const half8*)(x + tm_offset(start + p, lane * 8, D));
+        v[r][1] = *(const half8*)(x + tm_offset(start + p, 512 + lane * 8, D));
+      } else {
+        const f16* xr = x + (size_t)(start + p) * D + lane * 8;
+        v[r][0] = *(const half8*)xr;
+        v[r][1] = *(const half8*)(xr + 512);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -508,15 +519,16 @@ __global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restr
 
 hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float eps,
                           const int32_t* cu, void* out, int out_is_f32, void* encoded, int N, int S,
-                          int d, int pooling, hipStream_t stream, int x_f16) {
+                          int d, int pooling, hipStream_t stream, int x_f16, int x_tm) {
   if (N <= 0 || pooling < 0 || pooling > 2) return hipErrorInvalidValue;
+  if (x_tm && !(d == 1024 && x_f16 && !encoded)) return hipErrorInvalidValue;  // tile-major x: the fast path only
   if (d == 1024 && x_f16 && !encoded) {
     if (out_is_f32)
       hipLaunchKernelGGL(ln_pool1024_f16_kernel<float>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
-                         (float*)out, pooling);
+                         (float*)out, pooling, x_tm);
     else
       hipLaunchKernelGGL(ln_pool1024_f16_kernel<f16>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
-                         (f16*)out, pooling);
+                         (f16*)out, pooling, x_tm);
     return hipGetLastError();
   }
 #define SMI_LP_LAUNCH(NV, OutT, XT)                                                                               \

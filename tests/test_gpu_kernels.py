@@ -69,7 +69,7 @@ def test_pack_tile_major(lib, rows, k):
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (256, 512, 192), (512, 1024, 1024), (256, 256, 8192),
                                    (1024, 768, 256)])
-@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1), (6, 0), (8, 0)])
+@pytest.mark.parametrize("epi,out_tm", [(0, 0), (0, 1), (1, 1), (2, 0), (3, 0), (4, 0), (5, 1), (6, 0), (8, 0), (8, 1)])
 def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
     """Tile-major operands (and output) on both tile engines against the same fp32 reference."""
     from sonar_amd import _lib
@@ -86,9 +86,9 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
             resid = torch.randn(m, n, device="cuda", generator=g)
             out = resid.clone()
             want = resid + (ref if epi == 2 else 0.5 * ref)
-        elif epi == 8:
+        elif epi == 8:   # fp16 residual stream; out_tm: the stream itself is tile-major (read-modify-write in place)
             resid = torch.randn(m, n, device="cuda", generator=g).half()
-            out = resid.clone()
+            out = to_tile_major(resid) if out_tm else resid.clone()
             want = resid.float() + ref
         elif epi == 3:
             out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
