@@ -15,6 +15,8 @@
 // ds_read_b128), V row-major too and read through the LDS transpose read
 // (ds_read_b64_tr_b16); both arrive by double-buffered global->LDS DMA.  S <= 514 in SONAR, so the
 // kernel is HBM-bound (~64 flop/B); the score matrix never leaves registers.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -47,11 +49,19 @@ __device__ __forceinline__ half4 at_tr_read(unsigned lds_addr) {
 template <bool TM, bool QTM>
 __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
-                                                        f16* __restrict__ ctx, int d, float sl2e) {
+                                                        f16* __restrict__ ctx, int d, float sl2e, int order) {
   constexpr int TILE = AT_KB * 128;  // 8 KiB
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE];  // [buffer][K | V]
 
-  const int n = blockIdx.x, h = blockIdx.y;
+  // order 0: sentence = blockIdx.x, head = blockIdx.y (dispatch order: all sentences of head 0, then head 1, ...).
+  // order 1: the heads of a sentence are dispatched together, so the whole 6 KB qkv rows of a sentence are read at
+  // about the same time (each head's piece is one 128-B line of the row) instead of in 16 passes over the matrix.
+  int n = blockIdx.x, h = blockIdx.y;
+  if (order) {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    h = lin % (int)gridDim.y;
+    n = lin / (int)gridDim.y;
+  }
   const int start = cu[n];
   const int len = cu[n + 1] - start;
   const int q0 = blockIdx.z * AT_QB;
@@ -229,12 +239,16 @@ hipError_t launch_attention(const f16* qkv, const int32_t* cu, f16* ctx, int N, 
   if (heads <= 0 || d != heads * 64 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;  // Dh^-0.5 * log2(e)
   dim3 grid(N, heads, (max_len + AT_QB - 1) / AT_QB);
+  static const int order = [] {  // SMI_ATT_ORDER=0: head-major dispatch (A/B measurements)
+    const char* e = getenv("SMI_ATT_ORDER");
+    return e ? atoi(e) : 1;
+  }();
   // ctx_tm: bit 0 = ctx written tile-major, bit 1 = qkv read tile-major
   switch (ctx_tm & 3) {
-    case 0: hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
-    case 1: hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
-    case 2: hipLaunchKernelGGL((attention_kernel<false, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
-    default: hipLaunchKernelGGL((attention_kernel<true, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e); break;
+    case 0: hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
+    case 1: hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
+    case 2: hipLaunchKernelGGL((attention_kernel<false, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
+    default: hipLaunchKernelGGL((attention_kernel<true, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
   }
   return hipGetLastError();
 }
