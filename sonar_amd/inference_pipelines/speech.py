@@ -144,20 +144,23 @@ class SpeechModelPipelineInterface(torch.nn.Module):
         end = object()
         stop = threading.Event()
 
+        def offer(x) -> bool:  # False once the consumer has gone away (early exit / exception on its side)
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def work():
             try:
                 for hb in self._host_batches(items, batch_size, n_parallel):
-                    while not stop.is_set():
-                        try:
-                            q.put(hb, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not offer(hb):
                         return
-                q.put(end)
+                offer(end)
             except BaseException as e:  # surfaces on the consumer thread
-                q.put(e)
+                offer(e)
 
         th = threading.Thread(target=work, daemon=True)
         th.start()

@@ -71,28 +71,43 @@ def collate(seqs: Sequence[torch.Tensor], pad_value: int) -> dict:
 
 
 def _prefetch(it: Iterator, depth: int) -> Iterator:
-    """`.prefetch(depth)`: run the upstream stages on a background thread."""
+    """`.prefetch(depth)`: run the upstream stages on a background thread.  If the consumer stops early (an
+    exception in the model, a closed generator) the producer is told to stop instead of blocking on a full queue."""
     q: "queue.Queue" = queue.Queue(maxsize=max(depth, 1))
     end = object()
+    stop = threading.Event()
+
+    def offer(x) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(x, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for x in it:
-                q.put(x)
-            q.put(end)
+                if not offer(x):
+                    return
+            offer(end)
         except BaseException as e:  # propagate to the consumer
-            q.put(e)
+            offer(e)
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
-    while True:
-        x = q.get()
-        if x is end:
-            break
-        if isinstance(x, BaseException):
-            raise x
-        yield x
-    th.join()
+    try:
+        while True:
+            x = q.get()
+            if x is end:
+                break
+            if isinstance(x, BaseException):
+                raise x
+            yield x
+    finally:
+        stop.set()
+        th.join(timeout=5)
 
 
 class TextToEmbeddingModelPipeline(torch.nn.Module):
