@@ -14,6 +14,25 @@
 
 namespace smi {
 
+// ------------------------------------------------ tile-major rows, pair map
+// The fp16 residual stream may be TILE-MAJOR (common.hpp tm_offset): rows r, r+1 (r even) of a 32-column
+// block are 128 contiguous bytes.  The row kernels below therefore walk tile-major x in ROW PAIRS:
+//   lane -> block (lane>>3) + 8c, row of the pair (lane>>2)&1, 16-B chunk lane&3
+// so that one wave-wide 16-B access covers 8 FULL 128-B lines (the row-major lane map, lane -> columns
+// lane*8 of ONE row, touches 16 half lines per access on this layout: 0.65-0.75x the bandwidth, r02e).
+// A lane then owns 8 columns of every 256-column group c of its row.
+__device__ __forceinline__ int pair_rsel(int lane) { return (lane >> 2) & 1; }
+__device__ __forceinline__ int pair_col(int lane, int c) { return (((lane >> 3) + 8 * c) << 5) + ((lane & 3) << 3); }
+// sum over the 32 lanes that hold the same row of the pair
+__device__ __forceinline__ float pair_sum(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // ---------------------------------------------------------------- embed+pack
 // grid (N, ceil(max_len/4)), 256 threads: wave w handles position blockIdx.y*4+w
 // of sentence blockIdx.x; rows beyond the sentence length do nothing.
@@ -25,7 +44,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
                                                          const float* __restrict__ pos_table,
                                                          float scale, int pos_offset,
                                                          XT* __restrict__ x, int S, int d,
-                                                         int64_t vocab, int32_t* __restrict__ bad, int x_tm) {
+                                                         int64_t vocab, int32_t* __restrict__ bad) {
   const int n = blockIdx.x;
   const int p = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -41,8 +60,7 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
   const float* pe = pos_table + (size_t)(p + pos_offset) * d;
   XT* o = x + (size_t)(start + p) * d;
   for (int c = lane * 8; c < d; c += 512) {
-    // x_tm: the fp16 residual stream is tile-major (common.hpp), a lane's 8 columns are one 16-B chunk
-    XT* oc = x_tm ? x + tm_offset(start + p, c, d) : o + c;
+    XT* oc = o + c;
     const half8 ev = *(const half8*)(e + c);
     const f32x4 p0 = *(const f32x4*)(pe + c);
     const f32x4 p1 = *(const f32x4*)(pe + c + 4);
@@ -68,6 +86,44 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
   }
 }
 
+// Tile-major residual stream (d % 256 == 0): wave w handles the PAIR of packed rows (ge + 2k, ge + 2k + 1),
+// ge = start & ~1, k = blockIdx.y*4 + w, with the pair map above: table rows are read in 512-B runs, x is
+// written in full 128-B lines.  Rows of the pair outside the sentence belong to a neighbour and are left alone.
+__global__ __launch_bounds__(256) void embed_pack_tm_kernel(const int64_t* __restrict__ ids,
+                                                            const int32_t* __restrict__ cu,
+                                                            const f16* __restrict__ table,
+                                                            const float* __restrict__ pos_table, float scale,
+                                                            int pos_offset, f16* __restrict__ x, int S, int d,
+                                                            int64_t vocab, int32_t* __restrict__ bad) {
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int start = cu[n];
+  const int len = cu[n + 1] - start;
+  const int g = (start & ~1) + 2 * (blockIdx.y * 4 + (threadIdx.x >> 6)) + pair_rsel(lane);
+  const int p = g - start;
+  if (p < 0 || p >= len) return;
+  int64_t tok = ids[(size_t)n * S + p];
+  if (tok < 0 || tok >= vocab) {
+    if (bad && (lane & ~4) == 0) *bad = 1;
+    tok = tok < 0 ? 0 : vocab - 1;
+  }
+  const f16* e = table + (size_t)tok * d;
+  const float* pe = pos_table + (size_t)(p + pos_offset) * d;
+  for (int cg = 0; cg < d / 256; ++cg) {
+    const int c = pair_col(lane, cg);
+    const half8 ev = *(const half8*)(e + c);
+    const f32x4 p0 = *(const f32x4*)(pe + c);
+    const f32x4 p1 = *(const f32x4*)(pe + c + 4);
+    half8 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = (f16)((float)(f16)((float)ev[i] * scale) + p0[i]);
+      h[i + 4] = (f16)((float)(f16)((float)ev[i + 4] * scale) + p1[i]);
+    }
+    *(half8*)(x + tm_offset(g, c, d)) = h;
+  }
+}
+
 hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* table,
                              const float* pos_table, float scale, int pos_offset, void* x, int N,
                              int S, int max_len, int d, int64_t vocab, hipStream_t stream, int x_f16,
@@ -75,12 +131,19 @@ hipError_t launch_embed_pack(const int64_t* ids, const int32_t* cu, const f16* t
   if (x_tm && !x_f16) return hipErrorInvalidValue;
   if (d % 8 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(N, (max_len + 3) / 4);
+  if (x_tm) {
+    if (d % 256) return hipErrorInvalidValue;
+    // pairs per sentence: up to max_len/2 + 1 (a sentence starting on an odd row straddles one more pair)
+    hipLaunchKernelGGL(embed_pack_tm_kernel, dim3(N, (max_len / 2 + 1 + 3) / 4), dim3(256), 0, stream, ids, cu, table,
+                       pos_table, scale, pos_offset, (f16*)x, S, d, vocab, bad);
+    return hipGetLastError();
+  }
   if (x_f16)
     hipLaunchKernelGGL(embed_pack_kernel<f16>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (f16*)x, S, d, vocab, bad, x_tm);
+                       pos_offset, (f16*)x, S, d, vocab, bad);
   else
     hipLaunchKernelGGL(embed_pack_kernel<float>, grid, dim3(256), 0, stream, ids, cu, table, pos_table, scale,
-                       pos_offset, (float*)x, S, d, vocab, bad, 0);
+                       pos_offset, (float*)x, S, d, vocab, bad);
   return hipGetLastError();
 }
 
@@ -191,18 +254,70 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const XT* __restrict__ x
 // rows into an LDS tile and then writes them out per 32-column k-block: 16 rows x 64 B are one
 // contiguous 1 KiB run of a tile-major block, i.e. one fully coalesced wave store (a row-at-a-time
 // writer would scatter 64-B pieces 16 KiB apart).  h holds rows rounded up to 16 (256 in practice).
-template <int NV, typename XT>
+template <int NV, typename XT, bool XTM>
 __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ b, float eps,
-                                                           f16* __restrict__ h, int rows, int x_tm) {
+                                                           f16* __restrict__ h, int rows) {
   constexpr int D = NV * 256;
   constexpr int RS = D * 2 + 16;  // LDS row stride in bytes (+16: the 16 rows of a read hit different banks)
   __shared__ __attribute__((aligned(16))) char tile[16 * RS];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   for (int r0 = blockIdx.x * 16; r0 < rows; r0 += gridDim.x * 16) {
-    if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
+    if constexpr (XTM) {
+      // tile-major fp16 x: pair map (top of file).  Wave wv owns rows 4wv..4wv+3 of the group as two row pairs,
+      // a lane holds 8 columns of each 256-column group of ITS row of each pair; all loads are in flight
+      // before the first reduction.  r0 is a multiple of 16, so the pairs are line aligned.
+      static_assert(sizeof(XT) == 2, "tile-major x is fp16");
+      const int rsel = pair_rsel(lane);
+      half8 raw[2][NV];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = r0 + 4 * wv + 2 * j + rsel;  // < padded rows: x is allocated in whole 256-row panels
+#pragma unroll
+        for (int k = 0; k < NV; ++k) raw[j][k] = *(const half8*)(x + tm_offset(row, pair_col(lane, k), D));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int lr = 4 * wv + 2 * j + rsel;
+        float v[NV][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v[k][i] = (float)raw[j][k][i];
+            sum += v[k][i];
+          }
+        constexpr float inv_d = 1.0f / D;
+        const float mean = pair_sum(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v[k][i] -= mean;
+            sq += v[k][i] * v[k][i];
+          }
+        const float var = pair_sum(sq) * inv_d;
+        const float rstd = r0 + lr < rows ? 1.0f / sqrtf(var + eps) : 0.f;
+        const float keep = r0 + lr < rows ? 1.f : 0.f;  // rows past the end of x: zeros
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const int c = pair_col(lane, k);
+          const f32x4 w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
+          const f32x4 b0 = *(const f32x4*)(b + c), b1 = *(const f32x4*)(b + c + 4);
+          half8 o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = (f16)(v[k][i] * rstd * w0[i] + keep * b0[i]);
+            o[4 + i] = (f16)(v[k][4 + i] * rstd * w1[i] + keep * b1[i]);
+          }
+          *(half8*)(tile + lr * RS + c * 2) = o;
+        }
+      }
+    } else if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
       // fp16 stream: a lane owns 8 consecutive columns per 512-column block, so every global load and
       // every LDS store moves 16 B per lane (8-B accesses run at 0.54-0.70x the 16-B rate), and the
       // loads of the wave's 4 rows are all in flight before the first reduction
@@ -213,8 +328,7 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
         const int row = min(r0 + wv + 4 * q, rows - 1);
 #pragma unroll
         for (int k = 0; k < NH; ++k)
-          raw[q][k] = *(const half8*)(x_tm ? x + tm_offset(row, k * 512 + lane * 8, D)
-                                           : x + (size_t)row * D + k * 512 + lane * 8);
+          raw[q][k] = *(const half8*)(x + (size_t)row * D + k * 512 + lane * 8);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -297,9 +411,12 @@ hipError_t launch_layernorm(const void* x, const float* w, const float* b, float
   if (x_tm && !(out_tm && x_f16 && d % 512 == 0)) return hipErrorInvalidValue;  // tile-major x: fp16 stream, tile-major h
   const int blocks = out_tm ? min((rows + 15) / 16, 256 * 16) : min((rows + 3) / 4, 256 * 32);
 #define SMI_LN_LAUNCH(NV, XT)                                                                                      \
-  if (out_tm)                                                                                                      \
-    hipLaunchKernelGGL((layernorm_tm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, \
-                       h, rows, x_tm);                                                                             \
+  if (out_tm && x_tm)                                                                                              \
+    hipLaunchKernelGGL((layernorm_tm_kernel<NV, f16, true>), dim3(blocks), dim3(256), 0, stream, (const f16*)x, w, \
+                       b, eps, h, rows);                                                                           \
+  else if (out_tm)                                                                                                 \
+    hipLaunchKernelGGL((layernorm_tm_kernel<NV, XT, false>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w,  \
+                       b, eps, h, rows);                                                                           \
   else                                                                                                             \
     hipLaunchKernelGGL((layernorm_kernel<NV, XT>), dim3(blocks), dim3(256), 0, stream, (const XT*)x, w, b, eps, h, \
                        rows);
@@ -395,123 +512,129 @@ __global__ __launch_bounds__(256) void ln_pool_kernel(const XT* __restrict__ x,
 
 // Fast path of the headline configuration (d = 1024, fp16 residual stream, no `encoded_seqs` output): the
 // kernel is a pure HBM read (2 KB per token in, 2-4 KB per SENTENCE out), so all that matters is bytes in
-// flight: a lane owns 8 consecutive columns of each 512-column half (16-B loads), and the 8 loads of a
-// wave's 4 rows are issued before the first reduction (the generic kernel above walks one row at a time with
-// 8-B loads: 3.9 TB/s; this one: see DESIGN.md 3).
-template <typename OutT>
-__global__ __launch_bounds__(512) void ln_pool1024_f16_kernel(const f16* __restrict__ x, const float* __restrict__ w,
+// flight: 16-B loads, all loads of a wave step issued before the first reduction (the generic kernel above
+// walks one row at a time with 8-B loads: 3.9 TB/s).  Template shape: NW waves per sentence, NR rows per lane and
+// step, MINW = waves/SIMD the register budget must allow.  Sentences are short (16 tokens in the headline
+// workload = 32 KB), so the kernel is a latency chain per sentence and what pays is SENTENCES in flight per CU:
+// tile-major x, mean pooling: 4 waves x 1 row pair, 4 workgroups per CU (63 us; 8 waves x 2 pairs needs 168
+// VGPRs = 1 workgroup per CU: 71 us; r02 experiment 15).
+// Lane -> data map of a wave step (4 rows): row-major x: 2 chunks (columns h*512 + lane*8) of all 4 rows;
+// tile-major x: the pair map at the top of the file, 4 chunks of the lane's row of each of the 2 row pairs.
+template <bool TM, int NR_>
+struct PoolMap {
+  static constexpr int NR = NR_;                  // rows per lane and step
+  static constexpr int STEP = TM ? 2 * NR_ : NR_;  // rows per wave and step
+  static constexpr int NC = TM ? 4 : 2;  // 16-B chunks per row
+  __device__ static int row(int lane, int j) { return TM ? 2 * j + pair_rsel(lane) : j; }
+  __device__ static int col(int lane, int c) { return TM ? pair_col(lane, c) : c * 512 + lane * 8; }
+  __device__ static float row_sum(float v) { return TM ? pair_sum(v) : wave_sum(v); }
+};
+
+template <typename OutT, bool TM, bool MEAN, int NW, int NR, int MINW>  // MEAN: pooling == 0 (compile time: the other modes hold w, b per lane)
+__global__ __launch_bounds__(NW * 64, MINW) void ln_pool1024_f16_kernel(const f16* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, float eps,
                                                               const int32_t* __restrict__ cu, OutT* __restrict__ out,
-                                                              int pooling, int x_tm) {
+                                                              int pooling) {
+  using M = PoolMap<TM, NR>;
   constexpr int D = 1024;
-  constexpr int NW = 8;  // waves per sentence
   __shared__ __attribute__((aligned(16))) float red[NW][D];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int start = cu[n];
   const int len = cu[n + 1] - start;
-  float wr[2][8], br[2][8];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const f32x4 w0 = *(const f32x4*)(w + h * 512 + lane * 8), w1 = *(const f32x4*)(w + h * 512 + lane * 8 + 4);
-    const f32x4 b0 = *(const f32x4*)(b + h * 512 + lane * 8), b1 = *(const f32x4*)(b + h * 512 + lane * 8 + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      wr[h][e] = w0[e];
-      wr[h][4 + e] = w1[e];
-      br[h][e] = b0[e];
-      br[h][4 + e] = b1[e];
-    }
-  }
+  const int end = start + len;
   const float init = pooling == 1 ? -INFINITY : 0.f;
-  float acc[2][8];
+  float acc[M::NC][8];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int c = 0; c < M::NC; ++c)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[h][e] = init;
-  // wave wv owns rows wv*4 + 4*NW*i + (0..3)
-  for (int p0 = wv * 4; p0 < len; p0 += 4 * NW) {
-    half8 v[4][2];
+    for (int e = 0; e < 8; ++e) acc[c][e] = init;
+  // wave wv owns packed rows g0 .. g0+3, g0 = base + 4*(wv + NW*i); tile-major: base is even so that the row
+  // pairs are line aligned (the row in front of an odd start belongs to the previous sentence: read, not pooled)
+  const int base = TM ? (start & ~1) : start;
+  for (int g0 = base + wv * M::STEP; g0 < end; g0 += M::STEP * NW) {
+    half8 v[M::NR][M::NC];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = min(p0 + r, len - 1);  // clamped rows are loaded (cached) but not accumulated
-      if (x_tm) {
-        v[r][0] = *(const half8*)(x + tm_offset(start + p, lane * 8, D));
-        v[r][1] = *(const half8*)(x + tm_offset(start + p, 512 + lane * 8, D));
-      } else {
-        const f16* xr = x + (size_t)(start + p) * D + lane * 8;
-        v[r][0] = *(const half8*)xr;
-        v[r][1] = *(const half8*)(xr + 512);
-      }
+    for (int j = 0; j < M::NR; ++j) {
+      const int g = min(g0 + M::row(lane, j), end - 1);  // clamped rows are loaded (cached) but not accumulated
+#pragma unroll
+      for (int c = 0; c < M::NC; ++c)
+        v[j][c] = *(const half8*)(TM ? x + tm_offset(g, M::col(lane, c), D) : x + (size_t)g * D + M::col(lane, c));
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float f[2][8];
+    for (int j = 0; j < M::NR; ++j) {
+      float f[M::NC][8];
       float sum = 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int c = 0; c < M::NC; ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          f[h][e] = (float)v[r][h][e];
-          sum += f[h][e];
+          f[c][e] = (float)v[j][c][e];
+          sum += f[c][e];
         }
-      const float mean = wave_sum(sum) * (1.0f / D);
+      const float mean = M::row_sum(sum) * (1.0f / D);
       float q = 0.f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int c = 0; c < M::NC; ++c)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          f[h][e] -= mean;
-          q += f[h][e] * f[h][e];
+          f[c][e] -= mean;
+          q += f[c][e] * f[c][e];
         }
-      const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
-      const bool live = p0 + r < len;
-      const bool last = p0 + r == len - 1;
-      if (pooling == 0) {
-        // mean pooling: sum_r LN(x_r) = w * sum_r (x_r - mean_r) * rstd_r + n * b -- the affine part is applied once
-        // per sentence after the row loop (one fma per element and row here; the kernel is VALU-bound otherwise)
+      const float rstd = 1.0f / sqrtf(M::row_sum(q) * (1.0f / D) + eps);
+      const int g = g0 + M::row(lane, j);
+      const bool live = g >= start && g < end;
+      const bool last = g == end - 1;
+      if constexpr (MEAN) {
+        // mean pooling: sum_r LN(x_r) = w * sum_r (x_r - mean_r) * rstd_r + len * b (one fma per element and row
+        // here; the kernel is VALU-bound otherwise)
         const float sc = live ? rstd : 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int c = 0; c < M::NC; ++c)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[h][e] = __builtin_fmaf(f[h][e], sc, acc[h][e]);
+          for (int e = 0; e < 8; ++e) acc[c][e] = __builtin_fmaf(f[c][e], sc, acc[c][e]);
       } else {
+        // max / last pooling need the affine part per row; w, b are re-read (L1) to keep the mean path's registers
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int c = 0; c < M::NC; ++c) {
+          const int col = M::col(lane, c);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float y = f[h][e] * rstd * wr[h][e] + br[h][e];
+            const float y = f[c][e] * rstd * w[col + e] + b[col + e];
             if (pooling == 1)
-              acc[h][e] = live ? fmaxf(acc[h][e], y) : acc[h][e];
+              acc[c][e] = live ? fmaxf(acc[c][e], y) : acc[c][e];
             else if (last)
-              acc[h][e] = y;
+              acc[c][e] = y;
           }
+        }
       }
     }
   }
-  if (pooling == 0) {  // rows owned by this wave: p = wv*4 + 32*i + r < len
-    int nrows = 0;
-    for (int p0 = wv * 4; p0 < len; p0 += 4 * NW) nrows += min(4, len - p0);
+  if constexpr (TM) {  // the two rows of a pair sit in lanes 4 apart: fold them, the even-row lanes publish
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int c = 0; c < M::NC; ++c)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[h][e] = acc[h][e] * wr[h][e] + (float)nrows * br[h][e];
+      for (int e = 0; e < 8; ++e) {
+        const float o = __shfl_xor(acc[c][e], 4, 64);
+        acc[c][e] = pooling == 1 ? fmaxf(acc[c][e], o) : acc[c][e] + o;
+      }
   }
+  if (!TM || pair_rsel(lane) == 0) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[wv][h * 512 + lane * 8 + e] = acc[h][e];
+    for (int c = 0; c < M::NC; ++c) {
+      float* r = &red[wv][M::col(lane, c)];
+      *(f32x4*)r = f32x4{acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+      *(f32x4*)(r + 4) = f32x4{acc[c][4], acc[c][5], acc[c][6], acc[c][7]};
+    }
+  }
   __syncthreads();
   // reference (model.py:115-124): weights = 1/(seq_len + 1e-7), in fp32 here
   const float wgt = 1.0f / ((float)len + 1e-7f);
   for (int c = threadIdx.x; c < D; c += 64 * NW) {
-    float v;
-    if (pooling == 1)
-      v = fmaxf(fmaxf(fmaxf(red[0][c], red[1][c]), fmaxf(red[2][c], red[3][c])),
-                fmaxf(fmaxf(red[4][c], red[5][c]), fmaxf(red[6][c], red[7][c])));
-    else
-      v = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
-    if (pooling == 0) v *= wgt;
+    float v = red[0][c];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) v = pooling == 1 ? fmaxf(v, red[i][c]) : v + red[i][c];
+    if (MEAN) v = (v * w[c] + (float)len * b[c]) * wgt;
     if (len <= 0) v = 0.f;
     out[(size_t)n * D + c] = (OutT)v;
   }
@@ -523,12 +646,28 @@ hipError_t launch_ln_pool(const void* x, const float* w, const float* b, float e
   if (N <= 0 || pooling < 0 || pooling > 2) return hipErrorInvalidValue;
   if (x_tm && !(d == 1024 && x_f16 && !encoded)) return hipErrorInvalidValue;  // tile-major x: the fast path only
   if (d == 1024 && x_f16 && !encoded) {
-    if (out_is_f32)
-      hipLaunchKernelGGL(ln_pool1024_f16_kernel<float>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
-                         (float*)out, pooling, x_tm);
-    else
-      hipLaunchKernelGGL(ln_pool1024_f16_kernel<f16>, dim3(N), dim3(512), 0, stream, (const f16*)x, w, b, eps, cu,
-                         (f16*)out, pooling, x_tm);
+#define SMI_LP1024_K(OutT, TM, MEAN, NW, NR, MINW)                                                                  \
+  hipLaunchKernelGGL((ln_pool1024_f16_kernel<OutT, TM, MEAN, NW, NR, MINW>), dim3(N), dim3(NW * 64), 0, stream,      \
+                     (const f16*)x, w, b, eps, cu, (OutT*)out, pooling)
+#define SMI_LP1024(OutT)                                  \
+  if (pooling != 0) {                                     \
+    if (x_tm) {                                           \
+      SMI_LP1024_K(OutT, true, false, 8, 2, 2);           \
+    } else {                                              \
+      SMI_LP1024_K(OutT, false, false, 8, 4, 2);          \
+    }                                                     \
+  } else if (!x_tm) {                                     \
+    SMI_LP1024_K(OutT, false, true, 8, 4, 4);             \
+  } else {                                                \
+    SMI_LP1024_K(OutT, true, true, 4, 1, 4);              \
+  }
+    if (out_is_f32) {
+      SMI_LP1024(float)
+    } else {
+      SMI_LP1024(f16)
+    }
+#undef SMI_LP1024_K
+#undef SMI_LP1024
     return hipGetLastError();
   }
 #define SMI_LP_LAUNCH(NV, OutT, XT)                                                                               \
