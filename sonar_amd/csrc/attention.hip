@@ -47,7 +47,7 @@ __device__ __forceinline__ half4 at_tr_read(unsigned lds_addr) {
 // [4 keys][16 dims] block and every lane receives the 4 keys of its dim, i.e. the V^T fragment without
 // a transposed copy (keys r, r+2 of a group sit in different halves of the 128-B row: all 64 banks).
 template <bool TM, bool QTM>
-__global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ qkv,
+__global__ __launch_bounds__(256, 4) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         f16* __restrict__ ctx, int d, float sl2e, int order) {
   constexpr int TILE = AT_KB * 128;  // 8 KiB
@@ -124,95 +124,83 @@ __global__ __launch_bounds__(256) void attention_kernel(const f16* __restrict__ 
     if (kv0 + AT_KB < len) stage(kv0 + AT_KB, (t + 1) & 1);
     const char* Ks = lds + (t & 1) * 2 * TILE;
 
-    // ---- S^T = K . Q^T for 2 blocks of 32 keys ----
-    f32x16 s[2];
+    // The tile's two 32-key blocks are taken one after the other, each with its own online-softmax step: only
+    // 16 scores, 8 P values and 16 V^T registers are live at a time (the 64-key version needed 131 VGPRs =
+    // 3 workgroups per CU; the kernel is a short latency chain per workgroup, so resident workgroups are what pays).
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // ---- S^T = K . Q^T, 32 keys ----
+      f32x16 sc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) sc[r] = 0.f;
       const int krow = kb * 32 + l31;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const half8 kf = *(const half8*)(Ks + krow * 128 + (((ks * 2 + hi) ^ ((krow >> 1) & 7)) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sc, 0, 0, 0);
       }
-    }
-
-    // ---- online softmax (per query = per lane, halves joined by one shuffle) ----
-    if (kv0 + AT_KB > len) {  // only the last tile of a sentence has keys to mask
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      // ---- online softmax (per query = per lane, halves joined by one shuffle) ----
+      if (kv0 + AT_KB > len) {  // only the last tile of a sentence has keys to mask
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= len) s[kb][r] = -INFINITY;
-    }
-    float mx = s[0][0];
+          if (kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= len) sc[r] = -INFINITY;
+      }
+      float mx = sc[0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;  // sl2e > 0: the scaled maximum
+      // Lazy rescale: the reference m only moves when some query's block maximum exceeds it by more than
+      // 2^8; until then p = exp2(x - m) <= 256 (fine in fp32 and for the fp16 P operand) and the 32
+      // output accumulators are left alone.
+      if (__any(mx > m + 8.0f)) {
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        lsum *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;  // sl2e > 0: the scaled maximum
-    // Lazy rescale: the reference m only moves when some query's tile maximum exceeds it by more than
-    // 2^8; until then p = exp2(x - m) <= 256 (fine in fp32 and for the fp16 P operand) and the 32
-    // output accumulators are left alone.
-    if (__any(mx > m + 8.0f)) {
-      const float m_new = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-      m = m_new;
-      lsum *= alpha;
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    float psum = 0.f;
-    half8 pf[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      float psum = 0.f;
+      half8 pf[2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], sl2e, -m));
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], sl2e, -m));
         psum += p;
-        pf[kb][r >> 3][r & 7] = (f16)p;
+        pf[r >> 3][r & 7] = (f16)p;
       }
-    lsum += psum;
+      lsum += psum;
 
-    // ---- O^T += V^T . P^T ----
-    half4 va[2][2][2][2];  // [db][kb][u][part]
+      // ---- O^T += V^T . P^T ----
+      half4 va[2][2][2];  // [db][u][part]
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
-      const unsigned a = vaddr[db] + (t & 1) * 2 * TILE;
-      va[db][0][0][0] = at_tr_read<0>(a);
-      va[db][0][0][1] = at_tr_read<1024>(a);
-      va[db][0][1][0] = at_tr_read<2048>(a);
-      va[db][0][1][1] = at_tr_read<3072>(a);
-      va[db][1][0][0] = at_tr_read<4096>(a);
-      va[db][1][0][1] = at_tr_read<5120>(a);
-      va[db][1][1][0] = at_tr_read<6144>(a);
-      va[db][1][1][1] = at_tr_read<7168>(a);
-    }
-    // the wait carries the results as operands: the MFMAs below depend on IT, not just on the reads
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(va[0][0][0][0]), "+v"(va[0][0][0][1]), "+v"(va[0][0][1][0]), "+v"(va[0][0][1][1]),
-                   "+v"(va[0][1][0][0]), "+v"(va[0][1][0][1]), "+v"(va[0][1][1][0]), "+v"(va[0][1][1][1]),
-                   "+v"(va[1][0][0][0]), "+v"(va[1][0][0][1]), "+v"(va[1][0][1][0]), "+v"(va[1][0][1][1]),
-                   "+v"(va[1][1][0][0]), "+v"(va[1][1][0][1]), "+v"(va[1][1][1][0]), "+v"(va[1][1][1][1])
-                 :
-                 : "memory");
+      for (int db = 0; db < 2; ++db) {
+        const unsigned a = vaddr[db] + (t & 1) * 2 * TILE + kb * 4096;
+        va[db][0][0] = at_tr_read<0>(a);
+        va[db][0][1] = at_tr_read<1024>(a);
+        va[db][1][0] = at_tr_read<2048>(a);
+        va[db][1][1] = at_tr_read<3072>(a);
+      }
+      // the wait carries the results as operands: the MFMAs below depend on IT, not just on the reads
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]),
+                     "+v"(va[1][0][0]), "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1])
+                   :
+                   : "memory");
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           half8 vf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            vf[e] = va[db][kb][u][0][e];
-            vf[e + 4] = va[db][kb][u][1][e];
+            vf[e] = va[db][u][0][e];
+            vf[e + 4] = va[db][u][1][e];
           }
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][u], o[db], 0, 0, 0);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
         }
+    }
   }
 
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
