@@ -181,37 +181,34 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
   for (int j0 = 0; j0 <= pos; j0 += 64) {
     float s[8];
-    // positions j0 + it*8 + pg; only the `nit` 8-position groups that hold a position <= pos are touched
-    // (uniform per wave).  The kernel is bound by the CU's vector-memory path (every K / V row piece is a
-    // 16-B lane load), so the masked tail of the last 64-position chunk must not issue loads at all.
-    const int nit = min(8, (pos - j0) / 8 + 1);
-    half8 kr[8], vr[8];
-    // all K rows and all V rows (the V row follows its K row at +d) are requested before the first score
-    // is formed: one memory round trip per 64 positions instead of two
-#pragma unroll
-    for (int it = 0; it < 8; ++it)
-      if (it < nit) {
-        const int j = j0 + it * 8 + pg;
-        const bool valid = j <= pos;
-        const int src = valid ? (j == pos ? r : ar[j]) : r;
-        const f16* row = kbase + (size_t)(valid ? j : pos) * slab + (size_t)src * ld;  // masked lanes: own row (cached)
-        kr[it] = *(const half8*)row;
-        vr[it] = *(const half8*)(row + d);
-      }
+    // masked positions (j > pos) load ONE shared cached line (position 0, slot 0) in straight-line code: skipping
+    // them per 8-position group (uniform branches) measured 4.38 against 4.26 ms per step (r02 experiment 20)
+    const f16* row[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      s[it] = -INFINITY;
-      if (it < nit) {
-        const bool valid = j0 + it * 8 + pg <= pos;
-        const half8 kk = kr[it];
-        float acc = 0.f;
+      const int j = j0 + it * 8 + pg;
+      const bool valid = j <= pos;
+      const int src = valid ? (j == pos ? r : ar[j]) : 0;
+      row[it] = kbase + (size_t)(valid ? j : 0) * slab + (size_t)src * ld;
+    }
+    // all 8 K rows and all 8 V rows (the V row follows its K row at +d) are requested before the
+    // first score is formed: one memory round trip per 64 positions instead of two
+    half8 kr[8], vr[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += q[e] * (float)kk[e];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        s[it] = valid ? acc : -INFINITY;
-      }
+    for (int it = 0; it < 8; ++it) kr[it] = *(const half8*)row[it];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) vr[it] = *(const half8*)(row[it] + d);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const bool valid = j0 + it * 8 + pg <= pos;
+      const half8 kk = kr[it];
+      float acc = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += q[e] * (float)kk[e];
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      s[it] = valid ? acc : -INFINITY;
     }
     float mx = s[0];
 #pragma unroll
@@ -235,12 +232,11 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
-    for (int it = 0; it < 8; ++it)
-      if (it < nit) {
-        const half8 vv = vr[it];
+    for (int it = 0; it < 8; ++it) {
+      const half8 vv = vr[it];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] += s[it] * (float)vv[e];
-      }
+      for (int e = 0; e < 8; ++e) o[e] += s[it] * (float)vv[e];
+    }
   }
   half8 out;
 #pragma unroll
