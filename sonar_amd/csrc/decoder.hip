@@ -157,6 +157,10 @@ hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t
 // every load instruction fetches 8 whole 128-B K (or V) rows as 16 B per lane, a score is joined
 // across the 8 lanes of its position by 3 xor-shuffles, the softmax statistics across the 8 position
 // groups by 3 more, and the probabilities never leave the lanes that multiply them into V.
+// NG = 8-position groups per chunk (chunk = 8 NG positions), chosen by the launcher: the first chunk is rarely full at
+// decode time, and a compile-time chunk size keeps the loop body straight-line (run-time skipping of masked groups
+// was slower than loading them, r02 experiment 20).
+template <int NG>
 __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restrict__ kv,
                                                             const int32_t* __restrict__ anc,
                                                             int anc_stride, f16* __restrict__ ctx,
@@ -179,13 +183,13 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
   float o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  for (int j0 = 0; j0 <= pos; j0 += 64) {
-    float s[8];
+  for (int j0 = 0; j0 <= pos; j0 += 8 * NG) {
+    float s[NG];
     // masked positions (j > pos) load ONE shared cached line (position 0, slot 0) in straight-line code: skipping
     // them per 8-position group (uniform branches) measured 4.38 against 4.26 ms per step (r02 experiment 20)
-    const f16* row[8];
+    const f16* row[NG];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NG; ++it) {
       const int j = j0 + it * 8 + pg;
       const bool valid = j <= pos;
       const int src = valid ? (j == pos ? r : ar[j]) : 0;
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
     }
     // all 8 K rows and all 8 V rows (the V row follows its K row at +d) are requested before the
     // first score is formed: one memory round trip per 64 positions instead of two
-    half8 kr[8], vr[8];
+    half8 kr[NG], vr[NG];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) kr[it] = *(const half8*)row[it];
+    for (int it = 0; it < NG; ++it) kr[it] = *(const half8*)row[it];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) vr[it] = *(const half8*)(row[it] + d);
+    for (int it = 0; it < NG; ++it) vr[it] = *(const half8*)(row[it] + d);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NG; ++it) {
       const bool valid = j0 + it * 8 + pg <= pos;
       const half8 kk = kr[it];
       float acc = 0.f;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
     }
     float mx = s[0];
 #pragma unroll
-    for (int it = 1; it < 8; ++it) mx = fmaxf(mx, s[it]);
+    for (int it = 1; it < NG; ++it) mx = fmaxf(mx, s[it]);
     mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     float ps = 0.f;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NG; ++it) {
       s[it] = __builtin_amdgcn_exp2f(s[it] - m_new);  // 0 for masked positions
       ps += s[it];
     }
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NG; ++it) {
       const half8 vv = vr[it];
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += s[it] * (float)vv[e];
@@ -254,8 +258,25 @@ hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_strid
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream) {
   const float sl2e = 0.125f * 1.4426950408889634f;
   const int waves = rows * heads;
-  hipLaunchKernelGGL(dec_attention_kernel, dim3((waves + 3) / 4), dim3(256), 0, stream, kv, anc,
-                     anc_stride, ctx, rows, rows_pad, d, heads, pos, sl2e);
+  const dim3 grid((waves + 3) / 4);
+#define SMI_DA_LAUNCH(NG)                                                                                          \
+  hipLaunchKernelGGL(dec_attention_kernel<NG>, grid, dim3(256), 0, stream, kv, anc, anc_stride, ctx, rows, rows_pad, \
+                     d, heads, pos, sl2e)
+  // as few passes as 64-position chunks would need (each pass is a dependent memory round trip), and the smallest
+  // chunk that covers positions 0..pos in that many passes
+  const int passes = pos / 64 + 1;
+  const int ng = (pos / 8 + 1 + passes - 1) / passes;
+  switch (ng) {
+    case 1: SMI_DA_LAUNCH(1); break;
+    case 2: SMI_DA_LAUNCH(2); break;
+    case 3: SMI_DA_LAUNCH(3); break;
+    case 4: SMI_DA_LAUNCH(4); break;
+    case 5: SMI_DA_LAUNCH(5); break;
+    case 6: SMI_DA_LAUNCH(6); break;
+    case 7: SMI_DA_LAUNCH(7); break;
+    default: SMI_DA_LAUNCH(8); break;
+  }
+#undef SMI_DA_LAUNCH
   return hipGetLastError();
 }
 
