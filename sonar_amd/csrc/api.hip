@@ -85,6 +85,8 @@ struct smi_text_encoder {
   // workspace (capacity in packed+padded token rows)
   int64_t cap_rows = 0;
   DevBuf x, h, qkv, ctx, ffn;
+  DevBuf parts;  // fp32 split-K slabs of the FFN output projection (small batches only)
+  int num_cus = 256;
   // cu_seqlens staging ring: pinned host + device copies
   int32_t* h_cu[kCuRing] = {};
   DevBuf d_cu[kCuRing];
@@ -279,6 +281,12 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
       if (rc == SMI_OK) rc = to_tile_major(L.w_2, (int)d, (int)f);
     }
   }
+  {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      e->num_cus = cus;
+  }
   if (rc == SMI_OK && max_tokens_hint > 0) rc = ensure_workspace(e, (max_tokens_hint + 255) / 256 * 256);
   if (rc != SMI_OK) {
     delete e;
@@ -301,7 +309,7 @@ void smi_text_encoder_destroy(smi_text_encoder* enc) {
 
 int64_t smi_text_encoder_device_bytes(const smi_text_encoder* e) {
   if (!e) return 0;
-  return e->weight_bytes + (int64_t)(e->x.bytes + e->h.bytes + e->qkv.bytes + e->ctx.bytes + e->ffn.bytes);
+  return e->weight_bytes + (int64_t)(e->x.bytes + e->h.bytes + e->qkv.bytes + e->ctx.bytes + e->ffn.bytes + e->parts.bytes);
 }
 
 int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int32_t* seq_lens,
@@ -374,7 +382,20 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     const char* v = getenv("SMI_ENC_X_TM");
     return !(v && v[0] == '0');
   }();
-  const int x_tm = x_tm_enabled && e->tile_major && x16 && d == 1024 && !out_encoded;
+  // Small batches: the FFN output projection (K = ffn_inner_dim) has (M/256)*(d/256) output tiles -- a handful of
+  // CUs would each walk 256 K slices (C1, 1312 tokens: 130 us per layer, 3/4 of the forward).  It is then run as a
+  // split-K GEMM into fp32 slabs (ks * tiles units, one round on the chip) that a small kernel folds into x.
+  int ffn2_ks = 1;
+  {
+    const int64_t tiles = (rows / 256) * (d / 256);
+    while (ffn2_ks < 8 && tiles * ffn2_ks * 2 <= e->num_cus && f % (ffn2_ks * 2 * 512) == 0) ffn2_ks *= 2;
+    if (d % 256 || ffn2_ks < 2) ffn2_ks = 1;
+  }
+  if (ffn2_ks > 1 && e->parts.bytes < (size_t)ffn2_ks * rows * d * 4) {
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(e->parts.alloc((size_t)ffn2_ks * rows * d * 4));
+  }
+  const int x_tm = x_tm_enabled && e->tile_major && x16 && d == 1024 && !out_encoded && ffn2_ks == 1;
   if (rows > total) {
     if (x_tm)  // the rows of the last 256-row panel are interleaved: clear the whole panel, the embedding refills it
       HIP_TRY(hipMemsetAsync((char*)x + (size_t)(rows - 256) * d * xes, 0, (size_t)256 * d * xes, stream));
@@ -406,8 +427,14 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f,
                            stream)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
-    HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
-                           stream)); }
+    if (ffn2_ks > 1) {
+      HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), e->parts.as<float>(), M, d, f, ffn2_ks,
+                                    stream, tm));
+      HIP_TRY(launch_fold_residual(x, x16, e->parts.as<float>(), ffn2_ks, (size_t)M * d, (size_t)M * d, stream));
+    } else {
+      HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
+                             stream));
+    } }
   }
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);
   HIP_TRY(launch_ln_pool(x, e->lnf_w.as<float>(), e->lnf_b.as<float>(), c.ln_eps, d_cu, out_emb,

@@ -9,6 +9,8 @@
 //  * LayerNorm : StandardLayerNorm(d, bias=True), eps 1e-5 (factory.py:117)
 //  * pooling   : SonarTextTransformerEncoderModel.static_pooling,
 //                sonar/models/sonar_text/model.py:86-128
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -725,6 +727,63 @@ hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int
   if (rows <= 0 || rows % TM_ROWS || K <= 0 || K % 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pack_tile_major_kernel, dim3(K / 32, rows / 256), dim3(256), 0, stream, src, dst, K,
                      inverse);
+  return hipGetLastError();
+}
+
+// ------------------------------------------- split-K slabs -> residual stream
+// x[i] += sum_z parts[z][i] (fp32 adds in slab order, one rounding to the stream's type): the consumer of a
+// split-K GEMM that writes fp32 slabs (launch_gemm_tn_splitk; the bias sits in slab 0).  Small batches only
+// (api.hip): a K = 8192 GEMM with a handful of output tiles would otherwise run 256 K slices per tile on a few CUs.
+template <typename XT>
+__global__ __launch_bounds__(256) void fold_residual_kernel(XT* __restrict__ x, const float* __restrict__ parts,
+                                                            int nparts, size_t part_elems, size_t n8) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float acc[8];
+    if constexpr (sizeof(XT) == 2) {
+      const half8 xv = *(const half8*)(x + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = (float)xv[e];
+    } else {
+      const f32x4 a = *(const f32x4*)(x + i * 8), b = *(const f32x4*)(x + i * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = a[e];
+        acc[4 + e] = b[e];
+      }
+    }
+    float sum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = 0.f;
+    for (int z = 0; z < nparts; ++z) {
+      const float* pz = parts + (size_t)z * part_elems + i * 8;
+      const f32x4 a = *(const f32x4*)pz, b = *(const f32x4*)(pz + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sum[e] += a[e];
+        sum[4 + e] += b[e];
+      }
+    }
+    if constexpr (sizeof(XT) == 2) {
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)(acc[e] + sum[e]);
+      *(half8*)(x + i * 8) = o;
+    } else {
+      *(f32x4*)(x + i * 8) = f32x4{acc[0] + sum[0], acc[1] + sum[1], acc[2] + sum[2], acc[3] + sum[3]};
+      *(f32x4*)(x + i * 8 + 4) = f32x4{acc[4] + sum[4], acc[5] + sum[5], acc[6] + sum[6], acc[7] + sum[7]};
+    }
+  }
+}
+
+hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int nparts, size_t part_elems, size_t n,
+                                hipStream_t stream) {
+  if (n % 8 || nparts < 1) return hipErrorInvalidValue;
+  const size_t n8 = n / 8;
+  const int blocks = (int)std::min<size_t>((n8 + 255) / 256, 256 * 16);
+  if (x_f16)
+    hipLaunchKernelGGL(fold_residual_kernel<f16>, dim3(blocks), dim3(256), 0, stream, (f16*)x, parts, nparts, part_elems, n8);
+  else
+    hipLaunchKernelGGL(fold_residual_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)x, parts, nparts, part_elems, n8);
   return hipGetLastError();
 }
 
