@@ -155,6 +155,16 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
   TopK<K> best[8];  // one running list per accumulator row block
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) best[mi].init();
+  // Row thresholds shared by the 4 column waves (above the ring): thr[row][wc] = the K-th best score wave wc holds for
+  // that row, a lower bound of the row's K-th best.  Published and read WITHOUT a barrier: the values only grow, so a
+  // stale one is still a valid bound.  A lane's own K-th best is a much weaker test -- with it some lane of nearly
+  // every 16-row block passes and the whole wave walks the insertion path every tile (top-4: 610 ms against 480 for
+  // top-1 at 262 144 x 1 M, r02 experiment 24).
+  float* thr = (float*)(smem + G2_LDS_BYTES);
+  if (kg == 0) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = -INFINITY;
+  }
 
   if (S > 0) {
     // DMA stream state: slice s = (tile s / nt, k = s % nt)
@@ -241,6 +251,19 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
       SMI_BARRIER();
       if (++k == nt) {  // y tile finished: fold the 128x64 scores of this wave into the top-k
         k = 0;
+        float rowthr[8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          float my = best[mi].s[K - 1];
+          my = fmaxf(my, __shfl_xor(my, 16, 64));
+          my = fmaxf(my, __shfl_xor(my, 32, 64));
+          if (kg == 0) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = my;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const f32x4 t4 = *(const f32x4*)(thr + (wr * 128 + mi * 16 + l15) * 4);
+          rowthr[mi] = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
+        }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
           float vmax = -INFINITY;
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
-          if (vmax >= best[mi].s[K - 1]) {
+          if (vmax >= rowthr[mi]) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -533,7 +556,7 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
     static DeviceOnce attr256_done;
     if (!attr256_done.done()) {
       e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + 4096);
       if (e != hipSuccess) return e;
       attr256_done.set();
     }
@@ -541,7 +564,7 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
     nchunks = xsim_chunks(nty);
     const int tpc = (nty + nchunks - 1) / nchunks;
     int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
-    hipLaunchKernelGGL(xsim_tile256_kernel<K>, dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES,
+    hipLaunchKernelGGL(xsim_tile256_kernel<K>, dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
                        stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
   } else {
     const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
