@@ -23,6 +23,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// Non-temporal (streaming) store for kernel OUTPUTS written as whole 128-B lines (16 B per lane, contiguous across the
+// wave): the data is consumed by the next kernel, usually on other XCDs, so keeping it in this XCD's L2 only evicts the
+// operand panels the workgroups are sharing.  Measured on the tile-major GEMM epilogues (r02 experiment 26): C2 step
+// 109.6 -> 108.6 ms (the attention kernel reads the QKV output 9 % faster, the FFN pair ~1 %), decoder and speech
+// -0.5..1 %.  NOT for partial-line stores: the 8-B pieces of the attention output went 4.4 -> 10.5 ms with it.
+template <typename T>
+__device__ __forceinline__ void store_nt(T* p, const T& v) {
+  __builtin_nontemporal_store(v, p);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

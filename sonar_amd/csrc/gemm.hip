@@ -357,7 +357,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           half8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (f16)((float)oldv[mi][j][i] + c8[i]);
-          *(half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = o;
+          store_nt((half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), o);
         }
       }
     } else
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
           typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
           const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-          *(u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = chunk;
+          store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
         }
       }
     } else {
