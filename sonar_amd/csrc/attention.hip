@@ -205,7 +205,33 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const f16* __restrict
 
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = 1.0f / ltot;
-  if (qi < len) {
+  if constexpr (TM) {
+    // Tile-major context: a lane holds 8-B pieces of ONE row, so a direct store scatters 16-B pieces over 16 lines per
+    // instruction.  The wave parks its 32 rows x 128 B in LDS (the K / V buffers, free after the barrier) and writes
+    // them back as 16 rows x 64 B per instruction = one linear 1 KiB run of a tile-major block, 16 B per lane.
+    __syncthreads();  // every wave is done with the K / V tiles
+    char* st = lds + wave * 4096;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
+        *(half4*)(st + l31 * 128 + (((db * 4 + q) ^ (l31 & 7)) << 4) + hi * 8) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-local hand-over: the readers below are lanes of this wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hb = i >> 1, row = (i & 1) * 16 + (lane >> 2), slot = lane & 3;
+      const int qr = q0 + wave * 32 + row;
+      const int rr = (start + qr) & 255;
+      const int c4 = slot ^ tm_swz(rr);
+      const f32x4 v = *(const f32x4*)(st + row * 128 + (((hb * 4 + c4) ^ (row & 7)) << 4));
+      // whole 64-B row segments, read next by the attention-output GEMM on other XCDs: non-temporal (common.hpp)
+      if (qr < len) store_nt((f32x4*)(ctx + tm_offset(start + qr, h * 64 + hb * 32 + c4 * 8, d)), v);
+    }
+  } else if (qi < len) {
     f16* op = ctx + (size_t)(start + qi) * d + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -214,10 +240,7 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const f16* __restrict
         half4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
-        if constexpr (TM)
-          *(half4*)(ctx + tm_offset(start + qi, h * 64 + db * 32 + 8 * q + 4 * hi, d)) = v;
-        else
-          *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
+        *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
       }
   }
 }
