@@ -46,7 +46,9 @@ __device__ __forceinline__ half4 at_tr_read(unsigned lds_addr) {
 // fragments), V swz = ((r>>1)&1)<<2, read with ds_read_b64_tr_b16 -- a 16-lane group fetches a
 // [4 keys][16 dims] block and every lane receives the 4 keys of its dim, i.e. the V^T fragment without
 // a transposed copy (keys r, r+2 of a group sit in different halves of the 128-B row: all 64 banks).
-template <bool TM, bool QTM>
+// NTL: the K / V tiles are loaded non-temporally (launcher: every sentence fits ONE 128-query block, so each qkv line
+// is read by exactly one workgroup, once)
+template <bool TM, bool QTM, bool NTL = false>
 __global__ __launch_bounds__(256, 4) void attention_kernel(const f16* __restrict__ qkv,
                                                         const int32_t* __restrict__ cu,
                                                         f16* __restrict__ ctx, int d, float sl2e, int order) {
@@ -91,8 +93,13 @@ __global__ __launch_bounds__(256, 4) void attention_kernel(const f16* __restrict
       const int c = tid + 256 * x;
       const int key = c >> 3, slot = c & 7;
       const int row = min(kv0 + key, len - 1);
-      glds16(at(row, d + h * 64 + (slot ^ ((key >> 1) & 7)) * 8), kt + x * 4096 + wave * 1024);
-      glds16(at(row, 2 * d + h * 64 + (slot ^ (((key >> 1) & 1) << 2)) * 8), kt + TILE + x * 4096 + wave * 1024);
+      if constexpr (NTL) {
+        glds16_nt(at(row, d + h * 64 + (slot ^ ((key >> 1) & 7)) * 8), kt + x * 4096 + wave * 1024);
+        glds16_nt(at(row, 2 * d + h * 64 + (slot ^ (((key >> 1) & 1) << 2)) * 8), kt + TILE + x * 4096 + wave * 1024);
+      } else {
+        glds16(at(row, d + h * 64 + (slot ^ ((key >> 1) & 7)) * 8), kt + x * 4096 + wave * 1024);
+        glds16(at(row, 2 * d + h * 64 + (slot ^ (((key >> 1) & 1) << 2)) * 8), kt + TILE + x * 4096 + wave * 1024);
+      }
     }
   };
   // V^T fragments: lane p of a 16-lane group feeds row (p>>2) of its [4 keys][16 dims] block and gets
@@ -259,7 +266,12 @@ hipError_t launch_attention(const f16* qkv, const int32_t* cu, f16* ctx, int N, 
     case 0: hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
     case 1: hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
     case 2: hipLaunchKernelGGL((attention_kernel<false, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
-    default: hipLaunchKernelGGL((attention_kernel<true, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;
+    default:
+      if (max_len <= AT_QB)
+        hipLaunchKernelGGL((attention_kernel<true, true, true>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order);
+      else
+        hipLaunchKernelGGL((attention_kernel<true, true, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order);
+      break;
   }
   return hipGetLastError();
 }

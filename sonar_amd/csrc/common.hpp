@@ -23,6 +23,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// glds16 with the non-temporal cache policy (aux = 2, `nt`): for lines that exactly ONE workgroup reads, once.
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 2);
+}
+
 // Non-temporal (streaming) store for kernel OUTPUTS written as whole 128-B lines (16 B per lane, contiguous across the
 // wave): the data is consumed by the next kernel, usually on other XCDs, so keeping it in this XCD's L2 only evicts the
 // operand panels the workgroups are sharing.  Measured on the tile-major GEMM epilogues (r02 experiment 26): C2 step
