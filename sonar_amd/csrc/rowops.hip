@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
       for (int j = 0; j < 2; ++j) {
         const int row = r0 + 4 * wv + 2 * j + rsel;  // < padded rows: x is allocated in whole 256-row panels
 #pragma unroll
-        for (int k = 0; k < NV; ++k) raw[j][k] = *(const half8*)(x + tm_offset(row, pair_col(lane, k), D));
+        for (int k = 0; k < NV; ++k)  // every line of x is read by this workgroup only, once: non-temporal
+          raw[j][k] = __builtin_nontemporal_load((const half8*)(x + tm_offset(row, pair_col(lane, k), D)));
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
