@@ -122,8 +122,9 @@ int smi_text_encoder_forward(smi_text_encoder* enc, const int64_t* ids, const in
 /* Synchronises `stream` and reports what the device found while running the forward calls enqueued on
  * it: SMI_ERR_INVALID_ARG if a batch held token ids outside [0, vocab_size) -- the reference's
  * embedding lookup raises an IndexError there (tokenizer / model vocabulary mismatch); the engine never
- * reads outside the table, flags the batch instead, and the flag is also returned by the next
- * smi_text_encoder_forward on this handle.  predict() calls this before it returns embeddings. */
+ * reads outside the table and flags the batch instead.  The flag is reported (and cleared) ONLY here, after
+ * the synchronisation -- smi_text_encoder_forward never refuses a later, valid batch because of it.
+ * predict() calls this before it returns embeddings. */
 int smi_text_encoder_status(smi_text_encoder* enc, void* stream);
 
 /* Bytes of device memory currently held by the handle (weights + workspace). */

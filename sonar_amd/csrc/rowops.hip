@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
             sq += v[k][i] * v[k][i];
           }
         const float var = pair_sum(sq) * inv_d;
-        const float rstd = r0 + lr < rows ? 1.0f / sqrtf(var + eps) : 0.f;
-        const float keep = r0 + lr < rows ? 1.f : 0.f;  // rows past the end of x: zeros
+        const bool live = r0 + lr < rows;  // rows past the end of x: exact zeros, whatever the padding of x holds
+        const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
           const int c = pair_col(lane, k);
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
           half8 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            o[i] = (f16)(v[k][i] * rstd * w0[i] + keep * b0[i]);
-            o[4 + i] = (f16)(v[k][4 + i] * rstd * w1[i] + keep * b1[i]);
+            o[i] = live ? (f16)(v[k][i] * rstd * w0[i] + b0[i]) : (f16)0.f;
+            o[4 + i] = live ? (f16)(v[k][4 + i] * rstd * w1[i] + b1[i]) : (f16)0.f;
           }
           *(half8*)(tile + lr * RS + c * 2) = o;
         }
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
             v[k][i] -= mean;
             sq += v[k][i] * v[k][i];
           }
-        const float rstd = r0 + lr < rows ? 1.0f / sqrtf(wave_sum(sq) * inv_d + eps) : 0.f;
-        const float keep = r0 + lr < rows ? 1.f : 0.f;  // rows past the end of x: zeros
+        const bool live = r0 + lr < rows;  // rows past the end of x: exact zeros
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
 #pragma unroll
         for (int k = 0; k < NH; ++k) {
           const float* wp = w + k * 512 + lane * 8;
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void layernorm_tm_kernel(const XT* __restrict_
           half8 o;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            o[i] = (f16)(v[k][i] * rstd * w0[i] + keep * b0[i]);
-            o[4 + i] = (f16)(v[k][4 + i] * rstd * w1[i] + keep * b1[i]);
+            o[i] = live ? (f16)(v[k][i] * rstd * w0[i] + b0[i]) : (f16)0.f;
+            o[4 + i] = live ? (f16)(v[k][4 + i] * rstd * w1[i] + b1[i]) : (f16)0.f;
           }
           *(half8*)(tile + lr * RS + (k * 512 + lane * 8) * 2) = o;
         }

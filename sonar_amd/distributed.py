@@ -120,6 +120,11 @@ class EngineXsimBackend:
         return xsim.margin_select(fs, fi, bs, margin, x_index_offset, err_count)
 
 
+def _empty_normalized(be, like: torch.Tensor) -> torch.Tensor:
+    """[0, d] matrix of the backend's normalised-row dtype (an empty shard in a collective)."""
+    return be.normalize(like.new_zeros((1, like.shape[1])))[:0]
+
+
 def _row_offsets(counts: Sequence[int]) -> List[int]:
     offs = [0]
     for c in counts:
@@ -132,14 +137,21 @@ def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, 
     local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k])."""
     be = backend or EngineXsimBackend()
     rank, ws = world()
-    xn = be.normalize(x_local)
+    nx_local, d = x_local.shape
+    xn = be.normalize(x_local) if nx_local else None
     if ws == 1:
-        return be.topk(xn, x_local.shape[0], be.normalize(y_local), y_local.shape[0], k)
+        return be.topk(xn, nx_local, be.normalize(y_local), y_local.shape[0], k)
     # normalise locally (fp16), gather the unpadded rows, then re-pad once
-    yn_local = be.normalize(y_local)[: y_local.shape[0]]
+    if y_local.shape[0]:
+        yn_local = be.normalize(y_local)[: y_local.shape[0]]
+    else:  # an empty shard still takes part in the all-gather
+        yn_local = _empty_normalized(be, y_local)
     yn_all, counts = all_gather_rows(yn_local)
     ny = sum(counts)
-    return be.topk(xn, x_local.shape[0], be.pad_rows(yn_all, ny), ny, k)
+    if not nx_local:
+        return (torch.zeros((0, k), dtype=torch.float32, device=x_local.device),
+                torch.zeros((0, k), dtype=torch.int32, device=x_local.device))
+    return be.topk(xn, nx_local, be.pad_rows(yn_all, ny), ny, k)
 
 
 def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str = "ratio", k: int = 4,
@@ -157,8 +169,10 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
     rank, ws = world()
     nx_local, ny_local = x_local.shape[0], y_local.shape[0]
     dev = x_local.device
-    xn = be.normalize(x_local)
-    yn_local = be.normalize(y_local)
+    d = x_local.shape[1]
+    # an empty shard is legal (fewer rows than ranks): it takes part in every collective with zero rows
+    xn = be.normalize(x_local) if nx_local else _empty_normalized(be, x_local)
+    yn_local = be.normalize(y_local) if ny_local else _empty_normalized(be, y_local)
     if ws > 1:
         yn_all, y_counts = all_gather_rows(yn_local[:ny_local])
         ny = sum(y_counts)
@@ -174,21 +188,33 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
         raise ValueError(f"xsim expects aligned x and y ({nx} vs {ny} rows in total)")
     x_off = _row_offsets(x_counts)[rank]
     errs = torch.zeros(1, dtype=torch.int32, device=dev)
+    pred = torch.zeros(0, dtype=torch.int32, device=dev)
     if margin == "cosine":
-        fs, fi = be.topk(xn, nx_local, yn, ny, 1)
-        pred, _ = be.margin_select(fs, fi, None, "cosine", x_off, errs)
+        if nx_local:
+            fs, fi = be.topk(xn, nx_local, yn, ny, 1)
+            pred, _ = be.margin_select(fs, fi, None, "cosine", x_off, errs)
     else:
-        kk = min(k, ny, min(x_counts))
-        fs, fi = be.topk(xn, nx_local, yn, ny, kk)
-        # y-side neighbourhoods: partial lists over the local x shard, for all y
-        bs_part, _ = be.topk(yn, ny, xn, nx_local, kk, x_off)
+        # the neighbourhood size is a property of the PROBLEM (LASER: k = 4), not of the sharding: a rank
+        # with fewer than kk local rows contributes the candidates it has, padded with -inf, so the merged
+        # lists -- and the margin means -- equal the single-process result for every shard layout
+        kk = min(k, nx)
+        kloc = min(kk, nx_local)
+        if kloc:
+            bs_part, _ = be.topk(yn, ny, xn, nx_local, kloc, x_off)
+            bs_part = bs_part[:ny]
+            if kloc < kk:
+                bs_part = torch.cat([bs_part, bs_part.new_full((ny, kk - kloc), float("-inf"))], dim=1)
+        else:
+            bs_part = torch.full((ny, kk), float("-inf"), dtype=torch.float32, device=dev)
         if ws > 1:
             parts = bs_part.new_empty((ws * bs_part.shape[0], bs_part.shape[1]))
             dist.all_gather_into_tensor(parts, bs_part.contiguous())
             bs, _ = be.merge_topk(parts.view(ws, bs_part.shape[0], bs_part.shape[1]), None)
         else:
             bs = bs_part
-        pred, _ = be.margin_select(fs, fi, bs, margin, x_off, errs)
+        if nx_local:
+            fs, fi = be.topk(xn, nx_local, yn, ny, kk)
+            pred, _ = be.margin_select(fs, fi, bs, margin, x_off, errs)
     total = errs.to(torch.int64)
     if ws > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)

@@ -180,7 +180,12 @@ class SpeechModelPipelineInterface(torch.nn.Module):
         """Device half up to the model input: fbank of the whole batch in one launch, collated as
         Collater(pad_value=pad_idx, pad_to_multiple=2) (speech.py:444)."""
         if hb.ready is not None:
-            torch.cuda.current_stream(hb.cat.device).wait_event(hb.ready)
+            cur = torch.cuda.current_stream(hb.cat.device)
+            cur.wait_event(hb.ready)
+            # `cat` was allocated on the producer's side stream: tell the caching allocator that THIS stream reads
+            # it, or the block returns to the side-stream pool when `hb` is dropped and a later batch's H2D copy
+            # (issued batches ahead of the GPU) may overwrite it before the filterbank kernel has run
+            hb.cat.record_stream(cur)
         fb, lens = fbank_batch_flat(hb.cat, hb.offsets)
         t = fb.shape[1]
         if pad_idx != 0:

@@ -22,7 +22,8 @@ from typing import Callable, Dict, Mapping, Optional, Union
 
 import torch
 
-FORMAT_VERSION = 1
+FORMAT_VERSION = 2  # v2: sdpa.u_bias / sdpa.v_bias stay fp32
+_FP32_2D_SUFFIXES = ("depthwise_conv.weight", "sdpa.u_bias", "sdpa.v_bias")
 
 
 def cache_dir() -> Optional[Path]:
@@ -50,7 +51,9 @@ def pack_state_dict(sd: Mapping[str, object]) -> Dict[str, torch.Tensor]:
         t = v.detach()
         if not t.is_floating_point():
             continue  # num_batches_tracked and friends
-        if t.dim() >= 2 and not k.endswith("depthwise_conv.weight"):
+        # fp32 like the engine keeps them: vectors, depthwise taps and the conformer's [heads, head_dim]
+        # relative-position biases (u_bias / v_bias -- 2-D, but added to q in fp32, never a GEMM operand)
+        if t.dim() >= 2 and not k.endswith(_FP32_2D_SUFFIXES):
             t = t.to(torch.float16)
         else:
             t = t.to(torch.float32)

@@ -375,7 +375,10 @@ class SonarTextTransformerEncoderModel:
     def forward(self, batch: SequenceBatch) -> SonarEncoderOutput:
         lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else None
         if getattr(batch, "ready", None) is not None:
-            torch.cuda.current_stream(self.device).wait_event(batch.ready)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(batch.ready)
+            if batch.seqs.is_cuda:  # allocated on the producer's stream: this stream reads it too (allocator reuse)
+                batch.seqs.record_stream(cur)
         emb, enc = self.engine.forward(batch.seqs, lens, self.dtype, self.return_encoded_seqs)
         return SonarEncoderOutput(encoded_seqs=enc, sentence_embeddings=emb, padding_mask=batch.padding_mask)
 

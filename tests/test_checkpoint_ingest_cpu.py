@@ -113,3 +113,10 @@ def test_packed_cache(tmp_path, monkeypatch):
     assert p["encoder.layers.0.conv.depthwise_conv.weight"].dtype == torch.float32
     assert p["encoder.layers.0.conv.pointwise_conv1.weight"].dtype == torch.float16
     assert len(p) == 2
+    # the conformer's relative-position biases are 2-D but the engine keeps them fp32 (never a GEMM operand):
+    # a file-loaded model must hold the same values as one built from the in-memory dict
+    ub = torch.randn(4, 64) * 1e-3 + 1.0   # values that fp16 would visibly round
+    q = PC.pack_state_dict({"encoder.layers.0.self_attn.sdpa.u_bias": ub, "encoder.layers.0.self_attn.sdpa.v_bias": ub + 1})
+    assert q["encoder.layers.0.self_attn.sdpa.u_bias"].dtype == torch.float32
+    assert torch.equal(q["encoder.layers.0.self_attn.sdpa.u_bias"], ub)
+    assert torch.equal(q["encoder.layers.0.self_attn.sdpa.v_bias"], ub + 1)

@@ -140,6 +140,18 @@ def _xsim_worker(rank, world, port, q):
             err, pred = sharded_xsim_error(x[xb:xe], y[yb:ye], margin=m, k=4, backend=be)
             assert abs(err - fx[m + "_err"] / n) < 1e-12, (m, err, fx[m + "_err"])
             assert torch.equal(pred.long(), fx[m + "_pred"][xb:xe]), m
+        # shards SMALLER than the neighbourhood (k = 4) and an EMPTY shard: the margin means must not depend on
+        # the shard layout (round-2 advisor finding: k used to shrink to the smallest shard)
+        if world == 4:
+            xcut = [0, 2, 2, 3, n]          # rank 0: 2 rows, rank 1: none, rank 2: 1 row, rank 3: the rest
+            ycut = [0, n - 5, n - 5, n - 1, n]
+            xb, xe, yb, ye = xcut[rank], xcut[rank + 1], ycut[rank], ycut[rank + 1]
+            s, idx = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be)
+            assert idx.shape == (xe - xb, 3) and torch.equal(idx.long(), ri[xb:xe])
+            for m in ("cosine", "ratio", "distance"):
+                err, pred = sharded_xsim_error(x[xb:xe], y[yb:ye], margin=m, k=4, backend=be)
+                assert abs(err - fx[m + "_err"] / n) < 1e-12, (m, err, fx[m + "_err"])
+                assert torch.equal(pred.long(), fx[m + "_pred"][xb:xe]), m
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
