@@ -76,15 +76,21 @@ def best_of(fn, reps=3):
     return min(ts), ts
 
 
-def cpu_baseline(params, n_sent, c1_ids, c1_lens):
+def cpu_baseline(params, c2_ids, c1_ids, c1_lens):
     """Reference-equivalent op sequence (the oracle, kind 'port') on the host cores, on the SAME weights
-    the GPU engine holds: a slice of the C2 batch (n_sent x 128) and the whole C1 batch."""
+    the GPU engine holds: the first rows of the ACTUAL C2 batch the GPU step encodes (c2_ids, [n_sent, 128])
+    and the whole C1 batch.  Returns (record, C2-slice embeddings, C1 embeddings) for the parity fields."""
     from oracle import text_encoder as O
 
     cores = cpu_threads()
     cfg = O.OracleTextEncoderConfig()
-    ids, _ = O.synthetic_batch(n_sent, SEQ, SEQ, cfg.vocab_size, seed=0)
-    best, ts = best_of(lambda: O.text_encoder_forward(params, cfg, ids, None))
+    n_sent = c2_ids.shape[0]
+    c2_out = {}
+
+    def run_c2():
+        c2_out["emb"] = O.text_encoder_forward(params, cfg, c2_ids, None)[1]
+
+    best, ts = best_of(run_c2)
     c1_out = {}
 
     def run_c1():
@@ -92,15 +98,16 @@ def cpu_baseline(params, n_sent, c1_ids, c1_lens):
 
     c1_best, c1_ts = best_of(run_c1)
     return ({"value": n_sent / best, "unit": "sentences/s", "cores": cores, "kind": "port",
-             "sample": f"{n_sent} sentences x {SEQ} tokens (a slice of the C2 batch), full 24-layer fp32 model, torch CPU "
-                       f"oracle, warm-up 1 + best of 3 ({', '.join(f'{t:.1f}' for t in ts)} s)",
+             "sample": f"the first {n_sent} sentences x {SEQ} tokens of the C2 batch the GPU step encodes (same ids, same "
+                       f"weights), full 24-layer fp32 model, torch CPU oracle, warm-up 1 + best of 3 "
+                       f"({', '.join(f'{t:.1f}' for t in ts)} s)",
              "c1": {"value": c1_ids.shape[0] / c1_best, "unit": "sentences/s", "seconds": c1_best,
                     "sample": f"BASELINE configs[0]: {c1_ids.shape[0]} sentences, lengths randint(8,65) seed 0 "
                               f"({int(c1_lens.sum())} tokens), fp32, warm-up 1 + best of 3"}},
-            c1_out["emb"])
+            c2_out["emb"], c1_out["emb"])
 
 
-def xsim_cpu_baseline(nx=16384, ny=65536):
+def xsim_cpu_baseline(nx=8192, ny=32768):
     """Blocked fp32 normalise + matmul + top-1 on the host (the oracle's cosine_topk), extrapolated per pair."""
     import torch
 
@@ -237,6 +244,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run
+        # (rendezvous on 127.0.0.1, a free port); rank 0's JSON line is the only thing on stdout either way
+        import socket
+        import subprocess
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[launcher] WORLD_SIZE unset and --gpus {args.gpus}: re-launching as {' '.join(cmd)}")
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     batch_n, seq = (BATCH, SEQ) if not DRYRUN else (8, 16)
@@ -257,6 +280,14 @@ def main():
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", device_id=dev)
         padded_rows = lambda n: int(xs_mod._lib.load().smi_xsim_padded_rows(n))
+    # what the process group actually is (the first SCALE record must prove N ranks over RCCL)
+    collective = {"world_size": dist.get_world_size() if world > 1 else 1,
+                  "backend": (dist.get_backend() if world > 1 else None)}
+    if not DRYRUN:
+        try:
+            collective["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            collective["rccl_version"] = None
 
     def barrier():
         if world > 1:
@@ -320,6 +351,10 @@ def main():
     model.engine.set_profiling(False)
     prof = model.engine.read_profile()
 
+    c2_gpu = None
+    if not DRYRUN and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        c2_gpu = step()[: args.cpu_sentences].float().cpu()   # the rows the CPU oracle will encode (untimed extra call)
+        c2_ids_cpu = ids[: args.cpu_sentences].cpu()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * batch_n * args.steps / elapsed
     ffn1 = prof["gemm_ffn1"]
@@ -382,6 +417,14 @@ def main():
         extra["c1"] = {"workload": "BASELINE configs[0] on the GPU engine: 32 sentences, lengths randint(8,65) seed 0, fp16",
                        "tokens": int(c1_lens.sum()), "ms": c1_t / 20 * 1e3, "sentences_per_s": 32 * 20 / c1_t}
 
+        # the reference's DEFAULT call: predict(..., batch_size=5) (sonar/inference_pipelines/text.py:178)
+        b5_ids, b5_lens = O.synthetic_batch(5, 8, 64, V, seed=1)
+        b5_batch = SequenceBatch(b5_ids.to(dev), PaddingMask(b5_lens, b5_ids.shape[1]))
+        b5_t = timed(lambda: model(b5_batch).sentence_embeddings, 50, 5)
+        extra["batch5"] = {"workload": "one predict() bucket at the reference's default batch_size=5: 5 sentences, lengths "
+                                       "randint(8,65) seed 1, fp16 (text.py:178)",
+                           "tokens": int(b5_lens.sum()), "ms": b5_t / 50 * 1e3, "sentences_per_s": 5 * 50 / b5_t}
+
     # ------------------------------------------------------------ xsim leg (BASELINE configs[2])
     xs = None
     if not args.no_xsim:
@@ -391,8 +434,9 @@ def main():
         nloc = n_total // world
         gx = torch.Generator(device=dev).manual_seed(2 + rank)
         y_local = torch.randn(nloc, D, device=dev, generator=gx, dtype=torch.float32).half()
-        x_local = (y_local[torch.randint(0, nloc, (nloc,), device=dev, generator=gx)].float()
-                   + 0.3 * torch.randn(nloc, D, device=dev, generator=gx)).half()
+        # x_i = y_src(i) + noise: the nearest neighbour of every x row is known by construction
+        src_local = torch.randint(0, nloc, (nloc,), device=dev, generator=gx)
+        x_local = (y_local[src_local].float() + 0.3 * torch.randn(nloc, D, device=dev, generator=gx)).half()
         dense = nloc == padded_rows(nloc)   # equal shards of whole 256-row tiles gather into a dense layout
         yn_all = torch.empty((world * nloc, D), dtype=torch.float16, device=dev) if world > 1 and dense else None
 
@@ -414,6 +458,12 @@ def main():
 
         reps = 3
         xt = timed(mine, reps, 1) / reps
+        # correctness of the timed configuration itself: top-1 index == the constructed source row (global index)
+        _, top_i = mine()
+        hit = (top_i[:nloc, 0].long() == src_local + rank * nloc).sum().to(torch.float64)
+        if world > 1:
+            dist.all_reduce(hit)
+        top1_agree = float(hit.item()) / n_total
         # the HBM-bound half of the leg on its own: L2 normalisation of one side (read fp16, write fp16)
         nt_ = timed(lambda: xs_mod.normalize_rows(y_local), 3, 1) / 3
         pairs = float(n_total) * n_total
@@ -423,10 +473,11 @@ def main():
               "d": D, "k": 1, "tflops": pairs * 2 * D / xt / 1e12,
               "frac_of_mfma_peak": pairs * 2 * D / xt / 1e12 / (MFMA_PEAK_TFLOPS * world),
               "includes": "row normalisation of X and Y, Y all-gather (N>1), top-1 mining + chunk merge",
+              "top1_agreement_with_constructed_neighbours": top1_agree,
               "normalise": {"ms": nt_ * 1e3, "bytes": nloc * D * 4, "achieved_GBs": nloc * D * 4 / nt_ / 1e9,
                             "frac_of_hbm_peak": nloc * D * 4 / nt_ / 1e9 / 8000.0},
               "scaling": "strong (the 1M x 1M problem is fixed, X rows are split over the ranks)"}
-        del x_local, y_local, yn_all
+        del x_local, y_local, yn_all, src_local
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
             xs["cpu_baseline"] = xsim_cpu_baseline()
 
@@ -452,7 +503,11 @@ def main():
 
         if c1_gpu is None:
             c1_ids, c1_lens = O.synthetic_batch(32, 8, 64, V, seed=0)
-        cb, c1_cpu = cpu_baseline(sd_cpu, args.cpu_sentences, c1_ids, c1_lens)
+        cb, c2_cpu, c1_cpu = cpu_baseline(sd_cpu, c2_ids_cpu, c1_ids, c1_lens)
+        if c2_gpu is not None:
+            cos2 = torch.nn.functional.cosine_similarity(c2_gpu, c2_cpu, dim=-1)
+            cb["c2_max_1_minus_cos_vs_gpu"] = float((1 - cos2).max())
+            cb["c2_rows_compared"] = int(c2_gpu.shape[0])
         if c1_gpu is not None:
             cos = torch.nn.functional.cosine_similarity(c1_gpu, c1_cpu, dim=-1)
             extra["c1"]["max_1_minus_cos_vs_cpu_oracle"] = float((1 - cos).max())
@@ -469,6 +524,11 @@ def main():
                        "global_batch": world * batch_n, "seq_len": seq, "parallelism": f"dp{world}",
                        "weights": "random-init basic arch (24L, d=1024, F=8192, V=256206)"},
             "roofline": roofline, "cpu_baseline": cb,
+            "parity": {"tolerance_1_minus_cos": 1e-3,
+                       "c2_max_1_minus_cos_vs_cpu_oracle": cb.get("c2_max_1_minus_cos_vs_gpu") if cb else None,
+                       "c1_max_1_minus_cos_vs_cpu_oracle": extra.get("c1", {}).get("max_1_minus_cos_vs_cpu_oracle"),
+                       "xsim_top1_agreement": xs.get("top1_agreement_with_constructed_neighbours") if xs else None},
+            "collective": collective,
             "encoder_tflops": value * FLOPS_PER_SENTENCE / 1e12,
             "encoder_frac_of_mfma_peak": value * FLOPS_PER_SENTENCE / 1e12 / (MFMA_PEAK_TFLOPS * world),
             "kernels": kernels, "hbm_kernels": hbm_kernels, "xsim": xs, **extra,

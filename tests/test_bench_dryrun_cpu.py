@@ -21,11 +21,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
-def test_bench_control_flow_dry_run(world):
+@pytest.mark.parametrize("world,form", [(1, "plain"), (2, "torchrun"), (4, "torchrun"), (2, "plain"), (4, "plain")])
+def test_bench_control_flow_dry_run(world, form):
+    """form "torchrun": the driver's documented N > 1 command; form "plain": `python bench.py --gpus N` with no
+    WORLD_SIZE in the environment -- bench.py then launches its own ranks (round-2 verdict: the first SCALE
+    record must not die on the launch contract)."""
     env = dict(os.environ, SONAR_BENCH_DRYRUN="1", OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
     args = ["--gpus", str(world), "--steps", "3", "--warmup", "1"]
-    if world == 1:
+    if form == "plain":
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -40,12 +45,20 @@ def test_bench_control_flow_dry_run(world):
     assert out["config"]["global_batch"] == 8 * world and out["config"]["parallelism"] == f"dp{world}"
     assert out["value"] > 0 and out["ms_per_step"] > 0
     assert abs(out["value"] - 8 * world * 3 / (out["ms_per_step"] * 3 / 1e3)) / out["value"] < 1e-6
+    assert out["collective"]["world_size"] == world
+    assert out["collective"]["backend"] == ("gloo" if world > 1 else None)
     xs = out["xsim"]
     assert xs["nx_total"] == xs["ny_total"] == 512 * world and xs["nx_per_gpu"] == 512 and xs["pairs_per_s"] > 0
+    # the timed xsim configuration checks itself: the constructed neighbour of every row, global indices over ranks
+    assert xs["top1_agreement_with_constructed_neighbours"] >= 0.99
+    assert out["parity"]["xsim_top1_agreement"] == xs["top1_agreement_with_constructed_neighbours"]
     for key in ("metric", "unit", "roofline", "cpu_baseline", "vs_baseline", "dtype"):
         assert key in out
-    # wrong launch is refused, not silently run on one rank
-    if world == 2:
-        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
-                             capture_output=True, text=True, timeout=120)
-        assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_bench_refuses_a_rank_count_that_contradicts_gpus():
+    """Launched under a process group of the wrong size, bench.py stops instead of measuring something else."""
+    env = dict(os.environ, SONAR_BENCH_DRYRUN="1", OMP_NUM_THREADS="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)

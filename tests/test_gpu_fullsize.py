@@ -306,6 +306,105 @@ def test_basic_decoder_tokens_vs_oracle_full_size(basic_decoder, beam):
     assert excused <= 1
 
 
+def test_basic_decoder_long_prefix_vs_oracle_full_size(basic_decoder):
+    """Round 3: the full-size decoder beyond toy lengths.  (1) teacher-forced logits of 2 sentences x 70 positions
+    (single-query attention with NG = 1..8 and two online-softmax passes; the C5 bench leg times 65 such steps);
+    (2) greedy decoding with 70 forced steps, every decision checked against the oracle's arg-max on the engine's
+    own prefix; (3) beam 5 with 70 forced steps: the best hypothesis re-scored by the oracle (its cumulative score
+    went through the ancestry table and the KV cache for 70 steps)."""
+    OD, ocfg, params, eng = basic_decoder
+    g = torch.Generator().manual_seed(61)
+    n, t = 2, 70
+    emb = F.normalize(torch.randn(n, 1024, generator=g), dim=-1) * 0.2
+    prev = torch.randint(4, 256000, (n, t), generator=g)
+    prev[:, 0] = 3
+    prev[:, 1] = 256047
+    ref = OD.decoder_logits(params, ocfg, emb, prev)
+    got = eng.logits(emb.cuda(), prev.cuda()).cpu()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs().amax(dim=(0, 2))
+    print(f"basic decoder logits over {t} positions: max |diff| / scale {err.max().item() / scale:.2e} "
+          f"(worst position {int(err.argmax())}), last position {err[-1].item() / scale:.2e}")
+    assert err.max().item() <= 5e-3 * scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+    del got, ref
+
+    prompt = [3, 256047]
+    forced = 70
+    kw = dict(min_gen_len=forced, max_gen_len=(0, forced + 6))
+    max_len, min_len = len(prompt) + forced + 6, len(prompt) + forced
+    lg = OD.decoder_logits(params, ocfg, emb, torch.tensor([prompt] * n))
+    eps = 1e-3 * (lg.max() - lg.min()).item()
+    for beam in (1, 5):
+        toks, lens, scores = eng.generate(emb.cuda(), prompt, beam_size=beam, **kw)
+        toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
+        ties = 0
+        for i in range(n):
+            L = int(lens[i, 0])
+            seq = toks[i, 0, :L].tolist()
+            assert forced + 1 <= L <= forced + 6 and seq[-1] == 3 and 3 not in seq[:-1] and 0 not in seq
+            full = torch.tensor([prompt + seq])
+            lp = torch.log_softmax(OD.decoder_logits(params, ocfg, emb[i:i + 1], full[:, :-1]), dim=-1, dtype=torch.float32)[0]
+            total = lp[torch.arange(full.shape[1] - 1), full[0, 1:]].sum().item()
+            assert abs(total / (len(prompt) + L - 1) - scores[i, 0].item()) <= 5e-3, (beam, i, total, scores[i, 0].item())
+            if beam != 1:
+                continue
+            for tt in range(len(prompt) - 1, full.shape[1] - 1):
+                step_nr, chosen = tt + 1, int(full[0, tt + 1])
+                if step_nr == max_len - 1:
+                    continue
+                row = lp[tt].clone()
+                row[0] = -torch.inf
+                if step_nr < min_len:
+                    row[3] = -torch.inf
+                best = int(row.argmax())
+                if chosen != best:
+                    assert (row[best] - row[chosen]).item() < eps, (i, step_nr, chosen, best)
+                    ties += 1
+        print(f"basic decoder beam {beam}, {forced} forced steps: scores equal the oracle's re-scoring"
+              + (f"; greedy decisions within eps {eps:.2e} of the arg-max: {ties}" if beam == 1 else ""))
+        assert ties <= 2
+
+
+def test_speech_encoder_english_10s_clip_vs_oracle_full_size():
+    """BASELINE configs[3] at its own shape: ONE 10 s clip (998 filterbank frames -> 499 conformer frames, relative
+    positions out to +-498, eight 64-key tiles in the relative-position attention) through the full
+    sonar_speech_encoder_eng, waveform -> embedding, against the fp32 oracle; fp16 residual stream as benchmarked."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveforms_to_fbank_batch
+    from tools.synth import speech_encoder_state_dict
+
+    dev = torch.device("cuda:0")
+    sd = speech_encoder_state_dict(dev)
+    params = _cpu_fp32(sd)
+    so = OS.OracleSpeechEncoderConfig(model_dim=1024, num_layers=24, num_heads=16, ffn_inner_dim=4096, conv_kernel=31,
+                                      pooler_layers=3, pooler_heads=16, pooler_ffn_dim=4096, pooler_vocab=1024)
+    g = torch.Generator().manual_seed(23)
+    ns = 160000
+    wav = (torch.rand(ns, generator=g) * 2 - 1) * 0.5 + 0.2 * torch.sin(torch.arange(ns) * 0.03)
+    f = OS.kaldi_fbank(wav)
+    assert f.shape[0] == 998
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    _, ref = OS.speech_encoder_forward(params, so, f.unsqueeze(0), torch.tensor([998]))
+    eng = SpeechEncoderEngine(get_speech_encoder_config("english"), sd, device=dev, fp16_residual=True)
+    gfb, glens = waveforms_to_fbank_batch([wav.to(dev)])
+    assert glens == [998]
+    out = eng.forward(gfb, glens, torch.float32).cpu()
+    err = _cos_err(out, ref)
+    rel = (out - ref).abs().max().item() / ref.abs().max().item()
+    print(f"english speech encoder, one 10 s clip (499 frames): max (1 - cos) {err:.2e}, max |diff| / max |ref| {rel:.2e}")
+    assert err <= 1e-3 and rel <= 5e-2
+    # the same clip inside a batch of shorter ones gives the same vector
+    wavs = [wav.to(dev), wav[:52000].to(dev), wav[:160000 - 321].to(dev)]
+    gfb, glens = waveforms_to_fbank_batch(wavs)
+    outb = eng.forward(gfb, glens, torch.float32).cpu()
+    assert _cos_err(outb[:1], out) <= 1e-5
+
+
 def test_speech_encoder_english_vs_oracle_full_size():
     """sonar_speech_encoder_eng (24 conformer blocks, d 1024, 3-layer pooler) on 3 clips of 1.0 / 1.6 / 2.0 s,
     waveform -> embedding, against the fp32 oracle (filterbank included), both residual precisions."""

@@ -75,6 +75,33 @@ def test_speech_encoder_vs_oracle(ragged, fp16_residual):
     assert _cos_err(one, emb[i:i + 1]) <= 1e-5
 
 
+def test_speech_encoder_10s_frames_ragged_vs_oracle():
+    """The shape BASELINE configs[3] is timed on (998 filterbank frames = 499 conformer frames per clip: eight 64-key
+    tiles and relative positions out to +-498 in `relpos_attention_kernel`), as a RAGGED batch at small width."""
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import SpeechEncoderEngine
+
+    ocfg, cfg = _cfgs()
+    params = OS.make_synthetic_params(ocfg, seed=123, std=0.06)
+    g = torch.Generator().manual_seed(17)
+    lens = torch.tensor([998, 640, 130, 996, 386])
+    fb = torch.randn(len(lens), 998, 80, generator=g)
+    for i, L in enumerate(lens.tolist()):
+        fb[i, L:] = 0
+    _, ref = OS.speech_encoder_forward(params, ocfg, fb, lens)
+    for fp16_residual in (True, False):
+        eng = SpeechEncoderEngine(cfg, params, device="cuda:0", fp16_residual=fp16_residual)
+        emb = eng.forward(fb.cuda(), lens, torch.float32)
+        assert torch.isfinite(emb).all()
+        err = _cos_err(emb, ref)
+        print(f"5 clips of 499 / 320 / 65 / 498 / 193 frames, fp16_residual={fp16_residual}: max (1 - cos) {err:.2e}")
+        assert err <= 1e-3, err
+        assert (emb.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
+        one = eng.forward(fb[:1].cuda(), None, torch.float32)     # the full-length clip alone
+        assert _cos_err(one, emb[:1]) <= 1e-5
+        del eng
+
+
 def test_speech_pipeline_end_to_end(tmp_path):
     from oracle import speech_encoder as OS
     from sonar_amd.inference_pipelines import SpeechToEmbeddingModelPipeline
