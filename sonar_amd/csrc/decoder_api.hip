@@ -106,7 +106,7 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
                                  L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
                            rows_pad, 3 * d, d, 3 * d, stream));
-    HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
+    HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, group, stream));
     // the two N = d projections have too few tiles to fill 256 CUs at decode batch sizes:
     // split K into fp32 slabs that the next fused sum+LayerNorm folds into the residual stream
     HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));

@@ -109,8 +109,10 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
                                 f16* h, int rows, int d, hipStream_t stream, int h_tm = 0);
+// single-query attention of one decode step; `group` = rows per sentence (beam size; 1 = independent rows): the
+// beams of a sentence are reduced by one wave that shares the K / V rows their ancestries have in common
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
-                                int rows_pad, int d, int heads, int pos, hipStream_t stream);
+                                int rows_pad, int d, int heads, int pos, int group, hipStream_t stream);
 constexpr int kVocabScanK2Max = 16;
 // Per row: softmax normaliser (pmax, psum) from the GEMM's tile statistics and the top-k2 candidates
 // among the k2 best tiles + tile 0 (pval / pidx [rows][kVocabScanK2Max]), without re-reading the whole
