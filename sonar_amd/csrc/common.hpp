@@ -38,6 +38,57 @@ __device__ __forceinline__ void store_nt(T* p, const T& v) {
   __builtin_nontemporal_store(v, p);
 }
 
+// Cross-lane reductions: the whole wave (wave_sum / wave_max, result in every lane), and for the single-query
+// attention kernels (lane = 8 * pg + c) over the 8 lanes c of a position group and over the 8 position groups pg
+// with the lane's c kept.  DPP row operations and the gfx950 lane-swap
+// instructions run at VALU rate; __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip per step
+// (-DSMI_SHFL_REDUCE restores the shuffles for A/B builds).
+#ifndef SMI_SHFL_REDUCE
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {              // all 64 lanes, result in every lane
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);                                           // 8 lanes joined
+  v += dpp_f<0x140>(v);                                           // row_mirror: the other half of the 16-lane row
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float sum_over_8(float v) {            // lanes c = 0..7 of a group: xor 1, 2, then mirror
+  v += dpp_f<0xB1>(v);                                            // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                                            // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);                                           // row_half_mirror: lane i <-> 7 - i
+  return v;
+}
+__device__ __forceinline__ float sum_over_groups_of_8(float v) {  // same c, all 8 position groups
+  v += dpp_f<0x128>(v);                                           // row_ror:8 (lane i <- lane i + 8 within 16)
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);             // rows 16 apart joined on both sides
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float max_over_groups_of_8(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v));
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -48,6 +99,25 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+__device__ __forceinline__ float sum_over_8(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ float sum_over_groups_of_8(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float max_over_groups_of_8(float v) {
+  v = fmaxf(v, __shfl_xor(v, 8, 64));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+#endif
 
 // XCD-aware block id remap (bijective for any grid size): hardware deals
 // block b to XCD b%8; give every XCD one contiguous range of logical ids so

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
   if (r >= rows) return;
   float* xr = x + (size_t)r * D;
   // The kernel is one dependent chain per wave (loads -> two wave reductions -> store) at ~1 wave per
-  // SIMD, so every load is issued before the first add: x, the constant, then the slabs four at a time.
+  // SIMD, so every load is issued before the first add: x, the constant, then the slabs eight at a time.
   // The summation order (x, slabs ascending, constant) is fixed.
   f32x4 v[NV], cv[NV];
 #pragma unroll
@@ -85,16 +85,17 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
     cv[k] = c ? *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float* pr = parts + (size_t)r * D + lane * 4;
-  for (int z0 = 0; z0 < nparts; z0 += 4) {
-    f32x4 p[4][NV];
+  constexpr int ZB = NV <= 4 ? 8 : 4;  // slabs per round trip (register budget: ZB * NV f32x4)
+  for (int z0 = 0; z0 < nparts; z0 += ZB) {
+    f32x4 p[ZB][NV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < ZB; ++j)
 #pragma unroll
       for (int k = 0; k < NV; ++k)
         p[j][k] = z0 + j < nparts ? *(const f32x4*)(pr + (size_t)(z0 + j) * part_stride + k * 256)
                                   : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < ZB; ++j)
 #pragma unroll
       for (int k = 0; k < NV; ++k) v[k] += p[j][k];
   }
@@ -211,17 +212,13 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
       float acc = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += q[e] * (float)kk[e];
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
+      acc = sum_over_8(acc);
       s[it] = valid ? acc : -INFINITY;
     }
     float mx = s[0];
 #pragma unroll
     for (int it = 1; it < NG; ++it) mx = fmaxf(mx, s[it]);
-    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_over_groups_of_8(mx);
     const float m_new = fmaxf(m, mx);
     const float alpha = __builtin_amdgcn_exp2f(m - m_new);
     float ps = 0.f;
@@ -230,9 +227,7 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
       s[it] = __builtin_amdgcn_exp2f(s[it] - m_new);  // 0 for masked positions
       ps += s[it];
     }
-    ps += __shfl_xor(ps, 8, 64);
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
+    ps = sum_over_groups_of_8(ps);
     l = l * alpha + ps;
     m = m_new;
 #pragma unroll
@@ -247,244 +242,15 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const f16* __restric
   half8 out;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    float v = o[e];
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    const float v = sum_over_groups_of_8(o[e]);
     out[e] = (f16)(v / l);
   }
   if (pg == 0) *(half8*)(ctx + (size_t)r * d + h * 64 + c * 8) = out;
 }
 
-// ------------------------------------- single-query attention, the beams of a sentence in ONE wave
-// (round 3).  The rows of a sentence's beams share most of their ancestry: at position j the table
-// anc[row][j] names the same cache row for every beam until the hypotheses diverge, so with one wave per
-// (row, head) the five beams of a sentence fetch the same K / V rows five times -- and, more to the point for
-// this latency-bound kernel, the chip runs five rounds of short dependent chains (ancestry -> K/V rows ->
-// reduce) instead of one.  Here one wave owns (sentence sub-group of NB rows, head): per chunk of 8 NG
-// positions it loads beam 0's K / V rows once and tests, wave-uniformly per beam, whether every lane's
-// ancestor equals beam 0's; only a beam that really diverges inside the chunk pays a second fetch (lanes whose
-// ancestor agrees re-request beam 0's line: an L1 hit).  The current position -- the one place where the rows
-// always differ -- is folded in up front from the step's own q|k|v slab, together with q.  The ancestry words of
-// chunk i+1 are requested before chunk i is reduced.  Same arithmetic per beam as dec_attention_kernel (fp32
-// scores / online softmax in the log2 domain / fp32 context), one more term order (self first).
-template <int NG, int NB>
-__global__ __launch_bounds__(256) void dec_attention_beams_kernel(const f16* __restrict__ kv,
-                                                                  const int32_t* __restrict__ anc,
-                                                                  int anc_stride, f16* __restrict__ ctx,
-                                                                  int ngroups, int rows_pad, int d, int heads,
-                                                                  int pos, float sl2e) {
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= ngroups * heads) return;
-  const int sg = wid / heads, h = wid % heads;
-  const int r0 = sg * NB;
-  const int lane = threadIdx.x & 63, pg = lane >> 3, c = lane & 7;
-  const size_t ld = (size_t)3 * d;
-  const size_t slab = (size_t)rows_pad * ld;
-
-  // this step's own slab: q, and the K / V of position `pos` (self), per beam
-  const f16* cur = kv + (size_t)pos * slab + (size_t)r0 * ld + h * 64 + c * 8;
-  half8 qh[NB], ks[NB], vs[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    qh[b] = *(const half8*)(cur + (size_t)b * ld);
-    ks[b] = *(const half8*)(cur + (size_t)b * ld + d);
-    vs[b] = *(const half8*)(cur + (size_t)b * ld + 2 * d);
-  }
-  const int32_t* ar = anc + (size_t)r0 * anc_stride;
-  const int nchunk = (pos + 8 * NG - 1) / (8 * NG);  // chunks over the ancestry positions 0..pos-1
-  int src[NB][NG];
-  auto load_src = [&](int j0) {
-#pragma unroll
-    for (int it = 0; it < NG; ++it) {
-      const int j = j0 + it * 8 + pg;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) src[b][it] = j < pos ? ar[(size_t)b * anc_stride + j] : 0;
-    }
-  };
-  if (nchunk > 0) load_src(0);
-
-  float q[NB][8], m[NB], l[NB], o[NB][8];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    float acc = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      q[b][e] = (float)qh[b][e] * sl2e;
-      acc += q[b][e] * (float)ks[b][e];
-    }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
-    m[b] = acc;  // the self score: p = exp2(0) = 1
-    l[b] = 1.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[b][e] = pg == 0 ? (float)vs[b][e] : 0.f;  // joined over pg at the end
-  }
-
-  const f16* kbase = kv + d + h * 64 + c * 8;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int j0 = ch * 8 * NG;
-    // beam 0's rows for the whole chunk (masked positions: one shared cached line, straight-line code)
-    const f16* row0[NG];
-    int s0[NG];
-    bool valid[NG];
-#pragma unroll
-    for (int it = 0; it < NG; ++it) {
-      const int j = j0 + it * 8 + pg;
-      valid[it] = j < pos;
-      s0[it] = src[0][it];
-      row0[it] = kbase + (size_t)(valid[it] ? j : 0) * slab + (size_t)s0[it] * ld;
-    }
-    half8 k0[NG], v0[NG];
-#pragma unroll
-    for (int it = 0; it < NG; ++it) k0[it] = *(const half8*)row0[it];
-#pragma unroll
-    for (int it = 0; it < NG; ++it) v0[it] = *(const half8*)(row0[it] + d);
-    // which beams leave beam 0's ancestry inside this chunk (wave-uniform answer per beam)
-    int sb[NB][NG];
-    bool differs[NB];
-    differs[0] = false;
-#pragma unroll
-    for (int b = 1; b < NB; ++b) {
-      bool dl = false;
-#pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        sb[b][it] = src[b][it];
-        dl |= valid[it] && sb[b][it] != s0[it];
-      }
-      differs[b] = __any(dl);
-    }
-    if (ch + 1 < nchunk) load_src(j0 + 8 * NG);  // next chunk's ancestry words, behind this chunk's reduction
-
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      half8 kb[NG], vb[NG];
-#pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        kb[it] = k0[it];
-        vb[it] = v0[it];
-      }
-      if (b > 0 && differs[b]) {
-#pragma unroll
-        for (int it = 0; it < NG; ++it) {
-          const f16* rb = row0[it] + ((ptrdiff_t)sb[b][it] - (ptrdiff_t)s0[it]) * (ptrdiff_t)ld;
-          kb[it] = *(const half8*)rb;
-        }
-#pragma unroll
-        for (int it = 0; it < NG; ++it) {
-          const f16* rb = row0[it] + ((ptrdiff_t)sb[b][it] - (ptrdiff_t)s0[it]) * (ptrdiff_t)ld;
-          vb[it] = *(const half8*)(rb + d);
-        }
-      }
-      float s[NG];
-#pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += q[b][e] * (float)kb[it][e];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        s[it] = valid[it] ? acc : -INFINITY;
-      }
-      float mx = s[0];
-#pragma unroll
-      for (int it = 1; it < NG; ++it) mx = fmaxf(mx, s[it]);
-      mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m[b], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m[b] - m_new);
-      float ps = 0.f;
-#pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        s[it] = __builtin_amdgcn_exp2f(s[it] - m_new);  // 0 for masked positions
-        ps += s[it];
-      }
-      ps += __shfl_xor(ps, 8, 64);
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
-      l[b] = l[b] * alpha + ps;
-      m[b] = m_new;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[b][e] *= alpha;
-#pragma unroll
-      for (int it = 0; it < NG; ++it)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[b][e] += s[it] * (float)vb[it][e];
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    half8 out;
-    const float inv_l = 1.0f / l[b];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float v = o[b][e];
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      out[e] = (f16)(v * inv_l);
-    }
-    if (pg == 0) *(half8*)(ctx + (size_t)(r0 + b) * d + h * 64 + c * 8) = out;
-  }
-}
-
-static int dec_attn_mode() {  // SMI_DEC_ATTN: 0 = one wave per (row, head) [round-2 kernel], 1 = beams merged (default)
-  static const int mode = [] {
-    const char* e = getenv("SMI_DEC_ATTN");
-    return e ? atoi(e) : 1;
-  }();
-  return mode;
-}
-
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
-                                int rows_pad, int d, int heads, int pos, int group, hipStream_t stream) {
+                                int rows_pad, int d, int heads, int pos, hipStream_t stream) {
   const float sl2e = 0.125f * 1.4426950408889634f;
-  if (dec_attn_mode() != 0 && group >= 1 && rows % group == 0) {
-    // beams per wave: the whole beam up to 5 (fairseq2's default beam_size), sub-groups of 4 / 3 for 8 / 6
-    const int nb = group <= 5 ? group : (group % 4 == 0 ? 4 : (group % 3 == 0 ? 3 : 1));
-    const int ngroups = rows / nb;
-    const dim3 grid((ngroups * heads + 3) / 4);
-    // ancestry positions 0..pos-1 in as few chunks as `cap` 8-position groups per chunk allow (register budget:
-    // a merged wave holds NB accumulator sets), and the smallest chunk that covers them in that many passes
-    const int cap = nb > 1 ? 4 : 8;
-    const int g8 = (pos + 7) / 8;
-    const int passes = g8 > 0 ? (g8 + cap - 1) / cap : 1;
-    const int ng = g8 > 0 ? (g8 + passes - 1) / passes : 1;
-#define SMI_DAB(NG_, NB_)                                                                                        \
-  hipLaunchKernelGGL((dec_attention_beams_kernel<NG_, NB_>), grid, dim3(256), 0, stream, kv, anc, anc_stride, ctx, \
-                     ngroups, rows_pad, d, heads, pos, sl2e)
-#define SMI_DAB_NG(NB_)              \
-  switch (ng) {                      \
-    case 1: SMI_DAB(1, NB_); break;  \
-    case 2: SMI_DAB(2, NB_); break;  \
-    case 3: SMI_DAB(3, NB_); break;  \
-    default: SMI_DAB(4, NB_); break; \
-  }
-    switch (nb) {
-      case 1:
-        switch (ng) {
-          case 1: SMI_DAB(1, 1); break;
-          case 2: SMI_DAB(2, 1); break;
-          case 3: SMI_DAB(3, 1); break;
-          case 4: SMI_DAB(4, 1); break;
-          case 5: SMI_DAB(5, 1); break;
-          case 6: SMI_DAB(6, 1); break;
-          case 7: SMI_DAB(7, 1); break;
-          default: SMI_DAB(8, 1); break;
-        }
-        break;
-      case 2: SMI_DAB_NG(2) break;
-      case 3: SMI_DAB_NG(3) break;
-      case 4: SMI_DAB_NG(4) break;
-      default: SMI_DAB_NG(5) break;
-    }
-#undef SMI_DAB_NG
-#undef SMI_DAB
-    return hipGetLastError();
-  }
   const int waves = rows * heads;
   const dim3 grid((waves + 3) / 4);
 #define SMI_DA_LAUNCH(NG)                                                                                          \

@@ -3,6 +3,7 @@
 // (reference op order: sonar/models/sonar_text/factory.py:261-307, pre-LN decoder layers,
 // final LayerNorm, tied projection; generation control: fairseq2 BeamSearchSeq2SeqGenerator).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "api_common.hpp"
@@ -19,6 +20,8 @@ struct DecLayer {
 };
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+constexpr int kMaxParts = 16;  // split-K slabs the `parts` buffer holds
 
 }  // namespace
 
@@ -94,7 +97,15 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
   const int P = D->kv_positions;
   float* parts = D->parts.as<float>();
   const size_t part_stride = (size_t)rows_pad * d;  // elements
-  const int ks_out = d % 256 == 0 ? 4 : 1, ks_ffn = f % 512 == 0 ? 8 : (f % 256 == 0 ? 4 : 1);
+  // Split-K parts of the two N = d projections.  FFN output (K = f): 8 parts of 32 K slices = 160 lone units at
+  // 1280 rows; 10 / 12 parts (unequal K ranges, 200 / 240 units) were traced and are NOT faster -- a unit's K loop
+  // shrinks 20.0 -> 15.3 us but its 256 KiB slab store grows 4.3 -> 6.4 us (the slab writes run at the chip's
+  // ~9.8 TB/s write path either way) and the fold reads 4 more slabs (profiles/r03_experiments.txt).
+  // Attention output (K = d): as many parts as keep every 128x128 unit on a CU of its own (2 at 1280 rows: 160 units
+  // on the lone-tile ring engine); SMI_DEC_KS_OUT overrides for A/B runs, 1 = no split, residual epilogue.
+  static const int ks_out_env = [] { const char* e = getenv("SMI_DEC_KS_OUT"); return e ? atoi(e) : 0; }();
+  const int ks_out = ks_out_env > 0 ? ks_out_env : gemm_splitk_parts(rows_pad, d, d, kMaxParts);
+  const int ks_ffn = f % 512 == 0 ? 8 : (f % 256 == 0 ? 4 : 1);
   HIP_TRY(launch_dec_embed(D->tok.as<int32_t>(), D->embed.as<f16>(),
                            D->pos.as<float>() + (size_t)(pos + c.pos_offset) * d, c.embed_scale, x, rows, d,
                            c.vocab_size, stream));
@@ -106,14 +117,18 @@ int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_p
                                  L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
                            rows_pad, 3 * d, d, 3 * d, stream));
-    HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, group, stream));
+    HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
     // the two N = d projections have too few tiles to fill 256 CUs at decode batch sizes:
     // split K into fp32 slabs that the next fused sum+LayerNorm folds into the residual stream
-    HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
+    if (ks_out == 1)  // no split: the projection adds into the fp32 residual stream itself
+      HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, rows_pad, d, d, d, stream));
+    else
+      HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
     // the FFN runs on tile-major operands (common.hpp): LN output, hidden activation and both weights
     const int tm = D->ffn_tile_major;
-    HIP_TRY(launch_sum_layernorm(x, parts, ks_out, part_stride, D->cc.as<float>() + (size_t)l * n_pad * d, group,
-                                 L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream, tm));
+    HIP_TRY(launch_sum_layernorm(x, ks_out == 1 ? nullptr : parts, ks_out, part_stride,
+                                 D->cc.as<float>() + (size_t)l * n_pad * d, group, L.ln3_w.as<float>(), L.ln3_b.as<float>(),
+                                 c.ln_eps, h, rows, d, stream, tm));
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | (tm ? GEMM_IN_TM | GEMM_OUT_TM : 0), h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn,
                            rows_pad, f, d, f, stream));
     HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm));
@@ -139,7 +154,7 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   HIP_TRY(D->ctx.reserve((size_t)rows_pad * d * 2));
   HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * 2));
   HIP_TRY(D->logits.reserve((size_t)rows_pad * D->vocab_pad * 4));
-  HIP_TRY(D->parts.reserve((size_t)8 * rows_pad * d * 4));
+  HIP_TRY(D->parts.reserve((size_t)kMaxParts * rows_pad * d * 4));
   // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM).
   // `positions` may be smaller than the generation cap: grow_kv() extends the cache when a call
   // actually decodes that far (the cap is max_seq_len = 512 for sentence vectors, fairseq2's

@@ -76,8 +76,10 @@ __device__ __forceinline__ half4 epi_act_pack(f32x4 v) {
 // output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N);
 // 3 = tile-major X, W and a tile-major fp16 RESIDUAL STREAM that is read-modified-written
 // (EPI_RESID_F16 only: the text encoder's x, so that the residual epilogue needs no LDS staging).
-template <int EPI, int LAYOUT = 0>
-__global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __restrict__ X,
+// RING: 0 = the two-stage loop, 2 workgroups per CU (launches with more tiles than CUs); 3 / 4 = the counted-wait
+// ring of gemm_tile.hpp with that many stages, 1 workgroup per CU (launches whose tiles all fit on the chip at once).
+template <int EPI, int LAYOUT = 0, int RING = 0>
+__global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
                                                                 const float* __restrict__ bias,
                                                                 void* __restrict__ out, int M, int N,
@@ -93,7 +95,10 @@ __global__ __launch_bounds__(GT_THREADS, 2) void gemm_tn_kernel(const f16* __res
   // the consumer sums the slabs (decode-time GEMMs have too few tiles to fill 256 CUs otherwise)
   const int kz = blockIdx.y;
   const int klen = K / ksplit;
-  gt_mainloop<(LAYOUT > 0)>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
+  if constexpr (RING)
+    gt_mainloop_ring<(LAYOUT > 0), RING>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
+  else
+    gt_mainloop<(LAYOUT > 0)>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
   if (kz > 0) {
     bias = nullptr;
     out = (char*)out + (size_t)kz * part_stride;
@@ -189,9 +194,19 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   constexpr bool TM = LAYOUT > 0;
   // work unit = (tile, K part kz): split-K (EPI_STORE_F32 only) gives each part its own fp32 output slab
   // at out + kz * part_stride bytes; the bias goes into part 0; the consumer sums the slabs.
-  const int klen = K / ksplit;
-  const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn * ksplit, nt = klen / G2_BK;
+  // K part kz of ksplit covers the K slices [S kz / ksplit, S (kz + 1) / ksplit), S = K / 32: the parts need not be
+  // equal (the decoder's FFN output projection runs 12 parts of 21-22 slices: 240 units on 256 CUs)
+  const int nslices = K / G2_BK;
+  auto kpart = [&](int kz_, int& s0, int& ns) {
+    s0 = (int)((long long)nslices * kz_ / ksplit);
+    ns = (int)((long long)nslices * (kz_ + 1) / ksplit) - s0;
+  };
+  const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn * ksplit;
   void* out = out_;
+#ifdef SMI_GEMM_TRACE
+  int trace_i = 0;
+  G2_TRACE(5);  // kernel entry
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // accumulator layout (gemm_tile256.hpp): lane -> row l15 of a 16-row block, 4 consecutive columns
   // at 4*kg of a 16-column block
@@ -243,13 +258,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   int tile = seek(xcd_remap(blockIdx.x, gridDim.x));
   if (tile >= nvirt) return;
   int kz = raster ? 0 : tile / nout;
-  G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
+  int ks0, nt;
+  kpart(kz, ks0, nt);
+  G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, ks0 * G2_BK);
   g2_prefetch(src, nt, smem);
   f32x4 bias_next = fetch_bias(tile_n * G2_BN, kz);
 
-#ifdef SMI_GEMM_TRACE
-  int trace_i = 0;
-#endif
   while (tile < nvirt) {
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
     const int tile_n_cur = tile_n;
@@ -265,7 +279,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     tile = seek(tile + (int)gridDim.x);  // (tile_m, tile_n) now name the NEXT tile; m0 / n0 keep this one
     if (tile < nvirt) {  // fill for the next tile, behind this tile's epilogue
       kz = raster ? 0 : tile / nout;
-      src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, kz * klen);
+      kpart(kz, ks0, nt);
+      src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, ks0 * G2_BK);
       g2_prefetch(src, nt, smem);
       bias_next = fetch_bias(tile_n * G2_BN, kz);
     }
@@ -560,20 +575,41 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   return hipGetLastError();
 }
 
-template <int EPI, int LAYOUT = 0>
-static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
-                             int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
+// SMI_GT_RING: stages of the lone-tile ring (0 = never use it, 3, 4; default 4) -- A/B switch
+static int gt_ring_stages() {
+  static const int st = [] {
+    const char* e = getenv("SMI_GT_RING");
+    const int v = e ? atoi(e) : 4;
+    return v == 3 || v == 4 ? v : 0;
+  }();
+  return st;
+}
+
+template <int EPI, int LAYOUT, int RING>
+static hipError_t launch_one_ring(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
+                                  int K, int ldo, hipStream_t stream, int ksplit, size_t part_stride) {
+  constexpr int lds = (RING ? RING : 2) * GT_STAGE_BYTES;
   static DeviceOnce attr_done;
   if (!attr_done.done()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI, LAYOUT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel<EPI, LAYOUT, RING>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done.set();
   }
   const int grid = (M / GT_BM) * (N / GT_BN);
-  hipLaunchKernelGGL((gemm_tn_kernel<EPI, LAYOUT>), dim3(grid, ksplit), dim3(GT_THREADS), GT_LDS_BYTES,
+  hipLaunchKernelGGL((gemm_tn_kernel<EPI, LAYOUT, RING>), dim3(grid, ksplit), dim3(GT_THREADS), lds,
                      stream, X, W, bias, out, M, N, K, ldo, ksplit, part_stride);
   return hipGetLastError();
+}
+
+template <int EPI, int LAYOUT = 0>
+static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
+                             int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
+  // every workgroup gets a CU of its own: hide the DMA latency with a deeper ring instead of a second workgroup
+  const int st = (M / GT_BM) * (N / GT_BN) * ksplit <= num_cus() ? gt_ring_stages() : 0;
+  if (st == 4) return launch_one_ring<EPI, LAYOUT, 4>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  if (st == 3) return launch_one_ring<EPI, LAYOUT, 3>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  return launch_one_ring<EPI, LAYOUT, 0>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
 }
 
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out,
@@ -641,17 +677,42 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
 // the consumer (launch_sum_layernorm) adds the slabs to the residual stream.
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
                                  int N, int K, int ksplit, hipStream_t stream, int in_tm) {
-  if (M % GT_BM || N % GT_BN || ksplit < 1 || K % (GT_BK * ksplit) || M <= 0) return hipErrorInvalidValue;
+  if (M % GT_BM || N % GT_BN || ksplit < 1 || K % GT_BK || M <= 0) return hipErrorInvalidValue;
   if (in_tm && (M % TM_ROWS || N % TM_ROWS)) return hipErrorInvalidValue;
   // the 256x256 ping-pong engine is far more efficient per CU than the 128x128 one (decoder FFN inner:
   // 160 tiles on 256 CUs still beat 640 small tiles); use it when the units roughly fill the chip once
-  // and every unit has a real K loop
+  // and every unit has a real K loop (its K parts may be unequal)
   const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
-  if (M % G2_BM == 0 && N % G2_BN == 0 && K / ksplit >= 16 * G2_BK && units256 >= 96 && units256 <= num_cus())
+  if (M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= 96 && units256 <= num_cus())
     return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4)
                  : launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
+  if (K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly
   return in_tm ? launch_one<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4)
                : launch_one<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
 }
 
+// How many K parts launch_gemm_tn_splitk should be given for a decode-time projection (M = beam x batch rows,
+// N = model_dim): as many as keep EVERY unit on a CU of its own -- one round of lone tiles is the fastest a
+// latency-bound launch gets -- without starving a unit of K loop.  <= max_parts (the slab buffer).
+int gemm_splitk_parts(int M, int N, int K, int max_parts) {
+  if (M % G2_BM == 0 && N % G2_BN == 0) {
+    const int tiles = (M / G2_BM) * (N / G2_BN);
+    const int ks = std::min(std::min(max_parts, num_cus() / std::max(tiles, 1)), (K / G2_BK) / 16);
+    if (ks >= 1 && tiles * ks >= 96) return ks;
+  }
+  const int tiles = (M / GT_BM) * (N / GT_BN);
+  int ks = 1;
+  while (ks * 2 <= max_parts && tiles * ks * 2 <= num_cus() && K % (GT_BK * ks * 2) == 0 && K / (ks * 2) >= 2 * GT_BK)
+    ks *= 2;
+  return ks;
+}
+
 }  // namespace smi
+
+#ifdef SMI_GEMM_TRACE
+extern "C" int smi_debug_gemm_splitk(const void* x, const void* w, const float* bias, float* parts, int m, int n, int k,
+                                     int ksplit, int in_tm, void* stream) {
+  return (int)smi::launch_gemm_tn_splitk((const smi::f16*)x, (const smi::f16*)w, bias, parts, m, n, k, ksplit,
+                                         (hipStream_t)stream, in_tm);
+}
+#endif

@@ -125,6 +125,103 @@ __device__ __forceinline__ void gt_mainloop(GemmTileAcc& acc, const f16* __restr
   }
 }
 
+// ---- latency-hiding variant for LONE tiles (round 3).  When a launch has no more tiles than CUs -- the decoder's
+// M = beam x batch projections, the encoder at small batches, the poolers -- a workgroup has the CU to itself and
+// the two-stage loop above is a chain of exposed DMA latencies: one K tile takes ~1.2 us (measured: 19.6 us for the
+// 16 K tiles of the decoder's fused QKV projection) against 0.2 us of MFMA work.  Here the ring holds ST stages of
+// K = 64 (ST * 32 KiB, one workgroup per CU), ST - 1 tiles are in flight, waits are COUNTED (vmcnt(8) per tile
+// still allowed in flight: a wave issues 8 DMA instructions per tile) and barriers are raw s_barrier, as in
+// gemm_tile256.hpp.  One interval per tile:
+//   fragments of tile t -> VGPRs | DMA of tile t+ST-1 into the stage tile t-1 was read from | counted wait for
+//   MY pieces of tile t+1 | lgkmcnt(0) + s_barrier | MFMAs of tile t
+// RAW: a wave passes vmcnt for its pieces of tile t+1 before the barrier that ends interval t, so after that barrier
+// every piece of tile t+1 is in LDS.  WAR: the stage refilled in interval t was last read in interval t-1, and every
+// wave retired those reads (lgkmcnt(0)) before the barrier that ended interval t-1.
+#define SMI_GT_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <bool TM, int ST>
+__device__ __forceinline__ void gt_mainloop_ring(GemmTileAcc& acc, const f16* __restrict__ X,
+                                                 const f16* __restrict__ W, int K, int m0, int n0,
+                                                 char* smem, int k0 = 0, int klen = -1) {
+  static_assert(ST == 3 || ST == 4, "ring of 3 or 4 stages");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const f16* xg[4];
+  const f16* wg[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = wave * 4 + q;
+    const int row = c * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    if constexpr (TM) {
+      xg[q] = X + tm_offset(m0 + row, k0 + chunk * 8, K);
+      wg[q] = W + tm_offset(n0 + row, k0 + chunk * 8, K);
+    } else {
+      xg[q] = X + (size_t)(m0 + row) * K + k0 + chunk * 8;
+      wg[q] = W + (size_t)(n0 + row) * K + k0 + chunk * 8;
+    }
+  }
+  constexpr int kstep = TM ? 2 * TM_BLOCK : GT_BK;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int t_sw = (hi ^ ((l31 >> 1) & 7)) << 4;
+  const int xrow_off = (wm * 64 + l31) * 128;
+  const int wrow_off = (wn * 64 + l31) * 128;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc.v[i][j][r] = 0.f;
+
+  const int nt = (klen < 0 ? K : klen) / GT_BK;
+#pragma unroll
+  for (int s = 0; s < ST - 1; ++s)
+    if (s < nt) gt_issue(xg, wg, s * kstep, smem + s * GT_STAGE_BYTES, wave);
+  // tile 0 landed (mine), the rest of the fill stays in flight
+  if (nt >= ST - 1) {
+    if constexpr (ST == 4) SMI_GT_WAIT_VMCNT(16); else SMI_GT_WAIT_VMCNT(8);
+  } else if (nt == 2) {
+    SMI_GT_WAIT_VMCNT(8);
+  } else {
+    SMI_GT_WAIT_VMCNT(0);
+  }
+  asm volatile("s_barrier" ::: "memory");
+  for (int t = 0; t < nt; ++t) {
+    const char* stage = smem + (t % ST) * GT_STAGE_BYTES;
+    const char* xs = stage + xrow_off;
+    const char* ws = stage + GT_BM * GT_BK * 2 + wrow_off;
+    half8 fw[4][2], fx[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = (t_sw ^ (ks << 5));
+      fw[ks][0] = *(const half8*)(ws + coff);
+      fw[ks][1] = *(const half8*)(ws + 32 * 128 + coff);
+      fx[ks][0] = *(const half8*)(xs + coff);
+      fx[ks][1] = *(const half8*)(xs + 32 * 128 + coff);
+    }
+    const int ahead = nt - 1 - t;  // tiles after this one
+    if (ahead >= ST - 1) {
+      gt_issue(xg, wg, (t + ST - 1) * kstep, smem + ((t + ST - 1) % ST) * GT_STAGE_BYTES, wave);
+      if constexpr (ST == 4) SMI_GT_WAIT_VMCNT(16); else SMI_GT_WAIT_VMCNT(8);
+    } else if (ahead == 2 && ST == 4) {
+      SMI_GT_WAIT_VMCNT(8);
+    } else {
+      SMI_GT_WAIT_VMCNT(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc.v[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][0], fx[ks][0], acc.v[0][0], 0, 0, 0);
+      acc.v[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][0], fx[ks][1], acc.v[0][1], 0, 0, 0);
+      acc.v[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][1], fx[ks][0], acc.v[1][0], 0, 0, 0);
+      acc.v[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks][1], fx[ks][1], acc.v[1][1], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Accumulator coordinates: acc.v[ni][mi][r] is C[m][n] with
 //   m = m0 + wm*64 + mi*32 + (lane&31)
 //   n = n0 + wn*64 + ni*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)

@@ -53,6 +53,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
                                  int N, int K, int ksplit, hipStream_t stream, int in_tm = 0);
+// number of K parts for a decode-time split-K projection (gemm.hip): every unit on its own CU, <= max_parts
+int gemm_splitk_parts(int M, int N, int K, int max_parts);
 
 // x[row(n,p), :] = E[ids[n*S+p], :] * scale + PE[p + pos_offset, :]   (packed rows)
 // x_f16: the residual stream x is fp16 (SMI_ENC_FP16_RESIDUAL) instead of fp32
@@ -109,10 +111,8 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
                                 f16* h, int rows, int d, hipStream_t stream, int h_tm = 0);
-// single-query attention of one decode step; `group` = rows per sentence (beam size; 1 = independent rows): the
-// beams of a sentence are reduced by one wave that shares the K / V rows their ancestries have in common
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
-                                int rows_pad, int d, int heads, int pos, int group, hipStream_t stream);
+                                int rows_pad, int d, int heads, int pos, hipStream_t stream);
 constexpr int kVocabScanK2Max = 16;
 // Per row: softmax normaliser (pmax, psum) from the GEMM's tile statistics and the top-k2 candidates
 // among the k2 best tiles + tile 0 (pval / pidx [rows][kVocabScanK2Max]), without re-reading the whole
