@@ -123,14 +123,16 @@ def xsim_cpu_baseline(nx=8192, ny=32768):
                       f"best of 2 ({', '.join(f'{t:.1f}' for t in ts)} s), extrapolated per pair"}
 
 
-def decoder_leg(dev, n=256, steps=64):
-    """BASELINE configs[4]: text_sonar_basic_decoder, beam 5, fp16, batch 256, `steps` forced steps."""
+def decoder_leg(dev, n=256, steps=64, cpu=True):
+    """BASELINE configs[4]: text_sonar_basic_decoder, beam 5, fp16, batch 256, `steps` forced steps; CPU baseline:
+    the oracle's incremental beam search (the reference's evaluation order) on a bounded sample, same weights."""
     import torch
 
     from sonar_amd.text_decoder import TextDecoderEngine, get_text_decoder_config
     from tools.synth import text_decoder_state_dict
 
-    eng = TextDecoderEngine(get_text_decoder_config("basic"), text_decoder_state_dict(dev), device=dev)
+    sd = text_decoder_state_dict(dev)
+    eng = TextDecoderEngine(get_text_decoder_config("basic"), sd, device=dev)
     g = torch.Generator(device=dev).manual_seed(7)
     emb = torch.nn.functional.normalize(torch.randn(n, D, device=dev, generator=g), dim=-1).half() * 0.2
     # untimed warm-up with the same shapes: the first call allocates the KV cache / logits workspace
@@ -141,20 +143,43 @@ def decoder_leg(dev, n=256, steps=64):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     flop_step = n * 5 * (L * (16 * D * D + 4 * D * F) + 2 * D * V)
-    return {"workload": f"text_sonar_basic_decoder beam 5 fp16, batch {n}, {steps + 1} decode steps (EOS blocked), eng_Latn prompt",
-            "ms": dt * 1e3, "ms_per_step": dt * 1e3 / (steps + 1), "sentences_per_s": n / dt,
-            "tokens_per_s": n * (steps + 1) / dt,
-            "frac_of_mfma_peak": flop_step * (steps + 1) / dt / 1e12 / MFMA_PEAK_TFLOPS}
+    out = {"workload": f"text_sonar_basic_decoder beam 5 fp16, batch {n}, {steps + 1} decode steps (EOS blocked), eng_Latn prompt",
+           "ms": dt * 1e3, "ms_per_step": dt * 1e3 / (steps + 1), "sentences_per_s": n / dt,
+           "tokens_per_s": n * (steps + 1) / dt,
+           "frac_of_mfma_peak": flop_step * (steps + 1) / dt / 1e12 / MFMA_PEAK_TFLOPS}
+    if cpu:
+        from oracle import text_decoder as OD
+
+        cores = cpu_threads()
+        ocfg = OD.OracleTextDecoderConfig()
+        params = {k: v.float().cpu() for k, v in sd.items()}
+        del sd
+        n_cpu, steps_cpu = 2, 12
+        e_cpu = emb[:n_cpu].float().cpu()
+        kw = dict(beam_size=5, min_gen_len=steps_cpu, max_gen_len=(0, steps_cpu))
+        t0 = time.perf_counter()
+        ref = OD.beam_search_incremental(params, ocfg, e_cpu, [3, 256047], **kw)
+        ct = time.perf_counter() - t0
+        toks, lens, _ = eng.generate(emb[:n_cpu], [3, 256047], **kw)
+        same = sum(toks[i, 0, : int(lens[i, 0])].tolist() == ref[i][0].seq.tolist() for i in range(n_cpu))
+        out["cpu_baseline"] = {"value": n_cpu * (steps_cpu + 1) / ct, "unit": "tokens/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_cpu} sentences x beam 5 x {steps_cpu + 1} decode steps, oracle incremental beam search "
+                                         f"(K/V cache, fp32, same weights), one run of {ct:.1f} s",
+                               "best_hypotheses_token_identical_to_gpu": f"{same}/{n_cpu}"}
+        out["speedup_vs_cpu_tokens_per_s"] = out["tokens_per_s"] / out["cpu_baseline"]["value"]
+    return out
 
 
-def speech_leg(dev, n=64):
-    """BASELINE configs[3]: sonar_speech_encoder_eng, 64 clips x 10 s @ 16 kHz (fbank + conformer + pooler)."""
+def speech_leg(dev, n=64, cpu=True):
+    """BASELINE configs[3]: sonar_speech_encoder_eng, 64 clips x 10 s @ 16 kHz (fbank + conformer + pooler); CPU baseline:
+    the oracle (Kaldi fbank + 24 conformer blocks + pooler, fp32, same weights) on 2 of the clips."""
     import torch
 
     from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveforms_to_fbank_batch
     from tools.synth import speech_encoder_state_dict
 
-    eng = SpeechEncoderEngine(get_speech_encoder_config("english"), speech_encoder_state_dict(dev), device=dev)
+    sd = speech_encoder_state_dict(dev)
+    eng = SpeechEncoderEngine(get_speech_encoder_config("english"), sd, device=dev)
     g = torch.Generator(device=dev).manual_seed(4)
     wavs = torch.rand(n, 160000, device=dev, generator=g) * 2 - 1
 
@@ -167,11 +192,36 @@ def speech_leg(dev, n=64):
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        run()
+        emb = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"workload": f"sonar_speech_encoder_eng fp16, {n} clips x 10 s @ 16 kHz, GPU fbank + 24 conformer blocks + pooler",
-            "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt}
+    out = {"workload": f"sonar_speech_encoder_eng fp16, {n} clips x 10 s @ 16 kHz, GPU fbank + 24 conformer blocks + pooler",
+           "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt}
+    if cpu:
+        from oracle import speech_encoder as OS
+
+        cores = cpu_threads()
+        so = OS.OracleSpeechEncoderConfig(model_dim=1024, num_layers=24, num_heads=16, ffn_inner_dim=4096, conv_kernel=31,
+                                          pooler_layers=3, pooler_heads=16, pooler_ffn_dim=4096, pooler_vocab=1024)
+        params = {k: v.float().cpu() for k, v in sd.items()}
+        del sd
+        n_cpu = 2
+        w_cpu = wavs[:n_cpu].cpu()
+
+        def cpu_run():
+            fb = torch.stack([OS.kaldi_fbank(w) for w in w_cpu])
+            return OS.speech_encoder_forward(params, so, fb, torch.tensor([fb.shape[1]] * n_cpu))[1]
+
+        t0 = time.perf_counter()
+        ref = cpu_run()
+        ct = time.perf_counter() - t0
+        cos = torch.nn.functional.cosine_similarity(emb[:n_cpu].float().cpu(), ref, dim=-1)
+        out["cpu_baseline"] = {"value": n_cpu / ct, "unit": "clips/s", "cores": cores, "kind": "port",
+                               "sample": f"{n_cpu} of the clips (10 s each), oracle Kaldi fbank + 24 conformer blocks + pooler, fp32, "
+                                         f"same weights, one run of {ct:.1f} s",
+                               "max_1_minus_cos_vs_gpu": float((1 - cos).max())}
+        out["speedup_vs_cpu"] = out["clips_per_s"] / out["cpu_baseline"]["value"]
+    return out
 
 
 # ---------------------------------------------------------------------- dry-run stubs (CPU, gloo)
@@ -486,11 +536,11 @@ def main():
         del model
         torch.cuda.empty_cache()
         try:
-            extra["decoder"] = decoder_leg(dev)
+            extra["decoder"] = decoder_leg(dev, cpu=not args.no_cpu_baseline)
         except Exception as e:  # the headline line must survive a failure here
             extra["decoder"] = {"error": repr(e)}
         try:
-            extra["speech"] = speech_leg(dev)
+            extra["speech"] = speech_leg(dev, cpu=not args.no_cpu_baseline)
         except Exception as e:
             extra["speech"] = {"error": repr(e)}
         model = None

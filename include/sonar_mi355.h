@@ -38,7 +38,11 @@ typedef enum smi_status {
   SMI_ERR_HIP = -5 /* a HIP runtime call failed; see smi_last_error() */
 } smi_status;
 
-typedef enum smi_dtype { SMI_F32 = 0, SMI_F16 = 1 } smi_dtype;
+/* SMI_BF16 exists at the BOUNDARY only (smi_cast): the engines take and return fp32 / fp16 tensors and compute with
+ * fp16 operands and fp32 accumulation whatever a model's nominal dtype is.  A bf16 model (the reference's pipelines
+ * accept any dtype, sonar/inference_pipelines/text.py:36-54,161-162) is served by casting: its weights are exactly
+ * representable in fp16 over the normal range, its outputs are rounded to bf16 once, on the way out. */
+typedef enum smi_dtype { SMI_F32 = 0, SMI_F16 = 1, SMI_BF16 = 2 } smi_dtype;
 typedef enum smi_pooling { SMI_POOL_MEAN = 0, SMI_POOL_MAX = 1, SMI_POOL_LAST = 2 } smi_pooling;
 
 /* A dense tensor handed to the engine at create time.  `data` may live in host
@@ -463,6 +467,10 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);
+/* dst[i] = (dst_dtype) src[i] for n elements of DEVICE memory (dtypes: smi_dtype incl. SMI_BF16; fp32 -> bf16 rounds to
+ * nearest even).  The bf16 side of the pipelines' `dtype=` argument: `model.to(device, dtype)` / the embeddings returned by
+ * TextToEmbeddingModelPipeline.predict (sonar/inference_pipelines/text.py:161-162, 262-268). */
+int smi_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream);
 /* out = f16(LN(x) * w + b); tile_major != 0: out in the tile-major layout ((rows+255)/256*256 rows allocated) */
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out_f16,
                   int32_t rows, int32_t d, int32_t tile_major, void* stream);

@@ -242,6 +242,126 @@ def beam_search(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, 
     return results
 
 
+class _IncrementalState:
+    """Per-layer self-attention K / V of the positions decoded so far, [beams, t, d] (fairseq2's IncrementalStateBag)."""
+
+    def __init__(self, num_layers: int):
+        self.k: List[Optional[torch.Tensor]] = [None] * num_layers
+        self.v: List[Optional[torch.Tensor]] = [None] * num_layers
+
+    def reorder(self, idx: torch.Tensor) -> None:
+        for i in range(len(self.k)):
+            if self.k[i] is not None:
+                self.k[i] = self.k[i].index_select(0, idx)
+                self.v[i] = self.v[i].index_select(0, idx)
+
+
+def _decoder_step_cached(params, cfg: OracleTextDecoderConfig, emb: torch.Tensor, tokens: torch.Tensor, pos: int,
+                         st: _IncrementalState) -> torch.Tensor:
+    """Logits [beams, V] of ONE new position `pos` for `tokens` [beams], given the cached prefix: the same arithmetic as
+    decoder_logits(...)[:, -1], evaluated the way the reference evaluates it (incremental decoding with a K/V cache,
+    cache rows re-ordered by index_select after each beam step).  Used for the CPU baseline timing of the C5 leg
+    (bench.py) and checked against the quadratic restatement in tests/test_oracle_decoder_cpu.py."""
+    d, hn = cfg.model_dim, cfg.num_heads
+    dh = d // hn
+    b = tokens.shape[0]
+    scale = 1.0 if cfg.no_scale_embedding else math.sqrt(d)
+    E = params["decoder_frontend.embed.weight"]
+    x = E[tokens].float() * scale + sinusoidal_table(cfg.pos_offset + pos + 1, d)[cfg.pos_offset + pos]
+    enc = emb.float().unsqueeze(1)
+    for i in range(cfg.num_layers):
+        p = f"decoder.layers.{i}."
+        h = _ln(x, params[p + "self_attn_layer_norm.weight"], params[p + "self_attn_layer_norm.bias"], cfg.ln_eps)
+        q = F.linear(h, params[p + "self_attn.q_proj.weight"], params[p + "self_attn.q_proj.bias"])
+        k = F.linear(h, params[p + "self_attn.k_proj.weight"], params[p + "self_attn.k_proj.bias"]).unsqueeze(1)
+        v = F.linear(h, params[p + "self_attn.v_proj.weight"], params[p + "self_attn.v_proj.bias"]).unsqueeze(1)
+        st.k[i] = k if st.k[i] is None else torch.cat([st.k[i], k], dim=1)
+        st.v[i] = v if st.v[i] is None else torch.cat([st.v[i], v], dim=1)
+        t = st.k[i].shape[1]
+        qh = q.view(b, 1, hn, dh).transpose(1, 2)
+        kh = st.k[i].view(b, t, hn, dh).transpose(1, 2)
+        vh = st.v[i].view(b, t, hn, dh).transpose(1, 2)
+        att = torch.softmax(torch.matmul(qh, kh.transpose(-1, -2)) * dh ** -0.5, dim=-1)
+        y = torch.matmul(att, vh).transpose(1, 2).reshape(b, d)
+        x = x + F.linear(y, params[p + "self_attn.output_proj.weight"], params[p + "self_attn.output_proj.bias"])
+        h = _ln(x, params[p + "encoder_decoder_attn_layer_norm.weight"],
+                params[p + "encoder_decoder_attn_layer_norm.bias"], cfg.ln_eps)
+        x = x + _mha(params, p + "encoder_decoder_attn.", h.unsqueeze(1), enc.expand(b, -1, -1), hn, causal=False).squeeze(1)
+        h = _ln(x, params[p + "ffn_layer_norm.weight"], params[p + "ffn_layer_norm.bias"], cfg.ln_eps)
+        h = F.relu(F.linear(h, params[p + "ffn.inner_proj.weight"], params[p + "ffn.inner_proj.bias"]))
+        x = x + F.linear(h, params[p + "ffn.output_proj.weight"], params[p + "ffn.output_proj.bias"])
+    x = _ln(x, params["decoder.layer_norm.weight"], params["decoder.layer_norm.bias"], cfg.ln_eps)
+    return F.linear(x, E)
+
+
+@torch.inference_mode()
+def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, prompt: Sequence[int],
+                            beam_size: int = 5, min_gen_len: int = 1, max_gen_len: Tuple[int, int] = (1, 128),
+                            max_seq_len: Optional[int] = None, normalize_scores: bool = True, len_penalty: float = 1.0,
+                            pad_idx: int = 0, eos_idx: int = 3, source_len: Optional[int] = None) -> List[List[Hypothesis]]:
+    """beam_search() with incremental decoding (K/V cache, index_select re-ordering): the evaluation order of the
+    reference's generator.  Same hypotheses as beam_search (tests/test_oracle_decoder_cpu.py); linear instead of
+    quadratic work in the output length, so this is the variant bench.py times as the CPU baseline."""
+    model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
+    plen = len(prompt)
+    if source_len is None:
+        source_len = cfg.model_dim
+    max_len = min(plen + int(max_gen_len[0] * source_len + max_gen_len[1]), model_max)
+    min_len = min(plen + min_gen_len, max_len)
+    results: List[List[Hypothesis]] = []
+    for e in embeddings:
+        emb = e.unsqueeze(0)
+        st = _IncrementalState(cfg.num_layers)
+        seqs = torch.tensor([list(prompt)], dtype=torch.int64)
+        cum = torch.zeros(1, plen, dtype=torch.float32)
+        for pos in range(plen - 1):      # prefill: teacher-forced prompt, scores of prompt tokens 1.. accumulate
+            lp = torch.log_softmax(_decoder_step_cached(params, cfg, emb, seqs[:, pos], pos, st), dim=-1, dtype=torch.float32)
+            cum[0, pos + 1] = cum[0, pos] + lp[0, seqs[0, pos + 1]]
+        finished: List[Hypothesis] = []
+        step_nr = plen
+        while True:
+            b = seqs.shape[0]
+            logits = _decoder_step_cached(params, cfg, emb.expand(b, -1), seqs[:, -1], step_nr - 1, st)
+            lprobs = torch.log_softmax(logits, dim=-1, dtype=torch.float32)
+            if step_nr == max_len - 1:
+                lprobs[:, :eos_idx] = -torch.inf
+                lprobs[:, eos_idx + 1:] = -torch.inf
+            else:
+                lprobs[:, pad_idx] = -torch.inf
+                if step_nr < min_len:
+                    lprobs[:, eos_idx] = -torch.inf
+            v = lprobs.shape[1]
+            cand = (lprobs + cum[:, -1:]).view(-1)
+            top_scores, top_idx = torch.topk(cand, min(2 * beam_size, v - 1))
+            seq_idx, vocab_idx = top_idx // v, top_idx % v
+            eos_mask = vocab_idx == eos_idx
+            done = False
+            head = eos_mask[:beam_size]
+            for si, sc in zip(seq_idx[:beam_size][head].tolist(), top_scores[:beam_size][head].tolist()):
+                seq = torch.cat([seqs[si], torch.tensor([eos_idx])])
+                steps = torch.cat([cum[si], torch.tensor([sc])])
+                seq_len = step_nr + 1
+                out_steps = steps[plen:seq_len] - steps[plen - 1:seq_len - 1]
+                score = sc / (seq_len - 1) ** len_penalty if normalize_scores else sc
+                finished.append(Hypothesis(seq[plen:], float(score), out_steps))
+                if len(finished) == beam_size:
+                    done = True
+                    break
+            if done:
+                break
+            keep = ~eos_mask
+            seq_idx, vocab_idx, top_scores = seq_idx[keep][:beam_size], vocab_idx[keep][:beam_size], top_scores[keep][:beam_size]
+            seqs = torch.cat([seqs[seq_idx], vocab_idx.unsqueeze(1)], dim=1)
+            cum = torch.cat([cum[seq_idx], top_scores.unsqueeze(1)], dim=1)
+            st.reorder(seq_idx)
+            step_nr += 1
+            if step_nr >= max_len:
+                break
+        finished.sort(key=lambda h: h.score, reverse=True)
+        results.append(finished)
+    return results
+
+
 @torch.inference_mode()
 def greedy_decode(params, cfg, embeddings, prompt, max_new: int, eos_idx: int = 3, pad_idx: int = 0):
     """Plain argmax decoding (used to sanity-check beam_size=1)."""

@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ["SMI_LIB"]).resolve() if os.environ.get("SMI_LIB") el
     Path(__file__).resolve().parent / "lib" / "libsonar_mi355.so"
 
 SMI_OK = 0
-SMI_F32, SMI_F16 = 0, 1
+SMI_F32, SMI_F16, SMI_BF16 = 0, 1, 2
 SMI_POOL = {"mean": 0, "max": 1, "last": 2}
 SMI_MARGIN = {"ratio": 0, "distance": 1, "cosine": 2}
 SMI_GEMM_IN_TM, SMI_GEMM_OUT_TM = 1 << 12, 1 << 13
@@ -256,6 +256,7 @@ SYMBOLS = {
     "smi_host_wav_info": (C.c_int, [_vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "smi_host_wav_decode": (C.c_int, [_vp, _i64, _vp, _i64, _i32]),
     "smi_pack_tile_major": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "smi_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "smi_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
@@ -287,6 +288,39 @@ def load() -> C.CDLL:
 def check(status: int) -> None:
     if status != SMI_OK:
         raise SmiError(status, load().smi_last_error().decode("utf-8", "replace"))
+
+
+_TORCH_DTYPES = None
+
+
+def smi_dtype_of(dtype) -> int:
+    """torch dtype -> smi_dtype of the boundary (fp32 / fp16 / bf16)."""
+    global _TORCH_DTYPES
+    if _TORCH_DTYPES is None:
+        import torch
+
+        _TORCH_DTYPES = {torch.float32: SMI_F32, torch.float16: SMI_F16, torch.bfloat16: SMI_BF16}
+    try:
+        return _TORCH_DTYPES[dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {dtype}: the engine's boundary speaks float32, float16 and bfloat16") from None
+
+
+def cast(t, dtype):
+    """Device tensor -> a new contiguous device tensor of `dtype`, converted by the engine (smi_cast) on the current
+    stream: the bf16 side of the pipelines' `dtype=` argument.  fp32 / fp16 / bf16 only."""
+    import torch
+
+    if t.dtype == dtype:
+        return t
+    if not t.is_cuda:
+        raise ValueError("smi_cast converts device tensors")
+    src = t.contiguous()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    with torch.cuda.device(src.device):
+        check(load().smi_cast(src.data_ptr(), smi_dtype_of(src.dtype), out.data_ptr(), smi_dtype_of(dtype), src.numel(),
+                              current_stream_ptr()))
+    return out
 
 
 def current_stream_ptr() -> int:

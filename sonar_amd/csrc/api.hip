@@ -554,6 +554,15 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
   return SMI_OK;
 }
 
+int smi_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return fail(SMI_ERR_INVALID_ARG, "bad argument");
+  if (src_dtype < SMI_F32 || src_dtype > SMI_BF16 || dst_dtype < SMI_F32 || dst_dtype > SMI_BF16)
+    return fail(SMI_ERR_INVALID_ARG, "bad dtype %d -> %d", src_dtype, dst_dtype);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_cast(src, src_dtype, dst, dst_dtype, (size_t)n, (hipStream_t)stream));
+  return SMI_OK;
+}
+
 int smi_layernorm(const float* x, const float* w, const float* b, float eps, void* out, int32_t rows,
                   int32_t d, int32_t tile_major, void* stream) {
   if (!x || !w || !b || !out || rows <= 0) return fail(SMI_ERR_INVALID_ARG, "bad argument");

@@ -85,6 +85,8 @@ hipError_t launch_attention(const f16* qkv, const int32_t* cu_seqlens, f16* ctx,
 
 // dst_f16[i] = f16(src_f32[i])
 hipError_t launch_f32_to_f16(const float* src, f16* dst, size_t n, hipStream_t stream);
+// element-wise cast, dtypes 0 = fp32, 1 = fp16, 2 = bf16 (smi_dtype)
+hipError_t launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, hipStream_t stream);
 // x[i] += sum_z parts[z * part_elems + i], i < n (n % 8 == 0); x fp16 or fp32 (rowops.hip)
 hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int nparts, size_t part_elems, size_t n,
                                 hipStream_t stream);

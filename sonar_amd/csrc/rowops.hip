@@ -809,6 +809,46 @@ __global__ __launch_bounds__(256) void f16_to_f32_kernel(const f16* __restrict__
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d[i] = (float)s[i];
 }
 
+// generic element-wise cast between the boundary dtypes (fp32 / fp16 / bf16): the engine computes in fp16 operands with
+// fp32 accumulation whatever the model's nominal dtype; a bf16 model's tensors enter and leave through this kernel
+// (bf16 -> fp32 is exact; fp32 -> bf16 rounds to nearest even, NaN kept quiet)
+struct Bf16 { uint16_t bits; };
+__device__ __forceinline__ float cast_load(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ float cast_load(const f16* p, size_t i) { return (float)p[i]; }
+__device__ __forceinline__ float cast_load(const Bf16* p, size_t i) { return __uint_as_float((uint32_t)p[i].bits << 16); }
+__device__ __forceinline__ void cast_store(float* p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void cast_store(f16* p, size_t i, float v) { p[i] = (f16)v; }
+__device__ __forceinline__ void cast_store(Bf16* p, size_t i, float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) {
+    u = (u >> 16) | 0x40u;  // NaN: keep it a (quiet) NaN
+  } else {
+    u = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even
+  }
+  p[i].bits = (uint16_t)u;
+}
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, size_t n) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) cast_store(d, i, cast_load(s, i));
+}
+
+hipError_t launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  if (src_dtype < 0 || src_dtype > 2 || dst_dtype < 0 || dst_dtype > 2) return hipErrorInvalidValue;
+  const int blocks = (int)min((size_t)8192, (n + 255) / 256);
+#define SMI_CAST(SI, ST, DI, DT)                                                                              \
+  if (src_dtype == SI && dst_dtype == DI) {                                                                   \
+    hipLaunchKernelGGL((cast_kernel<ST, DT>), dim3(blocks), dim3(256), 0, stream, (const ST*)src, (DT*)dst, n); \
+    return hipGetLastError();                                                                                 \
+  }
+  SMI_CAST(0, float, 0, float) SMI_CAST(0, float, 1, f16) SMI_CAST(0, float, 2, Bf16)
+  SMI_CAST(1, f16, 0, float) SMI_CAST(1, f16, 1, f16) SMI_CAST(1, f16, 2, Bf16)
+  SMI_CAST(2, Bf16, 0, float) SMI_CAST(2, Bf16, 1, f16) SMI_CAST(2, Bf16, 2, Bf16)
+#undef SMI_CAST
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_f32_to_f16(const float* src, f16* dst, size_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   const int blocks = (int)min((size_t)8192, (n / 4 + 255) / 256 + 1);

@@ -215,7 +215,7 @@ class SpeechToEmbeddingModelPipeline(SpeechModelPipelineInterface):
             if device.type != "cuda":
                 raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
             encoder = load_sonar_speech_encoder(str(encoder), device=device,
-                                                dtype=torch.float16 if fbank_dtype == torch.float16 else torch.float32)
+                                                dtype=fbank_dtype if fbank_dtype in (torch.float16, torch.bfloat16) else torch.float32)
         self.model = encoder.eval()
         self.device = getattr(encoder, "device", device)
         self.fbank_dtype = fbank_dtype

@@ -233,13 +233,16 @@ class SpeechEncoderEngine:
             if isinstance(fbank_lens, torch.Tensor):
                 fbank_lens = fbank_lens.detach().to("cpu", torch.int32).tolist()
             lens_arr = (C.c_int32 * n)(*[int(v) for v in fbank_lens])
-        out = torch.empty((n, self.cfg.model_dim), dtype=out_dtype, device=self.device)
+        if out_dtype not in (torch.float16, torch.float32, torch.bfloat16):
+            raise ValueError("out_dtype must be float16, bfloat16 or float32")
+        eng_dtype = torch.float32 if out_dtype == torch.bfloat16 else out_dtype   # bf16: rounded once, on the way out
+        out = torch.empty((n, self.cfg.model_dim), dtype=eng_dtype, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.smi_speech_encoder_forward(
                 self._handle, fb.data_ptr(), C.cast(lens_arr, C.c_void_p) if lens_arr is not None else None, n, t,
-                out.data_ptr(), _lib.SMI_F32 if out_dtype == torch.float32 else _lib.SMI_F16,
+                out.data_ptr(), _lib.SMI_F32 if eng_dtype == torch.float32 else _lib.SMI_F16,
                 _lib.current_stream_ptr()))
-        return out
+        return out if eng_dtype == out_dtype else _lib.cast(out, out_dtype)
 
 
 def waveform_to_fbank(waveform: torch.Tensor, waveform_scale: float = 2.0 ** 15, standardize: bool = True) -> torch.Tensor:
@@ -310,7 +313,7 @@ class SonarSpeechEncoderModel:
         self.model_dim = cfg.model_dim
         self.dtype = dtype
         self.engine = SpeechEncoderEngine(cfg, state_dict, device,
-                                          dtype == torch.float16 if fp16_residual is None else fp16_residual)
+                                          dtype in (torch.float16, torch.bfloat16) if fp16_residual is None else fp16_residual)
         self.device = self.engine.device
 
     def eval(self):

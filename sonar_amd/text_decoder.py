@@ -211,7 +211,9 @@ class TextDecoderEngine:
         if embeddings.dim() != 2 or embeddings.shape[1] != self.cfg.model_dim:
             raise ValueError(f"embeddings must be [n, {self.cfg.model_dim}]")
         e = embeddings.to(self.device)
-        if e.dtype not in (torch.float16, torch.float32):
+        if e.dtype == torch.bfloat16:
+            e = _lib.cast(e, torch.float32)      # a bf16 sentence vector is exact in fp32
+        elif e.dtype not in (torch.float16, torch.float32):
             e = e.float()
         return e.contiguous()
 

@@ -290,8 +290,11 @@ class TextEncoderEngine:
             if len(seq_lens) != n:
                 raise ValueError("seq_lens must have one entry per sequence")
             lens_arr = (C.c_int32 * n)(*[int(v) for v in seq_lens])
-        if out_dtype not in (torch.float16, torch.float32):
-            raise ValueError("out_dtype must be float16 or float32")
+        if out_dtype not in (torch.float16, torch.float32, torch.bfloat16):
+            raise ValueError("out_dtype must be float16, bfloat16 or float32")
+        want = out_dtype
+        if out_dtype == torch.bfloat16:  # bf16 exists at the boundary only: fp32 out of the engine, rounded once
+            out_dtype = torch.float32
         emb = torch.empty((n, self.cfg.model_dim), dtype=out_dtype, device=self.device)
         enc = torch.empty((n, s, self.cfg.model_dim), dtype=out_dtype, device=self.device) if return_encoded else None
         with torch.cuda.device(self.device):
@@ -300,6 +303,9 @@ class TextEncoderEngine:
                 n, s, emb.data_ptr(), enc.data_ptr() if enc is not None else None,
                 _lib.SMI_F32 if out_dtype == torch.float32 else _lib.SMI_F16,
                 _lib.current_stream_ptr()))
+        if want != out_dtype:
+            emb = _lib.cast(emb, want)
+            enc = _lib.cast(enc, want) if enc is not None else None
         return emb, enc
 
 
@@ -354,8 +360,12 @@ class SonarTextTransformerEncoderModel:
         """dtype: dtype of the returned embeddings and, as in the reference (`model.to(device, dtype)`,
         text.py:161-162), of the residual stream: fp16 model -> fp16 residual adds (one rounding each),
         fp32 model -> fp32 residual stream.  `fp16_residual` overrides that choice."""
+        if dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            raise ValueError(f"unsupported model dtype {dtype} (float16, bfloat16 or float32)")
         if fp16_residual is None:
-            fp16_residual = dtype == torch.float16
+            # a bf16 model runs the fast path too: its weights are exactly representable as fp16 operands, its
+            # embeddings are rounded to bf16 on the way out (include/sonar_mi355.h, SMI_BF16)
+            fp16_residual = dtype in (torch.float16, torch.bfloat16)
         self.config = cfg
         self.dtype = dtype
         self.model_dim = cfg.model_dim

@@ -213,3 +213,49 @@ def test_encoder_max_seq_len_514():
     assert _cos_err(emb, ref) <= 1e-3
     with pytest.raises(_lib.SmiError):
         model(SequenceBatch(torch.zeros(1, 515, dtype=torch.int64).cuda(), None))
+
+
+def test_smi_cast_matches_torch_rounding():
+    """The boundary cast (smi_cast): bf16 <-> fp32 <-> fp16, round-to-nearest-even incl. ties, +-0, inf, NaN, subnormals."""
+    from sonar_amd import _lib
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(100003, generator=g) * torch.logspace(-30, 30, 100003)
+    special = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1.0, 1.00390625, 1.01171875,   # ties at bf16
+                            3.3895313892515355e+38, 1e-40, -1e-45, 65504.0, 65520.0])
+    x = torch.cat([x, special]).cuda()
+    for dst in (torch.bfloat16, torch.float16, torch.float32):
+        for src in (torch.float32, torch.bfloat16, torch.float16):
+            a = x.to(src)
+            got = _lib.cast(a, dst)
+            want = a.to(dst)
+            assert got.dtype == dst and got.shape == a.shape
+            nan = torch.isnan(want.float())
+            assert torch.equal(torch.isnan(got.float()), nan), (src, dst)
+            assert torch.equal(got.float()[~nan], want.float()[~nan]), (src, dst)
+
+
+def test_bf16_model_at_the_boundary():
+    """`dtype=torch.bfloat16` (the reference's pipelines accept any dtype, text.py:36-54, 161-162): bf16 weights are
+    exact fp16 operands, embeddings come back in bf16 and stay within the north_star bound of the fp32 oracle run on
+    the SAME (bf16-representable) weights."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import (PaddingMask, SequenceBatch, SonarTextEncoderConfig,
+                                        SonarTextTransformerEncoderModel, VocabularyInfo)
+
+    ocfg = O.OracleTextEncoderConfig(model_dim=256, num_layers=2, num_heads=4, ffn_inner_dim=512, vocab_size=1000)
+    cfg = SonarTextEncoderConfig(model_dim=256, num_encoder_layers=2, num_encoder_attn_heads=4, ffn_inner_dim=512,
+                                 vocab_info=VocabularyInfo(size=1000), _from_fairseq=True)
+    params = {k: v.to(torch.bfloat16) for k, v in O.make_synthetic_params(ocfg, seed=77, std=0.08).items()}
+    ids, lens = O.synthetic_batch(9, 5, 40, ocfg.vocab_size, seed=3)
+    _, ref = O.text_encoder_forward({k: v.float() for k, v in params.items()}, ocfg, ids, lens)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.bfloat16)
+    out = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+    assert out.dtype == torch.bfloat16 and out.shape == (9, 256)
+    err = (1 - F.cosine_similarity(out.float().cpu(), ref, dim=-1)).abs().max().item()
+    print(f"bf16 model: max (1 - cos) vs oracle = {err:.2e}")
+    assert err <= 1e-3
+    # the same weights served as an fp16 model: identical up to the final rounding to bf16
+    m16 = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float16)
+    o16 = m16(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+    assert (out.float() - o16.float()).abs().max().item() <= 2 ** -7 * o16.float().abs().max().item()

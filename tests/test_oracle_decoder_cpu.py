@@ -118,3 +118,24 @@ def test_greedy_generation_matches_hf_generate():
                 m = len(want) - 1
                 assert g[:m] == want[:m]
     assert stopped >= 10 and capped >= 10     # the fixture exercises both exits
+
+
+def test_incremental_beam_search_equals_the_quadratic_restatement():
+    """oracle.beam_search_incremental (K/V cache + index_select re-ordering, the reference's evaluation order; the
+    variant bench.py times as the C5 CPU baseline) returns the hypotheses of oracle.beam_search."""
+    import torch
+
+    from oracle import text_decoder as OD
+
+    cfg = OD.OracleTextDecoderConfig(model_dim=64, num_layers=2, num_heads=4, ffn_inner_dim=96, vocab_size=200, max_seq_len=40)
+    params = OD.make_synthetic_params(cfg, seed=5, std=0.12)
+    emb = torch.randn(4, 64, generator=torch.Generator().manual_seed(1)) * 0.4
+    for beam, kw in ((1, dict(max_gen_len=(0, 12))), (3, dict(max_gen_len=(0, 17), min_gen_len=9)), (5, dict(max_gen_len=(0, 9)))):
+        a = OD.beam_search(params, cfg, emb, [3, 150], beam_size=beam, **kw)
+        b = OD.beam_search_incremental(params, cfg, emb, [3, 150], beam_size=beam, **kw)
+        for ha, hb in zip(a, b):
+            assert len(ha) == len(hb) == beam
+            for x, y in zip(ha, hb):
+                assert x.seq.tolist() == y.seq.tolist()
+                assert abs(x.score - y.score) <= 1e-5
+                assert torch.allclose(x.step_scores, y.step_scores, atol=1e-5)
