@@ -180,7 +180,7 @@ def beam_search(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, 
     # vec2text pipeline passes the stacked embeddings [n, model_dim] as source_seqs (text.py:329-333),
     # so the "source length" is model_dim there; text / speech sources pass their token / frame count.
     if source_len is None:
-        source_len = cfg.model_dim
+        source_len = cfg.cond_dim
     gen_cap = int(max_gen_len[0] * source_len + max_gen_len[1])
     max_len = min(plen + gen_cap, model_max)
     min_len = min(plen + min_gen_len, max_len)
@@ -305,7 +305,7 @@ def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: to
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
     plen = len(prompt)
     if source_len is None:
-        source_len = cfg.model_dim
+        source_len = cfg.cond_dim
     max_len = min(plen + int(max_gen_len[0] * source_len + max_gen_len[1]), model_max)
     min_len = min(plen + min_gen_len, max_len)
     results: List[List[Hypothesis]] = []
@@ -484,7 +484,7 @@ def sampling_generate(params, cfg: OracleTextDecoderConfig, embeddings: torch.Te
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
     plen = len(prompt)
     if source_len is None:
-        source_len = cfg.model_dim
+        source_len = cfg.cond_dim
     max_len = min(plen + int(max_gen_len[0] * source_len + max_gen_len[1]), model_max)
     min_len = min(plen + min_gen_len, max_len)
     out = []

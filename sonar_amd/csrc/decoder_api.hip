@@ -43,50 +43,109 @@ struct smi_text_decoder {
   int64_t weight_bytes = 0;
   int kv_positions = 0;  // positions per layer in the current kv allocation
   int ffn_tile_major = 0;  // FFN weights stored tile-major (d, f multiples of 256)
+  // Generic-dimension mode (flex.hip): head_dim != 64 or dimensions the MFMA engines do not tile for (the reference's
+  // `toy` arch, config.py:232-255).  fp32 weights, activations and KV cache; the beam search / sampling kernels are
+  // shared with the fast mode (they only see logits rows and tile statistics).
+  bool flex = false;
+  size_t act_bytes() const { return flex ? 4 : 2; }  // element size of h / ctx / ffn / the KV cache
 };
 
 namespace {
 
-int check_dec_cfg(const smi_text_decoder_config& c) {
-  if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim != c.num_heads * 64)
-    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must equal num_heads %d * 64", c.model_dim, c.num_heads);
-  if (c.model_dim % 256 || (c.model_dim / 256 > 4 && c.model_dim != 2048))
-    return fail(SMI_ERR_UNSUPPORTED, "model_dim %d must be 256/512/768/1024/2048", c.model_dim);
-  if (c.ffn_inner_dim <= 0 || c.ffn_inner_dim % 128)
-    return fail(SMI_ERR_UNSUPPORTED, "ffn_inner_dim %d must be a multiple of 128", c.ffn_inner_dim);
+// SMI_OK and *flex = false: the MFMA engines cover the shape; *flex = true: the generic-dimension kernels do
+int check_dec_cfg(const smi_text_decoder_config& c, bool* flex) {
+  if (c.model_dim <= 0 || c.num_heads <= 0 || c.model_dim % c.num_heads)
+    return fail(SMI_ERR_INVALID_ARG, "model_dim %d must be a positive multiple of num_heads %d", c.model_dim, c.num_heads);
+  if (c.ffn_inner_dim <= 0 || c.input_dim <= 0)
+    return fail(SMI_ERR_INVALID_ARG, "bad ffn_inner_dim %d / input_dim %d", c.ffn_inner_dim, c.input_dim);
   if (c.num_layers < 0 || c.vocab_size <= 16 || c.max_seq_len <= 1 || c.pos_offset < 0)
     return fail(SMI_ERR_INVALID_ARG, "bad num_layers/vocab_size/max_seq_len/pos_offset");
-  if (c.input_dim != c.model_dim)
-    return fail(SMI_ERR_UNSUPPORTED, "input_dim %d != model_dim %d is not covered", c.input_dim, c.model_dim);
+  const bool fast = c.model_dim == c.num_heads * 64 && c.model_dim % 256 == 0 &&
+                    (c.model_dim / 256 <= 4 || c.model_dim == 2048) && c.ffn_inner_dim % 128 == 0 && c.input_dim % 64 == 0;
+  if (!fast && c.model_dim / c.num_heads > 256)
+    return fail(SMI_ERR_UNSUPPORTED, "head_dim %d > 256 is not covered", c.model_dim / c.num_heads);
+  *flex = !fast;
   return SMI_OK;
 }
 
 // per-sentence cross-attention constants cc[l][s] = W_o (W_v e_s + b_v) + b_o  (fp32 [L][n_pad][d])
 int compute_cross_constants(smi_text_decoder* D, const void* emb, int emb_dtype, int n, int n_pad,
                             hipStream_t stream) {
-  const int d = D->cfg.model_dim;
-  HIP_TRY(D->emb16.reserve((size_t)n_pad * d * 2));
-  HIP_TRY(D->cvtmp.reserve((size_t)n_pad * d * 2));
+  const int d = D->cfg.model_dim, ci = D->cfg.input_dim;  // the conditioning vector may be wider / narrower than the model
   HIP_TRY(D->cc.reserve((size_t)D->cfg.num_layers * n_pad * d * 4));
-  HIP_TRY(hipMemsetAsync(D->emb16.p, 0, (size_t)n_pad * d * 2, stream));
+  if (D->flex) {
+    HIP_TRY(D->emb16.reserve((size_t)n * ci * 4));  // fp32 copy of the sentence vectors
+    HIP_TRY(D->cvtmp.reserve((size_t)n * d * 4));
+    if (emb_dtype == SMI_F32)
+      HIP_TRY(hipMemcpyAsync(D->emb16.p, emb, (size_t)n * ci * 4, hipMemcpyDeviceToDevice, stream));
+    else
+      HIP_TRY(launch_f16_to_f32((const f16*)emb, D->emb16.as<float>(), (size_t)n * ci, stream));
+    for (int l = 0; l < D->cfg.num_layers; ++l) {
+      DecLayer& L = D->layers[l];
+      HIP_TRY(launch_flex_linear(D->emb16.as<float>(), ci, L.wc_v.as<float>(), L.bc_v.as<float>(), D->cvtmp.as<float>(), d,
+                                 n, d, ci, 0, nullptr, 0, stream));
+      HIP_TRY(launch_flex_linear(D->cvtmp.as<float>(), d, L.wc_o.as<float>(), L.bc_o.as<float>(),
+                                 D->cc.as<float>() + (size_t)l * n_pad * d, d, n, d, d, 0, nullptr, 0, stream));
+    }
+    return SMI_OK;
+  }
+  HIP_TRY(D->emb16.reserve((size_t)n_pad * ci * 2));
+  HIP_TRY(D->cvtmp.reserve((size_t)n_pad * d * 2));
+  HIP_TRY(hipMemsetAsync(D->emb16.p, 0, (size_t)n_pad * ci * 2, stream));
   if (emb_dtype == SMI_F32)
-    HIP_TRY(launch_f32_to_f16((const float*)emb, D->emb16.as<f16>(), (size_t)n * d, stream));
+    HIP_TRY(launch_f32_to_f16((const float*)emb, D->emb16.as<f16>(), (size_t)n * ci, stream));
   else
-    HIP_TRY(hipMemcpyAsync(D->emb16.p, emb, (size_t)n * d * 2, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(D->emb16.p, emb, (size_t)n * ci * 2, hipMemcpyDeviceToDevice, stream));
   HIP_TRY(hipMemsetAsync(D->cc.p, 0, (size_t)D->cfg.num_layers * n_pad * d * 4, stream));
   for (int l = 0; l < D->cfg.num_layers; ++l) {
     DecLayer& L = D->layers[l];
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, D->emb16.as<f16>(), L.wc_v.as<f16>(), L.bc_v.as<float>(),
-                           D->cvtmp.p, n_pad, d, d, d, stream));
+                           D->cvtmp.p, n_pad, d, ci, d, stream));
     HIP_TRY(launch_gemm_tn(EPI_RESID_F32, D->cvtmp.as<f16>(), L.wc_o.as<f16>(), L.bc_o.as<float>(),
                            D->cc.as<float>() + (size_t)l * n_pad * d, n_pad, d, d, d, stream));
   }
   return SMI_OK;
 }
 
+// The same step on the generic-dimension kernels (flex.hip): fp32 throughout, one launch per reference module.
+int flex_decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_pad, int pos,
+                      const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale) {
+  const smi_text_decoder_config& c = D->cfg;
+  const int d = c.model_dim, f = c.ffn_inner_dim;
+  float* x = D->x.as<float>();
+  float* h = D->h.as<float>();
+  float* ctx = D->ctx.as<float>();
+  float* ffn = D->ffn.as<float>();
+  const size_t slab = (size_t)rows_pad * 3 * d;
+  const int P = D->kv_positions;
+  HIP_TRY(launch_flex_embed(nullptr, D->tok.as<int32_t>(), D->embed.as<float>(), D->pos.as<float>(), c.embed_scale, x, rows, d,
+                            1, c.pos_offset, pos, c.vocab_size, nullptr, stream));
+  for (int l = 0; l < c.num_layers; ++l) {
+    DecLayer& L = D->layers[l];
+    float* kvl = D->kv.as<float>() + (size_t)l * P * slab;
+    HIP_TRY(launch_flex_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, rows, d, stream));
+    HIP_TRY(launch_flex_linear(h, d, L.w_qkv.as<float>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab, 3 * d, rows, 3 * d,
+                               d, 0, nullptr, 0, stream));
+    HIP_TRY(launch_flex_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
+    HIP_TRY(launch_flex_linear(ctx, d, L.w_o.as<float>(), L.b_o.as<float>(), x, d, rows, d, d, 0, x, d, stream));
+    HIP_TRY(launch_flex_add_rows(x, D->cc.as<float>() + (size_t)l * n_pad * d, rows, d, group, stream));
+    HIP_TRY(launch_flex_layernorm(x, L.ln3_w.as<float>(), L.ln3_b.as<float>(), c.ln_eps, h, rows, d, stream));
+    HIP_TRY(launch_flex_linear(h, d, L.w_1.as<float>(), L.b_1.as<float>(), ffn, f, rows, f, d, 1, nullptr, 0, stream));
+    HIP_TRY(launch_flex_linear(ffn, f, L.w_2.as<float>(), L.b_2.as<float>(), x, d, rows, d, f, 0, x, d, stream));
+  }
+  HIP_TRY(launch_flex_layernorm(x, D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows, d, stream));
+  HIP_TRY(launch_flex_linear(h, d, D->embed.as<float>(), nullptr, D->logits.as<float>(), (int)D->vocab_pad, rows,
+                             (int)c.vocab_size, d, 0, nullptr, 0, stream));
+  if (stats_scale > 0.f)
+    HIP_TRY(launch_flex_tile_stats(D->logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size, stats_scale,
+                                   D->tile_max.as<float>(), D->tile_sum.as<float>(), rows_pad, stream));
+  return SMI_OK;
+}
+
 // one decoder step at position `pos` for `rows` rows (rows_pad GEMM rows); logits -> D->logits
 int decoder_step(smi_text_decoder* D, int rows, int rows_pad, int group, int n_pad, int pos,
                  const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f) {
+  if (D->flex) return flex_decoder_step(D, rows, rows_pad, group, n_pad, pos, anc, anc_stride, stream, stats_scale);
   const smi_text_decoder_config& c = D->cfg;
   const int d = c.model_dim, f = c.ffn_inner_dim;
   float* x = D->x.as<float>();
@@ -149,10 +208,11 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   const smi_text_decoder_config& c = D->cfg;
   const size_t d = c.model_dim, f = c.ffn_inner_dim;
   const size_t before = D->x.bytes + D->h.bytes + D->ctx.bytes + D->ffn.bytes;
+  const size_t es = D->act_bytes();
   HIP_TRY(D->x.reserve((size_t)rows_pad * d * 4));
-  HIP_TRY(D->h.reserve((size_t)rows_pad * d * 2));
-  HIP_TRY(D->ctx.reserve((size_t)rows_pad * d * 2));
-  HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * 2));
+  HIP_TRY(D->h.reserve((size_t)rows_pad * d * es));
+  HIP_TRY(D->ctx.reserve((size_t)rows_pad * d * es));
+  HIP_TRY(D->ffn.reserve((size_t)rows_pad * f * es));
   HIP_TRY(D->logits.reserve((size_t)rows_pad * D->vocab_pad * 4));
   HIP_TRY(D->parts.reserve((size_t)kMaxParts * rows_pad * d * 4));
   // kv cache for this call: [layers][positions][rows_pad][3d] (q|k|v slabs written by the QKV GEMM).
@@ -160,7 +220,7 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
   // actually decodes that far (the cap is max_seq_len = 512 for sentence vectors, fairseq2's
   // a * source_len + b rule; typical outputs stop after a few dozen tokens).
   {
-    const size_t per_pos = (size_t)c.num_layers * rows_pad * 3 * d * 2;
+    const size_t per_pos = (size_t)c.num_layers * rows_pad * 3 * d * es;
     const int have = per_pos ? (int)std::min<size_t>(D->kv.bytes / per_pos, (size_t)c.max_seq_len) : 0;
     if (have >= positions) {
       D->kv_positions = have;
@@ -183,7 +243,7 @@ int ensure_step_workspace(smi_text_decoder* D, int rows_pad, int positions) {
 // with room for `positions` positions per layer (layout [layer][position][rows_pad][3d])
 int grow_kv(smi_text_decoder* D, int rows_pad, int positions, hipStream_t stream) {
   const smi_text_decoder_config& c = D->cfg;
-  const size_t slab = (size_t)rows_pad * 3 * c.model_dim * 2;  // bytes per (layer, position)
+  const size_t slab = (size_t)rows_pad * 3 * c.model_dim * D->act_bytes();  // bytes per (layer, position)
   const int old_p = D->kv_positions;
   if (positions <= old_p) return SMI_OK;
   DevBuf bigger;
@@ -207,27 +267,30 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
                             smi_text_decoder** out) {
   if (!cfg || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
-  if (int rc = check_dec_cfg(*cfg)) return rc;
+  bool flex = false;
+  if (int rc = check_dec_cfg(*cfg, &flex)) return rc;
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->num_layers > 0 && !w->layers) return fail(SMI_ERR_INVALID_ARG, "null layers");
   smi_text_decoder* D = new smi_text_decoder();
   D->cfg = *cfg;
+  D->flex = flex;
   D->vocab_pad = round_up(cfg->vocab_size, 256);
-  const int64_t d = cfg->model_dim, f = cfg->ffn_inner_dim;
+  const int64_t d = cfg->model_dim, f = cfg->ffn_inner_dim, ci = cfg->input_dim;
   int rc = SMI_OK;
+  // flex mode keeps every tensor fp32 (upload converts); the MFMA mode wants fp16 matrices
   auto up = [&](const smi_tensor& t, int64_t numel, bool f16w, DevBuf& dst, const char* name, int64_t pad = 0) {
-    if (rc == SMI_OK) rc = upload(t, numel, f16w, dst, name, pad);
+    if (rc == SMI_OK) rc = upload(t, numel, f16w && !flex, dst, name, pad);
   };
   // the tied output projection multiplies by the embedding table: pad it to 256-row tiles
   up(w->embed, cfg->vocab_size * d, true, D->embed, "decoder_frontend.embed.weight", D->vocab_pad * d);
-  if (rc == SMI_OK && d % 256 == 0) {  // [vocab_pad][d] -> tile-major (common.hpp), ~0.5 GB for NLLB
+  if (rc == SMI_OK && !flex && d % 256 == 0) {  // [vocab_pad][d] -> tile-major (common.hpp), ~0.5 GB for NLLB
     rc = upload(w->embed, cfg->vocab_size * d, true, D->embed_tm, "decoder_frontend.embed.weight", D->vocab_pad * d);
     if (rc == SMI_OK) rc = to_tile_major(D->embed_tm, (int)D->vocab_pad, (int)d);
   }
   up(w->pos_table, (int64_t)(cfg->max_seq_len + cfg->pos_offset) * d, false, D->pos, "pos_table");
   up(w->final_layer_norm_w, d, false, D->lnf_w, "decoder.layer_norm.weight");
   up(w->final_layer_norm_b, d, false, D->lnf_b, "decoder.layer_norm.bias");
-  D->ffn_tile_major = d % 256 == 0 && f % 256 == 0;
+  D->ffn_tile_major = !flex && d % 256 == 0 && f % 256 == 0;
   D->layers.resize(cfg->num_layers);
   for (int l = 0; l < cfg->num_layers && rc == SMI_OK; ++l) {
     const smi_text_decoder_layer& s = w->layers[l];
@@ -238,7 +301,7 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
     up(s.ffn_layer_norm_b, d, false, L.ln3_b, "ffn_layer_norm.bias");
     up(s.out_w, d * d, true, L.w_o, "self_attn.output_proj.weight");
     up(s.out_b, d, false, L.b_o, "self_attn.output_proj.bias");
-    up(s.cross_v_w, d * d, true, L.wc_v, "encoder_decoder_attn.v_proj.weight");
+    up(s.cross_v_w, d * ci, true, L.wc_v, "encoder_decoder_attn.v_proj.weight");  // [model_dim, input_dim]
     up(s.cross_v_b, d, false, L.bc_v, "encoder_decoder_attn.v_proj.bias");
     up(s.cross_out_w, d * d, true, L.wc_o, "encoder_decoder_attn.output_proj.weight");
     up(s.cross_out_b, d, false, L.bc_o, "encoder_decoder_attn.output_proj.bias");
@@ -259,9 +322,10 @@ int smi_text_decoder_create(const smi_text_decoder_config* cfg, const smi_text_d
       up(s.k_b, d, false, bk, "self_attn.k_proj.bias");
       up(s.v_b, d, false, bv, "self_attn.v_proj.bias");
       if (rc == SMI_OK) {
-        hipError_t he = L.w_qkv.alloc((size_t)3 * d * d * 2);
+        const size_t wes = flex ? 4 : 2;
+        hipError_t he = L.w_qkv.alloc((size_t)3 * d * d * wes);
         if (he == hipSuccess) he = L.b_qkv.alloc((size_t)3 * d * 4);
-        const size_t wb = (size_t)d * d * 2, bb = (size_t)d * 4;
+        const size_t wb = (size_t)d * d * wes, bb = (size_t)d * 4;
         if (he == hipSuccess) he = hipMemcpy(L.w_qkv.p, tq.p, wb, hipMemcpyDeviceToDevice);
         if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + wb, tk.p, wb, hipMemcpyDeviceToDevice);
         if (he == hipSuccess) he = hipMemcpy((char*)L.w_qkv.p + 2 * wb, tv.p, wb, hipMemcpyDeviceToDevice);

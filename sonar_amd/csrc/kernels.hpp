@@ -19,6 +19,29 @@ struct DeviceOnce {
   bool done() const { return (mask.load(std::memory_order_acquire) >> dev()) & 1ull; }
   void set() { mask.fetch_or(1ull << dev(), std::memory_order_release); }
 };
+// ---- generic-dimension kernels (flex.hip): fp32 activations and weights, any model_dim / head_dim <= 256 ----
+// Y[M,N] = act(X[M,K] . W[N,K]^T + bias) (+ R); act 0 none, 1 relu; R may alias Y
+hipError_t launch_flex_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M,
+                              int N, int K, int act, const float* R, int ldr, hipStream_t stream);
+hipError_t launch_flex_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int d,
+                                 hipStream_t stream);
+// x[r] = table[id[r]] * scale (+ pe[pos + pos_offset]); ids64 ([n, s] batch, pos = r % s, fixed_pos = -1) or ids32
+// (one token per row at position fixed_pos); out-of-range ids raise *bad
+hipError_t launch_flex_embed(const int64_t* ids64, const int32_t* ids32, const float* table, const float* pe,
+                             float scale, float* x, int rows, int d, int s, int pos_offset, int fixed_pos,
+                             int64_t vocab, int32_t* bad, hipStream_t stream);
+// out[b, i] = softmax(q[b, i] . k[b, :klens[b]]^T / sqrt(hd)) . v per head; q rows b * sq + i, k / v rows b * sk + j
+hipError_t launch_flex_attention(const float* q, int ldq, const float* k, const float* v, int ldk, float* out, int ldo,
+                                 int items, int sq, int sk, const int32_t* klens, int heads, int hd, int causal,
+                                 hipStream_t stream);
+hipError_t launch_flex_dec_attention(const float* kv, const int32_t* anc, int anc_stride, float* ctx, int rows,
+                                     int rows_pad, int d, int heads, int pos, hipStream_t stream);
+hipError_t launch_flex_pool(const float* x, const int32_t* lens, int pooling, float* out, int n, int s, int d,
+                            hipStream_t stream);
+hipError_t launch_flex_tile_stats(const float* logits, int ld, int rows, int vocab, float scale, float* tile_max,
+                                  float* tile_sum, int stat_rows, hipStream_t stream);
+hipError_t launch_flex_add_rows(float* x, const float* c, int rows, int d, int group, hipStream_t stream);
+
 }  // namespace smi
 
 namespace smi {
@@ -215,5 +238,28 @@ struct SampleUpdateArgs {
 };
 hipError_t launch_sample_rows(const SampleRowsArgs& a, hipStream_t stream);
 hipError_t launch_sample_update(const SampleUpdateArgs& a, hipStream_t stream);
+
+// ---- generic-dimension kernels (flex.hip): fp32 activations and weights, any model_dim / head_dim <= 256 ----
+// Y[M,N] = act(X[M,K] . W[N,K]^T + bias) (+ R); act 0 none, 1 relu; R may alias Y
+hipError_t launch_flex_linear(const float* X, int ldx, const float* W, const float* bias, float* Y, int ldy, int M,
+                              int N, int K, int act, const float* R, int ldr, hipStream_t stream);
+hipError_t launch_flex_layernorm(const float* x, const float* w, const float* b, float eps, float* y, int rows, int d,
+                                 hipStream_t stream);
+// x[r] = table[id[r]] * scale (+ pe[pos + pos_offset]); ids64 ([n, s] batch, pos = r % s, fixed_pos = -1) or ids32
+// (one token per row at position fixed_pos); out-of-range ids raise *bad
+hipError_t launch_flex_embed(const int64_t* ids64, const int32_t* ids32, const float* table, const float* pe,
+                             float scale, float* x, int rows, int d, int s, int pos_offset, int fixed_pos,
+                             int64_t vocab, int32_t* bad, hipStream_t stream);
+// out[b, i] = softmax(q[b, i] . k[b, :klens[b]]^T / sqrt(hd)) . v per head; q rows b * sq + i, k / v rows b * sk + j
+hipError_t launch_flex_attention(const float* q, int ldq, const float* k, const float* v, int ldk, float* out, int ldo,
+                                 int items, int sq, int sk, const int32_t* klens, int heads, int hd, int causal,
+                                 hipStream_t stream);
+hipError_t launch_flex_dec_attention(const float* kv, const int32_t* anc, int anc_stride, float* ctx, int rows,
+                                     int rows_pad, int d, int heads, int pos, hipStream_t stream);
+hipError_t launch_flex_pool(const float* x, const int32_t* lens, int pooling, float* out, int n, int s, int d,
+                            hipStream_t stream);
+hipError_t launch_flex_tile_stats(const float* logits, int ld, int rows, int vocab, float scale, float* tile_max,
+                                  float* tile_sum, int stat_rows, hipStream_t stream);
+hipError_t launch_flex_add_rows(float* x, const float* c, int rows, int d, int group, hipStream_t stream);
 
 }  // namespace smi

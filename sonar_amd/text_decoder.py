@@ -66,8 +66,9 @@ def _small(vocab_size: int = 32005, depth: int = 6, hidden_dim: int = 1024 * 4) 
 
 
 def _toy() -> SonarTextDecoderConfig:
-    # the reference's `toy` arch (model_dim 32, 4 heads) has head_dim 8; the engine's attention
-    # kernels are head_dim 64 only, so `toy` is accepted as a config but not runnable on the engine.
+    # the reference's `toy` arch (config.py:232-255: model_dim 32, 4 heads of 8).  The MFMA engines are shaped for
+    # head_dim 64; this arch -- and any other shape they do not tile for -- runs on the library's generic-dimension
+    # kernels (csrc/flex.hip, fp32), selected inside smi_text_decoder_create.
     return SonarTextDecoderConfig(model_dim=32, vocab_info=VocabularyInfo(size=1024), num_encoder_layers=2,
                                   num_decoder_layers=2, num_encoder_attn_heads=4, num_decoder_attn_heads=4,
                                   ffn_inner_dim=128)
@@ -143,8 +144,6 @@ class TextDecoderEngine:
                  tokenizer_special: Tuple[int, int, int, int] = (0, 1, 2, 3)):
         if cfg.activation_fn != "ReLU" or cfg.layernorm_embedding or cfg.learned_pos or cfg.no_token_positional_embeddings:
             raise NotImplementedError("decoder variant not covered by the MI355X engine")
-        if (cfg.input_dim or cfg.model_dim) != cfg.model_dim:
-            raise NotImplementedError("input_dim != model_dim is not covered by the MI355X engine")
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -208,8 +207,9 @@ class TextDecoderEngine:
             self._handle = None
 
     def _emb(self, embeddings: torch.Tensor) -> torch.Tensor:
-        if embeddings.dim() != 2 or embeddings.shape[1] != self.cfg.model_dim:
-            raise ValueError(f"embeddings must be [n, {self.cfg.model_dim}]")
+        cond = self.cfg.input_dim or self.cfg.model_dim     # width of the conditioning vector (factory.py:264)
+        if embeddings.dim() != 2 or embeddings.shape[1] != cond:
+            raise ValueError(f"embeddings must be [n, {cond}]")
         e = embeddings.to(self.device)
         if e.dtype == torch.bfloat16:
             e = _lib.cast(e, torch.float32)      # a bf16 sentence vector is exact in fp32
@@ -242,7 +242,7 @@ class TextDecoderEngine:
         if model_max > self.cfg.max_seq_len:
             raise ValueError(f"max_seq_len cannot be larger than the decoder's {self.cfg.max_seq_len}")
         if source_len is None:
-            source_len = self.cfg.model_dim
+            source_len = self.cfg.input_dim or self.cfg.model_dim   # width of the stacked sentence vectors
         gen_cap = int(max_gen_len[0] * int(source_len) + max_gen_len[1])
         if gen_cap < 1:
             raise ValueError("`max_gen_len` must be greater than or equal to 1 for the given source length")
