@@ -43,7 +43,8 @@ typedef enum smi_status {
  * accept any dtype, sonar/inference_pipelines/text.py:36-54,161-162) is served by casting: its weights are exactly
  * representable in fp16 over the normal range, its outputs are rounded to bf16 once, on the way out. */
 typedef enum smi_dtype { SMI_F32 = 0, SMI_F16 = 1, SMI_BF16 = 2 } smi_dtype;
-typedef enum smi_pooling { SMI_POOL_MEAN = 0, SMI_POOL_MAX = 1, SMI_POOL_LAST = 2 } smi_pooling;
+/* SMI_POOL_ATTENTION: the trainable pooler of sonar/nn/encoder_pooler.py:49-95 (factory.py:155-226) */
+typedef enum smi_pooling { SMI_POOL_MEAN = 0, SMI_POOL_MAX = 1, SMI_POOL_LAST = 2, SMI_POOL_ATTENTION = 3 } smi_pooling;
 
 /* A dense tensor handed to the engine at create time.  `data` may live in host
  * or device memory (`on_device`); fp32 or fp16. */
@@ -57,7 +58,7 @@ typedef struct smi_tensor {
 /* Mirrors SonarTextEncoderConfig (sonar/models/sonar_text/config.py:14-85) for
  * the fields that affect the forward pass of the `basic`/`small` archs. */
 typedef struct smi_text_encoder_config {
-  int32_t model_dim;     /* 1024; must be num_heads*64 and a multiple of 256 */
+  int32_t model_dim;     /* 1024 (see "Shapes" below) */
   int32_t num_layers;    /* 24 */
   int32_t num_heads;     /* 16 */
   int32_t ffn_inner_dim; /* 8192; multiple of 128 */
@@ -68,7 +69,18 @@ typedef struct smi_text_encoder_config {
   float ln_eps;          /* 1e-5 */
   int32_t pooling;       /* smi_pooling (config.py: pooling="mean") */
   int32_t flags;         /* SMI_ENC_* */
+  /* Attention pooling (all 0 for the released models): width of the sentence vector (config.py `embedding_dim`,
+   * 0 = model_dim) and the shape of the pooler's decoder layers (num_decoder_layers, num_decoder_attn_heads,
+   * decoder_ffn_inner_dim or ffn_inner_dim; factory.py:190-226). */
+  int32_t embedding_dim;
+  int32_t pooler_layers;
+  int32_t pooler_heads;
+  int32_t pooler_ffn_dim;
 } smi_text_encoder_config;
+/* Shapes: the MFMA engines serve model_dim = num_heads * 64 in {256, 512, 768, 1024, 2048}, ffn_inner_dim % 128 == 0,
+ * static pooling -- the released models.  EVERY OTHER shape the reference's factory accepts (any model_dim divisible by
+ * num_heads with head_dim <= 256, attention pooling, the flags below other than FP16_RESIDUAL) runs on the library's
+ * generic-dimension fp32 kernels (csrc/flex.hip), chosen inside smi_text_encoder_create. */
 
 /* smi_text_encoder_config.flags */
 /* Keep the residual stream in fp16 instead of fp32.  The reference's fp16 model does exactly this
@@ -76,6 +88,14 @@ typedef struct smi_text_encoder_config {
  * the engine's default fp32 stream costs 2x the residual traffic and buys ~100x margin on the 1e-3
  * parity bound.  With the flag each residual add is one fp32 add rounded once to fp16. */
 #define SMI_ENC_FP16_RESIDUAL 1
+/* config.py `normalize_before`: the encoder stack ends in its own LayerNorm (StandardTransformerEncoder norm_order PRE,
+ * factory.py:107-109, weights encoder_layer_norm_*) and the pooler's layers are pre-norm with a final LayerNorm. */
+#define SMI_ENC_NORMALIZE_BEFORE 2
+/* config.py `layernorm_embedding`: LayerNorm on the frontend output (weights embed_layer_norm_*). */
+#define SMI_ENC_LAYERNORM_EMBEDDING 4
+/* config.py `no_token_positional_embeddings`: pos_table is absent (data NULL).  (`learned_pos` needs no flag: the caller
+ * passes encoder_frontend.pos_encoder.weight as pos_table with pos_offset 0.) */
+#define SMI_ENC_NO_POSITIONS 8
 
 /* Per-layer parameters, names as produced by the reference's checkpoint
  * conversion (sonar/models/sonar_text/handler.py:71-82).  Linear weights are
@@ -87,11 +107,32 @@ typedef struct smi_text_encoder_layer {
   smi_tensor ffn_inner_w, ffn_inner_b, ffn_out_w, ffn_out_b;
 } smi_text_encoder_layer;
 
+/* One decoder layer of the attention pooler (factory.py:199-218).  Its self-attention sees ONE token, so only the
+ * value and output projections matter (softmax over one key is 1); the cross-attention reads the encoder output:
+ * its k / v projections are [embedding_dim, model_dim]. */
+typedef struct smi_text_pooler_layer {
+  smi_tensor self_attn_layer_norm_w, self_attn_layer_norm_b;
+  smi_tensor self_v_w, self_v_b, self_out_w, self_out_b;
+  smi_tensor cross_layer_norm_w, cross_layer_norm_b;
+  smi_tensor cross_q_w, cross_q_b, cross_k_w, cross_k_b, cross_v_w, cross_v_b, cross_out_w, cross_out_b;
+  smi_tensor ffn_layer_norm_w, ffn_layer_norm_b;
+  smi_tensor ffn_inner_w, ffn_inner_b, ffn_out_w, ffn_out_b;
+} smi_text_pooler_layer;
+
 typedef struct smi_text_encoder_weights {
   smi_tensor embed;     /* encoder_frontend.embed.weight [vocab, model_dim] */
-  smi_tensor pos_table; /* sinusoidal table [max_seq_len + pos_offset, model_dim] fp32 */
+  smi_tensor pos_table; /* position table [max_seq_len + pos_offset, model_dim] fp32 (sinusoidal or learned); data NULL =
+                         * no_token_positional_embeddings */
   smi_tensor final_layer_norm_w, final_layer_norm_b; /* model-level layer_norm (factory.py:117) */
   const smi_text_encoder_layer* layers;              /* num_layers entries */
+  /* the rest is read only when the configuration asks for it */
+  smi_tensor encoder_layer_norm_w, encoder_layer_norm_b; /* encoder.layer_norm (SMI_ENC_NORMALIZE_BEFORE) */
+  smi_tensor embed_layer_norm_w, embed_layer_norm_b;     /* encoder_frontend.layer_norm (SMI_ENC_LAYERNORM_EMBEDDING) */
+  smi_tensor pooler_query;  /* [embedding_dim] fp32: pooler.decoder_frontend.embed.weight[bos] * sqrt(embedding_dim) +
+                             * PE[0] -- the pooler's one input token after its frontend (encoder_pooler.py:78-92) */
+  const smi_text_pooler_layer* pooler;                        /* pooler_layers entries */
+  smi_tensor pooler_layer_norm_w, pooler_layer_norm_b;   /* pooler.decoder.layer_norm (SMI_ENC_NORMALIZE_BEFORE) */
+  smi_tensor pooler_proj_w, pooler_proj_b;               /* pooler.projection_out [embedding_dim, embedding_dim] */
 } smi_text_encoder_weights;
 
 typedef struct smi_text_encoder smi_text_encoder; /* opaque */
@@ -116,7 +157,7 @@ void smi_text_encoder_destroy(smi_text_encoder* enc);
 /* ids:      device int64 [n, s] right-padded token ids (SequenceBatch.seqs)
  * seq_lens: HOST int32 [n] valid lengths, or NULL when the batch is not ragged
  *           (PaddingMask is None, sonar/inference_pipelines/utils.py:18-21)
- * out_emb:  device [n, model_dim] sentence_embeddings, out_dtype
+ * out_emb:  device [n, embedding_dim or model_dim] sentence_embeddings, out_dtype
  * out_encoded: optional device [n, s, model_dim] encoded_seqs (out_dtype), pads zeroed; may be NULL
  * stream:   hipStream_t (NULL = default stream) */
 int smi_text_encoder_forward(smi_text_encoder* enc, const int64_t* ids, const int32_t* seq_lens,
@@ -161,14 +202,15 @@ int smi_text_encoder_read_profile(smi_text_encoder* enc, double* ms, int64_t* la
  * BeamSearchSeq2SeqGenerator as driven by EmbeddingToTextModelPipeline.predict
  * (sonar/inference_pipelines/text.py:305-346). */
 typedef struct smi_text_decoder_config {
-  int32_t model_dim;     /* 1024 = num_heads*64 */
+  int32_t model_dim;     /* 1024; num_heads * 64 in {256, 512, 768, 1024, 2048} runs on the MFMA engines, any other
+                          * multiple of num_heads with head_dim <= 256 (e.g. the `toy` arch) on the generic fp32 kernels */
   int32_t num_layers;    /* 24 */
   int32_t num_heads;     /* 16 */
   int32_t ffn_inner_dim; /* 8192 */
   int64_t vocab_size;    /* 256206 */
   int32_t max_seq_len;   /* 512: longest target sequence incl. prompt (config.py:197-219) */
   int32_t pos_offset;    /* 2 = model pad_idx + 1 (_legacy_pad_idx, factory.py:248-252) */
-  int32_t input_dim;     /* conditioning vector dimension (= model_dim) */
+  int32_t input_dim;     /* conditioning vector dimension (config.py input_dim; model_dim when unset) */
   float embed_scale;     /* sqrt(model_dim) */
   float ln_eps;          /* 1e-5 */
   int32_t pad_idx, unk_idx, bos_idx, eos_idx; /* TOKENIZER ids: 0, 1, 2, 3 */

@@ -46,6 +46,15 @@ class OracleTextEncoderConfig:
     no_scale_embedding: bool = False
     pooling: str = "mean"
     ln_eps: float = 1e-5
+    # the less common builder options (config.py:54-85) and the attention pooler (factory.py:155-226)
+    normalize_before: bool = False      # encoder stack norm order PRE -> its own final LayerNorm; pooler layers pre-norm
+    layernorm_embedding: bool = False
+    learned_pos: bool = False
+    no_token_positional_embeddings: bool = False
+    embedding_dim: Optional[int] = None # sentence-vector width with pooling == "attention"
+    pooler_layers: int = 0              # config.num_decoder_layers
+    pooler_heads: int = 0               # config.num_decoder_attn_heads
+    pooler_ffn_dim: int = 0             # config.decoder_ffn_inner_dim or ffn_inner_dim
 
     @property
     def pos_offset(self) -> int:
@@ -56,6 +65,10 @@ class OracleTextEncoderConfig:
     @property
     def model_max_seq_len(self) -> int:
         return self.max_seq_len + (self.pad_idx + 1 if self.from_fairseq else 0)
+
+    @property
+    def edim(self) -> int:
+        return self.embedding_dim or self.model_dim
 
 
 def sinusoidal_table(num_positions: int, dim: int) -> torch.Tensor:
@@ -86,6 +99,25 @@ def param_names(cfg: OracleTextEncoderConfig):
             names += [p + lin + ".weight", p + lin + ".bias"]
         for ln in ("self_attn_layer_norm", "ffn_layer_norm"):
             names += [p + ln + ".weight", p + ln + ".bias"]
+    if cfg.normalize_before:
+        names += ["encoder.layer_norm.weight", "encoder.layer_norm.bias"]
+    if cfg.layernorm_embedding:
+        names += ["encoder_frontend.layer_norm.weight", "encoder_frontend.layer_norm.bias"]
+    if cfg.learned_pos and not cfg.no_token_positional_embeddings:
+        names += ["encoder_frontend.pos_encoder.weight"]
+    if cfg.pooling == "attention":
+        names += ["pooler.decoder_frontend.embed.weight", "pooler.projection_out.weight", "pooler.projection_out.bias"]
+        if cfg.normalize_before:
+            names += ["pooler.decoder.layer_norm.weight", "pooler.decoder.layer_norm.bias"]
+        for i in range(cfg.pooler_layers):
+            p = f"pooler.decoder.layers.{i}."
+            for att in ("self_attn", "encoder_decoder_attn"):
+                for lin in ("q_proj", "k_proj", "v_proj", "output_proj"):
+                    names += [p + f"{att}.{lin}.weight", p + f"{att}.{lin}.bias"]
+            for lin in ("ffn.inner_proj", "ffn.output_proj"):
+                names += [p + lin + ".weight", p + lin + ".bias"]
+            for ln in ("self_attn_layer_norm", "encoder_decoder_attn_layer_norm", "ffn_layer_norm"):
+                names += [p + ln + ".weight", p + ln + ".bias"]
     return names
 
 
@@ -93,6 +125,22 @@ def param_shape(cfg: OracleTextEncoderConfig, name: str) -> Tuple[int, ...]:
     d, f = cfg.model_dim, cfg.ffn_inner_dim
     if name == "encoder_frontend.embed.weight":
         return (cfg.vocab_size, d)
+    if name == "encoder_frontend.pos_encoder.weight":
+        return (cfg.model_max_seq_len, d)
+    if name.startswith("pooler."):
+        e, pf = cfg.edim, cfg.pooler_ffn_dim
+        w = name.endswith("weight")
+        if name == "pooler.decoder_frontend.embed.weight":
+            return (1, e)
+        if "layer_norm" in name:
+            return (e,)
+        if "ffn.inner_proj" in name:
+            return (pf, e) if w else (pf,)
+        if "ffn.output_proj" in name:
+            return (e, pf) if w else (e,)
+        if "encoder_decoder_attn.k_proj" in name or "encoder_decoder_attn.v_proj" in name:
+            return (e, d) if w else (e,)     # kv_dim = model_dim (factory.py:207-211)
+        return (e, e) if w else (e,)
     if name.endswith("layer_norm.weight") or name.endswith("layer_norm.bias"):
         return (d,)
     if "ffn.inner_proj" in name:
@@ -118,6 +166,58 @@ def make_synthetic_params(cfg: OracleTextEncoderConfig, seed: int = 1234,
 
 def _layer_norm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _mha_generic(params, prefix, q_in, kv_in, heads, key_mask):
+    """StandardMultiheadAttention(model_dim = q_in width, kv_dim = kv_in width): q_in [N, Tq, E], kv_in [N, Tk, Dk],
+    key_mask [N, Tk] True = padding."""
+    n, tq, e = q_in.shape
+    tk = kv_in.shape[1]
+    dh = e // heads
+    q = F.linear(q_in, params[prefix + "q_proj.weight"], params[prefix + "q_proj.bias"]).view(n, tq, heads, dh).transpose(1, 2)
+    k = F.linear(kv_in, params[prefix + "k_proj.weight"], params[prefix + "k_proj.bias"]).view(n, tk, heads, dh).transpose(1, 2)
+    v = F.linear(kv_in, params[prefix + "v_proj.weight"], params[prefix + "v_proj.bias"]).view(n, tk, heads, dh).transpose(1, 2)
+    att = torch.matmul(q, k.transpose(-1, -2)) * dh ** -0.5
+    if key_mask is not None:
+        att = att.masked_fill(key_mask[:, None, None, :], -torch.inf)
+    y = torch.matmul(torch.softmax(att, dim=-1), v).transpose(1, 2).reshape(n, tq, e)
+    return F.linear(y, params[prefix + "output_proj.weight"], params[prefix + "output_proj.bias"])
+
+
+def attention_pooling(params, cfg: OracleTextEncoderConfig, enc: torch.Tensor, seq_lens: Optional[torch.Tensor]) -> torch.Tensor:
+    """AttentionEncoderOutputPooler.__call__ (sonar/nn/encoder_pooler.py:72-95) as SonarTextEncoderFactory builds it
+    (factory.py:155-226): one BOS token (bos_idx 0 of a 1-row embedding) through TransformerEmbeddingFrontend
+    (x sqrt(embedding_dim), sinusoidal position 0, no legacy offset), `pooler_layers` StandardTransformerDecoderLayers
+    (self-attention on that one token, cross-attention to the encoder output with kv_dim = model_dim, FFN) in the model's
+    norm order, the decoder's final LayerNorm when pre-norm, projection_out.  PARITY UNPINNED against the reference
+    (fairseq2 is not installable here); restated from the cited source."""
+    n, s, _ = enc.shape
+    e = cfg.edim
+    x = params["pooler.decoder_frontend.embed.weight"][0].float() * math.sqrt(e) + sinusoidal_table(1, e)[0]
+    x = x.expand(n, 1, e).clone()
+    key_mask = None if seq_lens is None else torch.arange(s).unsqueeze(0) >= seq_lens.unsqueeze(1)
+    pre = cfg.normalize_before
+    for i in range(cfg.pooler_layers):
+        p = f"pooler.decoder.layers.{i}."
+        ln = lambda name, t: _layer_norm(t, params[p + name + ".weight"], params[p + name + ".bias"], cfg.ln_eps)
+        if pre:
+            h = ln("self_attn_layer_norm", x)
+            x = x + _mha_generic(params, p + "self_attn.", h, h, cfg.pooler_heads, None)
+            h = ln("encoder_decoder_attn_layer_norm", x)
+            x = x + _mha_generic(params, p + "encoder_decoder_attn.", h, enc, cfg.pooler_heads, key_mask)
+            h = ln("ffn_layer_norm", x)
+            x = x + F.linear(F.relu(F.linear(h, params[p + "ffn.inner_proj.weight"], params[p + "ffn.inner_proj.bias"])),
+                             params[p + "ffn.output_proj.weight"], params[p + "ffn.output_proj.bias"])
+        else:
+            x = ln("self_attn_layer_norm", x + _mha_generic(params, p + "self_attn.", x, x, cfg.pooler_heads, None))
+            x = ln("encoder_decoder_attn_layer_norm",
+                   x + _mha_generic(params, p + "encoder_decoder_attn.", x, enc, cfg.pooler_heads, key_mask))
+            x = ln("ffn_layer_norm",
+                   x + F.linear(F.relu(F.linear(x, params[p + "ffn.inner_proj.weight"], params[p + "ffn.inner_proj.bias"])),
+                                params[p + "ffn.output_proj.weight"], params[p + "ffn.output_proj.bias"]))
+    if pre:
+        x = _layer_norm(x, params["pooler.decoder.layer_norm.weight"], params["pooler.decoder.layer_norm.bias"], cfg.ln_eps)
+    return F.linear(x, params["pooler.projection_out.weight"], params["pooler.projection_out.bias"]).squeeze(1)
 
 
 def static_pooling(seqs: torch.Tensor, seq_lens: Optional[torch.Tensor], pooling: str) -> torch.Tensor:
@@ -163,8 +263,14 @@ def text_encoder_forward(params: Dict[str, torch.Tensor], cfg: OracleTextEncoder
     # frontend: TransformerEmbeddingFrontend (factory.py:73-100): E[tok]*sqrt(d) + PE, no LN
     scale = 1.0 if cfg.no_scale_embedding else math.sqrt(d)
     x = params["encoder_frontend.embed.weight"][ids].float() * scale
-    pe = sinusoidal_table(cfg.pos_offset + s, d)[cfg.pos_offset:]
-    x = x + pe.unsqueeze(0)
+    if not cfg.no_token_positional_embeddings:
+        if cfg.learned_pos:   # LearnedPositionEncoder: rows 0.. of its table, no legacy offset (factory.py:81-85)
+            pe = params["encoder_frontend.pos_encoder.weight"][:s].float()
+        else:
+            pe = sinusoidal_table(cfg.pos_offset + s, d)[cfg.pos_offset:]
+        x = x + pe.unsqueeze(0)
+    if cfg.layernorm_embedding:  # TransformerEmbeddingFrontend(layer_norm=True), factory.py:94-100
+        x = _layer_norm(x, params["encoder_frontend.layer_norm.weight"], params["encoder_frontend.layer_norm.bias"], cfg.ln_eps)
     key_mask = None
     if seq_lens is not None:
         key_mask = torch.arange(s).unsqueeze(0) >= seq_lens.unsqueeze(1)  # True = pad
@@ -193,9 +299,14 @@ def text_encoder_forward(params: Dict[str, torch.Tensor], cfg: OracleTextEncoder
         y = F.relu(y)  # factory.py:143-153
         y = F.linear(y, params[p + "ffn.output_proj.weight"], params[p + "ffn.output_proj.bias"])
         x = r + y
+    if cfg.normalize_before:  # StandardTransformerEncoder(norm_order=PRE) ends in its own LayerNorm (factory.py:107-109)
+        x = _layer_norm(x, params["encoder.layer_norm.weight"], params["encoder.layer_norm.bias"], cfg.ln_eps)
     # model-level LayerNorm (factory.py:117, model.py:136-137)
     x = _layer_norm(x, params["layer_norm.weight"], params["layer_norm.bias"], cfg.ln_eps)
-    emb = static_pooling(x, seq_lens, cfg.pooling)
+    if cfg.pooling == "attention":
+        emb = attention_pooling(params, cfg, x, seq_lens)
+    else:
+        emb = static_pooling(x, seq_lens, cfg.pooling)
     return x, emb
 
 

@@ -17,10 +17,13 @@ LIB_PATH = Path(os.environ["SMI_LIB"]).resolve() if os.environ.get("SMI_LIB") el
 
 SMI_OK = 0
 SMI_F32, SMI_F16, SMI_BF16 = 0, 1, 2
-SMI_POOL = {"mean": 0, "max": 1, "last": 2}
+SMI_POOL = {"mean": 0, "max": 1, "last": 2, "attention": 3}
 SMI_MARGIN = {"ratio": 0, "distance": 1, "cosine": 2}
 SMI_GEMM_IN_TM, SMI_GEMM_OUT_TM = 1 << 12, 1 << 13
 SMI_ENC_FP16_RESIDUAL = 1
+SMI_ENC_NORMALIZE_BEFORE = 2
+SMI_ENC_LAYERNORM_EMBEDDING = 4
+SMI_ENC_NO_POSITIONS = 8
 PROF_SLOTS = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_ffn1", "gemm_ffn2", "ln_pool"]
 STATUS_NAMES = {
     0: "SMI_OK",
@@ -60,6 +63,10 @@ class smi_text_encoder_config(C.Structure):
         ("ln_eps", C.c_float),
         ("pooling", C.c_int32),
         ("flags", C.c_int32),
+        ("embedding_dim", C.c_int32),
+        ("pooler_layers", C.c_int32),
+        ("pooler_heads", C.c_int32),
+        ("pooler_ffn_dim", C.c_int32),
     ]
 
 
@@ -75,6 +82,17 @@ class smi_text_encoder_layer(C.Structure):
     _fields_ = [(n, smi_tensor) for n in _LAYER_FIELDS]
 
 
+_TEXT_POOLER_LAYER_FIELDS = [
+    "self_attn_layer_norm_w", "self_attn_layer_norm_b", "self_v_w", "self_v_b", "self_out_w", "self_out_b",
+    "cross_layer_norm_w", "cross_layer_norm_b", "cross_q_w", "cross_q_b", "cross_k_w", "cross_k_b", "cross_v_w", "cross_v_b",
+    "cross_out_w", "cross_out_b", "ffn_layer_norm_w", "ffn_layer_norm_b", "ffn_inner_w", "ffn_inner_b", "ffn_out_w", "ffn_out_b",
+]
+
+
+class smi_text_pooler_layer(C.Structure):
+    _fields_ = [(n, smi_tensor) for n in _TEXT_POOLER_LAYER_FIELDS]
+
+
 class smi_text_encoder_weights(C.Structure):
     _fields_ = [
         ("embed", smi_tensor),
@@ -82,6 +100,16 @@ class smi_text_encoder_weights(C.Structure):
         ("final_layer_norm_w", smi_tensor),
         ("final_layer_norm_b", smi_tensor),
         ("layers", C.POINTER(smi_text_encoder_layer)),
+        ("encoder_layer_norm_w", smi_tensor),
+        ("encoder_layer_norm_b", smi_tensor),
+        ("embed_layer_norm_w", smi_tensor),
+        ("embed_layer_norm_b", smi_tensor),
+        ("pooler_query", smi_tensor),
+        ("pooler", C.POINTER(smi_text_pooler_layer)),
+        ("pooler_layer_norm_w", smi_tensor),
+        ("pooler_layer_norm_b", smi_tensor),
+        ("pooler_proj_w", smi_tensor),
+        ("pooler_proj_b", smi_tensor),
     ]
 
 

@@ -80,6 +80,7 @@ constexpr int kCuRing = 8;
 
 struct smi_text_encoder {
   smi_text_encoder_config cfg;
+  smi_host::FlexEncoder* flex = nullptr;  // set: the model runs on the generic-dimension kernels (flex_encoder.hip)
   DevBuf embed, pos, lnf_w, lnf_b;
   std::vector<Layer> layers;
   // workspace (capacity in packed+padded token rows)
@@ -109,6 +110,7 @@ struct smi_text_encoder {
   size_t ev_used = 0;
 
   ~smi_text_encoder() {
+    if (flex) smi_host::flex_encoder_destroy(flex);
     for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
     if (bad_ids) (void)hipHostFree(bad_ids);
     for (int i = 0; i < kCuRing; ++i) {
@@ -219,6 +221,16 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
                             int64_t max_tokens_hint, smi_text_encoder** out) {
   if (!cfg || !w || !out) return fail(SMI_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
+  if (flex_encoder_wanted(*cfg)) {  // a shape / option outside the MFMA engines' tiling: generic-dimension kernels
+    if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+    FlexEncoder* fe = nullptr;
+    if (int rc = flex_encoder_create(cfg, w, &fe)) return rc;
+    smi_text_encoder* e = new smi_text_encoder();
+    e->cfg = *cfg;
+    e->flex = fe;
+    *out = e;
+    return SMI_OK;
+  }
   if (int rc = check_cfg(*cfg)) return rc;
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->num_layers > 0 && !w->layers) return fail(SMI_ERR_INVALID_ARG, "null layers");
@@ -309,6 +321,7 @@ void smi_text_encoder_destroy(smi_text_encoder* enc) {
 
 int64_t smi_text_encoder_device_bytes(const smi_text_encoder* e) {
   if (!e) return 0;
+  if (e->flex) return flex_encoder_bytes(e->flex);
   return e->weight_bytes + (int64_t)(e->x.bytes + e->h.bytes + e->qkv.bytes + e->ctx.bytes + e->ffn.bytes + e->parts.bytes);
 }
 
@@ -331,6 +344,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   }
   // (the out-of-vocabulary flag is reported -- and cleared -- only by smi_text_encoder_status(), after a stream
   //  synchronisation: testing it here, unsynchronised, refused a later VALID batch at a timing-dependent point)
+  if (e->flex) return flex_encoder_forward(e->flex, ids, seq_lens, n, s, out_emb, out_encoded, out_dtype, e->bad_ids_dev, stream);
 
   if (int rc = ensure_cu(e, n)) return rc;
   const int slot = e->cu_next;

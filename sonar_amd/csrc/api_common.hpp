@@ -96,4 +96,13 @@ inline int to_tile_major(DevBuf& w, int rows, int K) {
   return SMI_OK;
 }
 
+// Text encoder on the generic-dimension kernels (flex_encoder.hip): configurations the MFMA engines do not tile for
+struct FlexEncoder;
+bool flex_encoder_wanted(const smi_text_encoder_config& c);
+int flex_encoder_create(const smi_text_encoder_config* cfg, const smi_text_encoder_weights* w, FlexEncoder** out);
+void flex_encoder_destroy(FlexEncoder* e);
+int64_t flex_encoder_bytes(const FlexEncoder* e);
+int flex_encoder_forward(FlexEncoder* e, const int64_t* ids, const int32_t* seq_lens, int n, int s, void* out_emb,
+                         void* out_encoded, int out_dtype, int32_t* bad_ids_dev, hipStream_t stream);
+
 }  // namespace smi_host

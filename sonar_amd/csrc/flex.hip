@@ -300,4 +300,27 @@ hipError_t launch_flex_add_rows(float* x, const float* c, int rows, int d, int g
   return hipGetLastError();
 }
 
+// encoded_seqs output: out[b, j] = x[b, j] for valid positions, zeros for padding; fp32 or fp16
+__global__ void flex_store_encoded_kernel(const float* __restrict__ x, const int32_t* __restrict__ lens, int s, int d,
+                                          void* __restrict__ out, int out_f16, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t row = i / d;
+  const int b = (int)(row / s), j = (int)(row % s);
+  const float v = j < lens[b] ? x[i] : 0.f;
+  if (out_f16)
+    ((f16*)out)[i] = (f16)v;
+  else
+    ((float*)out)[i] = v;
+}
+
+hipError_t launch_flex_store_encoded(const float* x, const int32_t* lens, int n, int s, int d, void* out, bool out_f16,
+                                     hipStream_t stream) {
+  const size_t total = (size_t)n * s * d;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(flex_store_encoded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, lens, s, d, out,
+                     out_f16 ? 1 : 0, total);
+  return hipGetLastError();
+}
+
 }  // namespace smi

@@ -41,6 +41,8 @@ hipError_t launch_flex_pool(const float* x, const int32_t* lens, int pooling, fl
 hipError_t launch_flex_tile_stats(const float* logits, int ld, int rows, int vocab, float scale, float* tile_max,
                                   float* tile_sum, int stat_rows, hipStream_t stream);
 hipError_t launch_flex_add_rows(float* x, const float* c, int rows, int d, int group, hipStream_t stream);
+hipError_t launch_flex_store_encoded(const float* x, const int32_t* lens, int n, int s, int d, void* out, bool out_f16,
+                                     hipStream_t stream);
 
 }  // namespace smi
 
@@ -261,5 +263,7 @@ hipError_t launch_flex_pool(const float* x, const int32_t* lens, int pooling, fl
 hipError_t launch_flex_tile_stats(const float* logits, int ld, int rows, int vocab, float scale, float* tile_max,
                                   float* tile_sum, int stat_rows, hipStream_t stream);
 hipError_t launch_flex_add_rows(float* x, const float* c, int rows, int d, int group, hipStream_t stream);
+hipError_t launch_flex_store_encoded(const float* x, const int32_t* lens, int n, int s, int d, void* out, bool out_f16,
+                                     hipStream_t stream);
 
 }  // namespace smi

@@ -94,18 +94,20 @@ def get_text_encoder_config(arch: str) -> SonarTextEncoderConfig:
 
 
 def check_supported(cfg: SonarTextEncoderConfig) -> None:
-    """The engine covers the configuration space the released SONAR text encoders use."""
+    """What the library runs: the released models' shapes on the MFMA engines, every other shape / option of the
+    reference's factory (any model_dim divisible by the head count with head_dim <= 256, attention pooling with
+    embedding_dim != model_dim, normalize_before, layernorm_embedding, learned / no positions) on its
+    generic-dimension kernels (csrc/flex.hip) -- chosen inside smi_text_encoder_create.  Not covered: activations
+    other than ReLU."""
     bad = []
-    if cfg.embedding_dim not in (None, cfg.model_dim) or cfg.pooling == "attention":
-        bad.append("attention pooling / embedding_dim != model_dim")
     if cfg.activation_fn != "ReLU":
         bad.append(f"activation_fn={cfg.activation_fn}")
-    if cfg.layernorm_embedding:
-        bad.append("layernorm_embedding")
-    if cfg.learned_pos or cfg.no_token_positional_embeddings:
-        bad.append("non-sinusoidal positions")
-    if cfg.pooling not in ("mean", "max", "last"):
+    if cfg.pooling not in ("mean", "max", "last", "attention"):
         bad.append(f"pooling={cfg.pooling}")
+    if cfg.embedding_dim not in (None, cfg.model_dim) and cfg.pooling != "attention":
+        bad.append("embedding_dim != model_dim without attention pooling")
+    if cfg.model_dim % max(cfg.num_encoder_attn_heads, 1) or cfg.model_dim // max(cfg.num_encoder_attn_heads, 1) > 256:
+        bad.append("model_dim must be a multiple of the head count with head_dim <= 256")
     if bad:
         raise NotImplementedError("not covered by the MI355X engine: " + ", ".join(bad))
 
@@ -199,13 +201,27 @@ class TextEncoderEngine:
         self.device = torch.device("cuda", idx)
         _lib.check(self.lib.smi_init(idx))
         d = cfg.model_dim
+        attn_pool = cfg.pooling == "attention"
+        self.embedding_dim = (cfg.embedding_dim or d) if attn_pool else d
+        flags = _lib.SMI_ENC_FP16_RESIDUAL if fp16_residual else 0
+        if cfg.normalize_before:
+            flags |= _lib.SMI_ENC_NORMALIZE_BEFORE
+        if cfg.layernorm_embedding:
+            flags |= _lib.SMI_ENC_LAYERNORM_EMBEDDING
+        if cfg.no_token_positional_embeddings:
+            flags |= _lib.SMI_ENC_NO_POSITIONS
+        # LearnedPositionEncoder indexes its table from 0; the sinusoidal encoder keeps fairseq's pad_idx + 1 offset
+        pos_offset = 0 if cfg.learned_pos else cfg.pos_offset
         ccfg = _lib.smi_text_encoder_config(
             model_dim=d, num_layers=cfg.num_encoder_layers, num_heads=cfg.num_encoder_attn_heads,
             ffn_inner_dim=cfg.ffn_inner_dim, vocab_size=cfg.vocab_info.size,
-            max_seq_len=cfg.model_max_seq_len, pos_offset=cfg.pos_offset,
+            max_seq_len=cfg.model_max_seq_len, pos_offset=pos_offset,
             embed_scale=1.0 if cfg.no_scale_embedding else math.sqrt(d), ln_eps=1e-5,
-            pooling=_lib.SMI_POOL[cfg.pooling],
-            flags=_lib.SMI_ENC_FP16_RESIDUAL if fp16_residual else 0)
+            pooling=_lib.SMI_POOL[cfg.pooling], flags=flags,
+            embedding_dim=self.embedding_dim if attn_pool else 0,
+            pooler_layers=cfg.num_decoder_layers if attn_pool else 0,
+            pooler_heads=cfg.num_decoder_attn_heads if attn_pool else 0,
+            pooler_ffn_dim=(cfg.decoder_ffn_inner_dim or cfg.ffn_inner_dim) if attn_pool else 0)
         keep: List[torch.Tensor] = []
         sd = state_dict
 
@@ -230,11 +246,49 @@ class TextEncoderEngine:
             L.ffn_out_w, L.ffn_out_b = tv(p + "ffn.output_proj.weight"), tv(p + "ffn.output_proj.bias")
         w = _lib.smi_text_encoder_weights()
         w.embed = tv("encoder_frontend.embed.weight")
-        pos = sinusoidal_table(cfg.model_max_seq_len + cfg.pos_offset, d)
-        w.pos_table = _tensor_view(pos, keep)
+        if cfg.no_token_positional_embeddings:
+            pass                                         # pos_table.data stays NULL (SMI_ENC_NO_POSITIONS)
+        elif cfg.learned_pos:
+            w.pos_table = tv("encoder_frontend.pos_encoder.weight")
+        else:
+            w.pos_table = _tensor_view(sinusoidal_table(cfg.model_max_seq_len + cfg.pos_offset, d), keep)
         w.final_layer_norm_w = tv("layer_norm.weight")
         w.final_layer_norm_b = tv("layer_norm.bias")
         w.layers = C.cast(layers, C.POINTER(_lib.smi_text_encoder_layer))
+        if cfg.normalize_before:
+            w.encoder_layer_norm_w, w.encoder_layer_norm_b = tv("encoder.layer_norm.weight"), tv("encoder.layer_norm.bias")
+        if cfg.layernorm_embedding:
+            w.embed_layer_norm_w = tv("encoder_frontend.layer_norm.weight")
+            w.embed_layer_norm_b = tv("encoder_frontend.layer_norm.bias")
+        if attn_pool:
+            # AttentionEncoderOutputPooler (sonar/nn/encoder_pooler.py:49-95, factory.py:155-226): the pooler's one
+            # input token after its frontend -- embed.weight[bos = 0] * sqrt(E) + the sinusoidal encoding of position 0
+            e_dim = self.embedding_dim
+            q0 = sd["pooler.decoder_frontend.embed.weight"][0].detach().float().cpu() * math.sqrt(e_dim) \
+                + sinusoidal_table(1, e_dim)[0]
+            w.pooler_query = _tensor_view(q0, keep)
+            w.pooler_proj_w, w.pooler_proj_b = tv("pooler.projection_out.weight"), tv("pooler.projection_out.bias")
+            if cfg.normalize_before:
+                w.pooler_layer_norm_w = tv("pooler.decoder.layer_norm.weight")
+                w.pooler_layer_norm_b = tv("pooler.decoder.layer_norm.bias")
+            pl = (_lib.smi_text_pooler_layer * max(cfg.num_decoder_layers, 1))()
+            for i in range(cfg.num_decoder_layers):
+                p = f"pooler.decoder.layers.{i}."
+                P = pl[i]
+                P.self_attn_layer_norm_w, P.self_attn_layer_norm_b = tv(p + "self_attn_layer_norm.weight"), tv(p + "self_attn_layer_norm.bias")
+                P.self_v_w, P.self_v_b = tv(p + "self_attn.v_proj.weight"), tv(p + "self_attn.v_proj.bias")
+                P.self_out_w, P.self_out_b = tv(p + "self_attn.output_proj.weight"), tv(p + "self_attn.output_proj.bias")
+                P.cross_layer_norm_w = tv(p + "encoder_decoder_attn_layer_norm.weight")
+                P.cross_layer_norm_b = tv(p + "encoder_decoder_attn_layer_norm.bias")
+                for nm in ("q", "k", "v"):
+                    setattr(P, f"cross_{nm}_w", tv(p + f"encoder_decoder_attn.{nm}_proj.weight"))
+                    setattr(P, f"cross_{nm}_b", tv(p + f"encoder_decoder_attn.{nm}_proj.bias"))
+                P.cross_out_w = tv(p + "encoder_decoder_attn.output_proj.weight")
+                P.cross_out_b = tv(p + "encoder_decoder_attn.output_proj.bias")
+                P.ffn_layer_norm_w, P.ffn_layer_norm_b = tv(p + "ffn_layer_norm.weight"), tv(p + "ffn_layer_norm.bias")
+                P.ffn_inner_w, P.ffn_inner_b = tv(p + "ffn.inner_proj.weight"), tv(p + "ffn.inner_proj.bias")
+                P.ffn_out_w, P.ffn_out_b = tv(p + "ffn.output_proj.weight"), tv(p + "ffn.output_proj.bias")
+            w.pooler = C.cast(pl, C.POINTER(_lib.smi_text_pooler_layer))
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.smi_text_encoder_create(C.byref(ccfg), C.byref(w), max_tokens_hint,
@@ -295,7 +349,7 @@ class TextEncoderEngine:
         want = out_dtype
         if out_dtype == torch.bfloat16:  # bf16 exists at the boundary only: fp32 out of the engine, rounded once
             out_dtype = torch.float32
-        emb = torch.empty((n, self.cfg.model_dim), dtype=out_dtype, device=self.device)
+        emb = torch.empty((n, self.embedding_dim), dtype=out_dtype, device=self.device)
         enc = torch.empty((n, s, self.cfg.model_dim), dtype=out_dtype, device=self.device) if return_encoded else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.smi_text_encoder_forward(

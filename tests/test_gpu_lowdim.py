@@ -107,3 +107,108 @@ def test_input_dim_differs_from_model_dim_on_the_mfma_path():
         assert (got - ref).abs().max().item() <= 1.5e-2 * ref.abs().max().item()
         with pytest.raises(ValueError):
             eng.logits(torch.randn(5, 256).cuda(), prev.cuda())
+
+
+def _enc_cfgs(**kw):
+    """(oracle config, engine config) for one SonarTextEncoderConfig variant."""
+    from oracle.text_encoder import OracleTextEncoderConfig
+    from sonar_amd.text_encoder import SonarTextEncoderConfig, VocabularyInfo
+
+    d, heads, ffn, layers, vocab = kw.pop("d"), kw.pop("heads"), kw.pop("ffn"), kw.pop("layers"), kw.pop("vocab")
+    pooling = kw.pop("pooling", "mean")
+    embedding_dim = kw.pop("embedding_dim", None)
+    dec_layers, dec_heads, dec_ffn = kw.pop("dec_layers", 0), kw.pop("dec_heads", 0), kw.pop("dec_ffn", None)
+    o = OracleTextEncoderConfig(model_dim=d, num_layers=layers, num_heads=heads, ffn_inner_dim=ffn, vocab_size=vocab,
+                                pooling=pooling, embedding_dim=embedding_dim, pooler_layers=dec_layers, pooler_heads=dec_heads,
+                                pooler_ffn_dim=dec_ffn or ffn, **kw)
+    c = SonarTextEncoderConfig(model_dim=d, num_encoder_layers=layers, num_decoder_layers=dec_layers,
+                               num_encoder_attn_heads=heads, num_decoder_attn_heads=dec_heads or heads, ffn_inner_dim=ffn,
+                               decoder_ffn_inner_dim=dec_ffn, vocab_info=VocabularyInfo(size=vocab), pooling=pooling,
+                               embedding_dim=embedding_dim, _from_fairseq=True, **kw)
+    return o, c
+
+
+def _run_encoder(o, c, ragged=True, seed=0, n=6, smax=19):
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import PaddingMask, SequenceBatch, SonarTextTransformerEncoderModel
+
+    params = O.make_synthetic_params(o, seed=seed + 1, std=0.12)
+    ids, lens = O.synthetic_batch(n, 3, smax, o.vocab_size, seed=seed)
+    if not ragged:
+        lens = None
+        ids = ids.clamp(min=4)
+    enc_ref, ref = O.text_encoder_forward(params, o, ids, lens)
+    model = SonarTextTransformerEncoderModel(c, params, device="cuda:0", dtype=torch.float32, return_encoded_seqs=True)
+    out = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]) if lens is not None else None))
+    return out, enc_ref, ref, lens
+
+
+def test_low_dim_encoder_attention_pooling():
+    """test_low_dimension_text_models.py:20-43: `basic` with model_dim 32, embedding_dim 256, 5 encoder layers, 2 pooler
+    layers, pooling "attention" (16 heads of 2 in the encoder, 16 of 16 in the pooler; post-norm pooler layers because
+    `basic` has normalize_before False), tokens [[0, 1, 2, 3, 4]] x 3 -> sentence_embeddings [3, 256]."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import SequenceBatch, SonarTextTransformerEncoderModel, get_text_encoder_config
+
+    cfg = get_text_encoder_config("basic")
+    cfg.model_dim, cfg.embedding_dim, cfg.num_encoder_layers, cfg.num_decoder_layers, cfg.pooling = 32, 256, 5, 2, "attention"
+    cfg.ffn_inner_dim, cfg.vocab_info.size = 64, 300          # (the reference test keeps F = 8192 and V = 256206: same code path)
+    o = O.OracleTextEncoderConfig(model_dim=32, num_layers=5, num_heads=16, ffn_inner_dim=64, vocab_size=300,
+                                  pooling="attention", embedding_dim=256, pooler_layers=2, pooler_heads=16, pooler_ffn_dim=64)
+    params = O.make_synthetic_params(o, seed=9, std=0.15)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    tokens = torch.tensor([[0, 1, 2, 3, 4]] * 3)
+    out = model(SequenceBatch(tokens.cuda(), None)).sentence_embeddings
+    assert out.shape == (3, 256)
+    _, ref = O.text_encoder_forward(params, o, tokens, None)
+    err = (out.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"low-dim encoder, attention pooling 32 -> 256: max |diff| / scale = {err:.2e}")
+    assert err <= 1e-4
+
+
+@pytest.mark.parametrize("variant", ["attention_pre", "attention_post_ragged", "mean_headdim8", "max_learned_pos",
+                                     "last_no_pos_ln_embed", "normalize_before_mean", "no_scale"])
+def test_generic_encoder_option_matrix(variant):
+    """Every builder option of SonarTextEncoderFactory.create_model (factory.py:72-120) against the oracle."""
+    base = dict(d=48, heads=6, ffn=80, layers=2, vocab=211)
+    v = {
+        "attention_pre": dict(pooling="attention", embedding_dim=96, dec_layers=2, dec_heads=4, dec_ffn=72, normalize_before=True),
+        "attention_post_ragged": dict(pooling="attention", embedding_dim=40, dec_layers=1, dec_heads=5),
+        "mean_headdim8": dict(pooling="mean"),
+        "max_learned_pos": dict(pooling="max", learned_pos=True),
+        "last_no_pos_ln_embed": dict(pooling="last", no_token_positional_embeddings=True, layernorm_embedding=True),
+        "normalize_before_mean": dict(pooling="mean", normalize_before=True),
+        "no_scale": dict(pooling="mean", no_scale_embedding=True),
+    }[variant]
+    o, c = _enc_cfgs(**base, **v)
+    out, enc_ref, ref, lens = _run_encoder(o, c, ragged=variant != "attention_pre", seed=len(variant))
+    emb = out.sentence_embeddings.cpu()
+    assert emb.shape == ref.shape
+    assert (emb - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), variant
+    enc = out.encoded_seqs.cpu()
+    if lens is not None:
+        keep = (torch.arange(enc.shape[1]).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+        assert (enc[~keep.expand_as(enc)] == 0).all()
+        enc_ref = torch.where(keep, enc_ref, torch.zeros_like(enc_ref))
+    assert (enc - enc_ref).abs().max().item() <= 1e-4 * enc_ref.abs().max().item()
+
+
+def test_generic_encoder_through_the_pipeline_types():
+    """fp16 / bf16 outputs and the out-of-vocabulary report work on the generic path too."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import PaddingMask, SequenceBatch, SonarTextTransformerEncoderModel
+
+    o, c = _enc_cfgs(d=40, heads=5, ffn=64, layers=1, vocab=97)
+    params = O.make_synthetic_params(o, seed=4, std=0.1)
+    ids, lens = O.synthetic_batch(4, 3, 9, 97, seed=2)
+    _, ref = O.text_encoder_forward(params, o, ids, lens)
+    for dt in (torch.float16, torch.bfloat16):
+        m = SonarTextTransformerEncoderModel(c, params, device="cuda:0", dtype=dt)
+        out = m(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+        assert out.dtype == dt
+        assert (1 - F.cosine_similarity(out.float().cpu(), ref, dim=-1)).abs().max().item() <= 1e-3
+    bad = ids.clone()
+    bad[0, 0] = 97
+    m(SequenceBatch(bad.cuda(), PaddingMask(lens, ids.shape[1])))
+    with pytest.raises(IndexError):
+        m.engine.check()
