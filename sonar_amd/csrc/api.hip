@@ -72,6 +72,9 @@ namespace {
 
 struct Layer {
   DevBuf ln1_w, ln1_b, w_qkv, b_qkv, w_o, b_o, ln2_w, ln2_b, w_1, b_1, w_2, b_2;
+  // LayerNorm fold (kernels.hpp: GemmLnFold): the projections that follow a LayerNorm with the LayerNorm weight
+  // multiplied into their columns, and the two per-column constants of the fold
+  DevBuf w_qkv_f, c1_qkv, c2_qkv, w_1_f, c1_1, c2_1;
 };
 
 constexpr int kCuRing = 8;
@@ -87,6 +90,9 @@ struct smi_text_encoder {
   int64_t cap_rows = 0;
   DevBuf x, h, qkv, ctx, ffn;
   DevBuf parts;  // fp32 split-K slabs of the FFN output projection (small batches only)
+  DevBuf rowpart;  // LayerNorm fold: float2 [d / 256][rows] partial (sum, sum of squares) of the residual rows
+  bool lnfold = false;  // the folded weights exist (tile-major fp16 configuration, d = 1024)
+  bool lnfold_centered = false;  // ... and their rows are centred (no "- mean * c1" term in the epilogue)
   int num_cus = 256;
   // cu_seqlens staging ring: pinned host + device copies
   int32_t* h_cu[kCuRing] = {};
@@ -286,6 +292,34 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
                     hipGetErrorString(he));
       }
     }
+    // LayerNorm fold: W (.) g, c1, c2 for the two projections that read a LayerNorm output (the configuration that uses
+    // them: fp16 tile-major residual stream, d = 1024; SMI_ENC_LNFOLD=0 keeps the LayerNorm launches for A/B runs)
+    // SMI_ENC_LNFOLD: 0 = LayerNorm launches, 1 = fold with the exact "- mean * c1" epilogue term, 2 (default) = fold with
+    // row-centred weights (kernels.hpp: GemmLnFold.centered)
+    static const int lnfold_env = [] { const char* v = getenv("SMI_ENC_LNFOLD"); return v ? atoi(v) : 2; }();
+    e->lnfold = lnfold_env > 0 && e->tile_major && e->x16 && d == 1024;
+    e->lnfold_centered = lnfold_env == 2;
+    if (rc == SMI_OK && e->lnfold) {
+      hipError_t he = L.w_qkv_f.alloc((size_t)3 * d * d * 2);
+      if (he == hipSuccess) he = L.c1_qkv.alloc((size_t)3 * d * 4);
+      if (he == hipSuccess) he = L.c2_qkv.alloc((size_t)3 * d * 4);
+      if (he == hipSuccess) he = L.w_1_f.alloc((size_t)f * d * 2);
+      if (he == hipSuccess) he = L.c1_1.alloc((size_t)f * 4);
+      if (he == hipSuccess) he = L.c2_1.alloc((size_t)f * 4);
+      if (he == hipSuccess)
+        he = launch_ln_fold_prep(L.w_qkv.as<f16>(), L.ln1_w.as<float>(), L.ln1_b.as<float>(), L.b_qkv.as<float>(),
+                                 L.w_qkv_f.as<f16>(), L.c1_qkv.as<float>(), L.c2_qkv.as<float>(), 3 * (int)d, (int)d,
+                                 e->lnfold_centered, nullptr);
+      if (he == hipSuccess)
+        he = launch_ln_fold_prep(L.w_1.as<f16>(), L.ln2_w.as<float>(), L.ln2_b.as<float>(), L.b_1.as<float>(),
+                                 L.w_1_f.as<f16>(), L.c1_1.as<float>(), L.c2_1.as<float>(), (int)f, (int)d,
+                                 e->lnfold_centered, nullptr);
+      if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+      if (he != hipSuccess)
+        rc = fail(he == hipErrorOutOfMemory ? SMI_ERR_OOM : SMI_ERR_HIP, "LayerNorm fold: %s", hipGetErrorString(he));
+      if (rc == SMI_OK) rc = to_tile_major(L.w_qkv_f, 3 * (int)d, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_1_f, (int)f, (int)d);
+    }
     if (rc == SMI_OK && e->tile_major) {
       rc = to_tile_major(L.w_qkv, 3 * (int)d, (int)d);
       if (rc == SMI_OK) rc = to_tile_major(L.w_o, (int)d, (int)d);
@@ -308,7 +342,7 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
   for (auto& L : e->layers)
     e->weight_bytes += (int64_t)(L.w_qkv.bytes + L.b_qkv.bytes + L.w_o.bytes + L.b_o.bytes +
                                  L.w_1.bytes + L.b_1.bytes + L.w_2.bytes + L.b_2.bytes +
-                                 4 * L.ln1_w.bytes);
+                                 4 * L.ln1_w.bytes + L.w_qkv_f.bytes + L.w_1_f.bytes + 2 * L.c1_qkv.bytes + 2 * L.c1_1.bytes);
   *out = e;
   return SMI_OK;
 }
@@ -420,23 +454,57 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   const int tm = e->tile_major;
   const int in_tm = tm ? GEMM_IN_TM : 0, io_tm = tm ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   const int x_out_tm = x_tm ? GEMM_OUT_TM : 0;
+  // LayerNorm fold (kernels.hpp: GemmLnFold): with the tile-major fp16 stream the two LayerNorms of a layer are not
+  // launched; the residual GEMMs leave the row sums of the stream, the QKV / FFN-inner GEMMs multiply the stream itself
+  // by the pre-scaled weights and apply mean / rstd in their epilogues.
+  const bool lnfold = x_tm && e->lnfold;
+  const int nparts = d / 256;
+  GemmLnFold fold_prod{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0}, fold_cons = fold_prod;
+  if (lnfold) {
+    if (e->rowpart.bytes < (size_t)nparts * M * 8) {
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(e->rowpart.alloc((size_t)nparts * M * 8));
+    }
+    fold_prod.part_out = e->rowpart.as<float2>();
+    fold_cons.part_in = e->rowpart.as<float2>();
+    fold_cons.nparts = nparts;
+    fold_cons.inv_k = 1.0f / d;
+    fold_cons.eps = c.ln_eps;
+    fold_cons.centered = e->lnfold_centered;
+    ProfScope ps(e, SMI_PROF_LAYERNORM, stream);  // the first LayerNorm's statistics have no producing GEMM
+    HIP_TRY(launch_row_stats_tm((const f16*)x, e->rowpart.as<float2>(), M, d, nparts, stream));
+  }
   for (int l = 0; l < c.num_layers; ++l) {
     Layer& L = e->layers[l];
+    if (lnfold) {
+      ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
+      fold_cons.c1 = L.c1_qkv.as<float>();
+      HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, (const f16*)x, L.w_qkv_f.as<f16>(), L.c2_qkv.as<float>(), qkv, M, 3 * d,
+                             d, 3 * d, stream, nullptr, &fold_cons));
+    } else {
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
     HIP_TRY(launch_layernorm(x, L.ln1_w.as<float>(), L.ln1_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16, x_tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d,
                            d, 3 * d, stream)); }
+    }
     { ProfScope ps(e, SMI_PROF_ATTENTION, stream);
     HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
     { ProfScope ps(e, SMI_PROF_GEMM_OUT, stream);
     HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, M, d, d, d,
-                           stream)); }
+                           stream, nullptr, lnfold ? &fold_prod : nullptr)); }
+    if (lnfold) {
+      ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
+      fold_cons.c1 = L.c1_1.as<float>();
+      HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, (const f16*)x, L.w_1_f.as<f16>(), L.c2_1.as<float>(), ffn, M, f, d, f,
+                             stream, nullptr, &fold_cons));
+    } else {
     { ProfScope ps(e, SMI_PROF_LAYERNORM, stream);
     HIP_TRY(launch_layernorm(x, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d, stream, tm, x16, x_tm)); }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN1, stream);
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f,
                            stream)); }
+    }
     { ProfScope ps(e, SMI_PROF_GEMM_FFN2, stream);
     if (ffn2_ks > 1) {
       HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), e->parts.as<float>(), M, d, f, ffn2_ks,
@@ -444,7 +512,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
       HIP_TRY(launch_fold_residual(x, x16, e->parts.as<float>(), ffn2_ks, (size_t)M * d, (size_t)M * d, stream));
     } else {
       HIP_TRY(launch_gemm_tn(epi_resid | in_tm | x_out_tm, ffn, L.w_2.as<f16>(), L.b_2.as<float>(), x, M, d, f, d,
-                             stream));
+                             stream, nullptr, lnfold ? &fold_prod : nullptr));
     } }
   }
   { ProfScope ps(e, SMI_PROF_LN_POOL, stream);

@@ -5,8 +5,8 @@
 // accumulate on MFMA (v_mfma_f32_16x16x32_f16 in the 256x256 engine, 32x32x16 in the 128x128 one),
 // with the epilogues fused.
 #include <algorithm>
-
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
@@ -167,6 +167,21 @@ __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const
   }
 }
 
+// LDS reads the compiler must NOT see as LDS reads: after the next tile's LDS-DMA pipeline fill has been issued, hipcc
+// puts `s_waitcnt vmcnt(0)` in front of every ordinary LDS load (its alias tracking cannot tell the ring slots from the
+// small constant area these helpers read), which would drain the fill AND serialise the epilogue's global stores.
+// The caller waits with lds_wait(...), which carries the values as operands.
+__device__ __forceinline__ float2 lds_read_f2_asm(const void* p) {
+  float2 v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
+  return v;
+}
+__device__ __forceinline__ f32x4 lds_read_f4_asm(const void* p) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
+  return v;
+}
+
 // Same epilogues on the 256x256 ping-pong tile engine (gemm_tile256.hpp).
 #ifdef SMI_GEMM_TRACE
 // development aid (-DSMI_GEMM_TRACE): per-tile phase timestamps (100 MHz wall clock) of thread 0
@@ -189,9 +204,14 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
                                                                 const float* __restrict__ bias,
                                                                 void* __restrict__ out_, int M, int N,
                                                                 int K, int ldo, GemmTileStats stats, int ksplit,
-                                                                size_t part_stride, int raster) {
+                                                                size_t part_stride, int raster, GemmLnFold fold) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool TM = LAYOUT > 0;
+  // LayerNorm fold (kernels.hpp: GemmLnFold).  CONSUMER: fp16 tile-major epilogues whose X operand is the residual stream
+  // itself; PRODUCER: the tile-major residual epilogue, which leaves the row sums of the stream it writes.
+  constexpr bool FOLD_CONSUMER = LAYOUT == 2 && (EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16);
+  constexpr bool FOLD_PRODUCER = LAYOUT == 3;
+  const bool folded = FOLD_CONSUMER && fold.part_in != nullptr;
   // work unit = (tile, K part kz): split-K (EPI_STORE_F32 only) gives each part its own fp32 output slab
   // at out + kz * part_stride bytes; the bias goes into part 0; the consumer sums the slabs.
   // K part kz of ksplit covers the K slices [S kz / ksplit, S (kz + 1) / ksplit), S = K / 32: the parts need not be
@@ -218,11 +238,37 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   // read back with ds_reads, which do not touch the vmcnt queue the next tile's fill sits in.
   float* bias_lds = (float*)g2_stage(smem, 1);
   const int tid = threadIdx.x;
-  auto fetch_bias = [&](int n0, int kz) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (bias && kz == 0 && tid < 64) v = *(const f32x4*)(bias + n0 + tid * 4);
+  auto fetch_bias = [&](int n0, int kz) {  // one value per thread (tid < 256): ONE register held across the epilogue
+    float v = 0.f;
+    if (bias && kz == 0 && tid < 256) v = bias[n0 + tid];
     return v;
   };
+  // fold consumer: the tile's c1 slice, and (mean, rstd) of its 256 rows from the producers' partial sums -- fetched with
+  // the pipeline fill like the bias, parked in LDS next to it (floats 256..511; half sums at 1536..), zeros at 1024.. for the
+  // accumulators' start value (the bias slot holds c2, which is added AFTER the row scaling)
+  float* c1_lds = bias_lds + 256;
+  float* zero_lds = bias_lds + 1024;
+  float2* rowsum_lds = (float2*)(bias_lds + 1536);  // fold producer: [4 column waves][256 rows]
+  auto fetch_c1 = [&](int n0) {
+    float v = 0.f;
+    if (folded && tid < 256) v = fold.c1[n0 + tid];
+    return v;
+  };
+  // Raw partial sums only -- NO arithmetic here: anything computed from the loads would put their s_waitcnt in front of
+  // the previous tile's epilogue and expose a full memory latency per tile (measured: +8..11 % on the consuming GEMMs).
+  // All 512 threads take part: thread t fetches partials (t >> 8), (t >> 8) + 2 of row t & 255 (nparts <= 4).
+  struct RawStat { float2 a, b; };
+  auto fetch_rowstat = [&](int m0) {
+    RawStat r{{0.f, 0.f}, {0.f, 0.f}};
+    if (folded) {
+      const int p = tid >> 8, row = m0 + (tid & 255);
+      if (p < fold.nparts) r.a = fold.part_in[(size_t)p * M + row];
+      if (p + 2 < fold.nparts) r.b = fold.part_in[(size_t)(p + 2) * M + row];
+    }
+    return r;
+  };
+  float2* stat_lds = (float2*)(bias_lds + 1536);  // [2][256] half sums, joined after the barrier of g2_begin
+  if (FOLD_CONSUMER && tid < 256) zero_lds[tid] = 0.f;  // published by the barrier of the first g2_begin
 
   // unit id = kz * (ntm * ntn) + output tile: neighbouring ids share operand panels of one K part
   const int nout = ntm * ntn;
@@ -261,8 +307,13 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   int ks0, nt;
   kpart(kz, ks0, nt);
   G2Src src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, ks0 * G2_BK);
+  // The small per-tile fetches are issued BEFORE the pipeline fill: their destination registers carried the previous
+  // tile's values, and hipcc guards the overwrite (zero-init + conditional load) with `s_waitcnt vmcnt(0)` -- which, placed
+  // after the LDS-DMA issue, waited for the whole fill in front of the epilogue (+1.3 us per K = 1024 tile, measured).
+  float bias_next = fetch_bias(tile_n * G2_BN, kz);
+  float c1_next = fetch_c1(tile_n * G2_BN);
+  RawStat stat_next = fetch_rowstat(tile_m * G2_BM);
   g2_prefetch(src, nt, smem);
-  f32x4 bias_next = fetch_bias(tile_n * G2_BN, kz);
 
   while (tile < nvirt) {
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
@@ -270,9 +321,32 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     (void)tile_n_cur;
     out = (char*)out_ + (size_t)kz * part_stride;
     G2_TRACE(0);
-    if (tid < 64) *(f32x4*)(bias_lds + tid * 4) = bias_next;
+    if (tid < 256) bias_lds[tid] = bias_next;
+    if (folded) {
+      if (tid < 256) c1_lds[tid] = c1_next;
+      stat_lds[tid] = float2{stat_next.a.x + stat_next.b.x, stat_next.a.y + stat_next.b.y};
+    }
     GemmTile256Acc acc;
-    g2_begin(acc, bias_lds);
+    g2_begin(acc, folded ? zero_lds : bias_lds);
+    // Fold consumer: what the epilogue needs stays in REGISTERS, spread over the wave, and is fetched there with
+    // ds_bpermute (a lane crossbar, no LDS memory access): after the next tile's LDS-DMA fill has been issued, hipcc puts
+    // `s_waitcnt vmcnt(0)` in front of every LDS load (its alias tracking cannot tell the ring from the constant area),
+    // which drained the fill and serialised the epilogue's stores (+9 % on the FFN-inner GEMM).  Lane L of a wave keeps
+    // (rstd, -rstd * mean) of the rows wr*128 + L and + 64 + L of the tile, and c1 / c2 of column wc*64 + L.
+    // Only the LDS reads happen here (nothing may read LDS once the next fill is in flight); the arithmetic on them
+    // waits for the epilogue, where VALU work hides behind the stores -- here it would sit, serial, in front of the K loop.
+    float2 row_sq[2] = {{0.f, 0.f}, {0.f, 0.f}};  // (sum, sum of squares) of the lane's two rows
+    float col_c1 = 0.f, col_c2 = 0.f;
+    if (folded) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = wr * 128 + u * 64 + lane;
+        const float2 h0 = stat_lds[row], h1 = stat_lds[256 + row];
+        row_sq[u] = float2{h0.x + h1.x, h0.y + h1.y};
+      }
+      col_c1 = c1_lds[wc * 64 + lane];
+      col_c2 = bias_lds[wc * 64 + lane];
+    }
     G2_TRACE(1);
     g2_mainloop(acc, src, nt, smem);
     G2_TRACE(2);
@@ -281,8 +355,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       kz = raster ? 0 : tile / nout;
       kpart(kz, ks0, nt);
       src = g2_make_src<TM, TM>(X, W, K, tile_m * G2_BM, tile_n * G2_BN, ks0 * G2_BK);
+      bias_next = fetch_bias(tile_n * G2_BN, kz);  // before the fill: see above
+      c1_next = fetch_c1(tile_n * G2_BN);
+      stat_next = fetch_rowstat(tile_m * G2_BM);
       g2_prefetch(src, nt, smem);
-      bias_next = fetch_bias(tile_n * G2_BN, kz);
     }
     G2_TRACE(3);
     // epilogues that leave through the fp32 staging passes (fp32 outputs and the fp16 residual stream,
@@ -357,8 +433,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
         for (int j = 0; j < 2; ++j) oldv[mi][j] = *(const half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32));
+      const bool emit = FOLD_PRODUCER && fold.part_out != nullptr;
+      float rs_sum[8], rs_sq[8];  // fold producer: sums of the lane's 16 NEW values of row (mi, l15)
 #pragma unroll
       for (int mi = 0; mi < 8; ++mi) {
+        rs_sum[mi] = 0.f;
+        rs_sq[mi] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const f32x4 a = acc.v[2 * j][mi], b = acc.v[2 * j + 1][mi];
@@ -372,7 +452,45 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           half8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (f16)((float)oldv[mi][j][i] + c8[i]);
+#ifdef SMI_FOLD_PLAIN_STORE
+          if (emit) *(half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = o; else
+#endif
           store_nt((half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), o);
+          if (emit) {
+            // of the ROUNDED values (what the consuming GEMM will read), two per v_dot2_f32_f16: exact fp16 products,
+            // fp32 accumulation -- 8 instructions per chunk instead of 8 conversions + 8 adds + 8 FMAs
+            const half2v ones = {(f16)1.f, (f16)1.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const half2v t2 = {o[2 * i], o[2 * i + 1]};
+              rs_sum[mi] = __builtin_amdgcn_fdot2(t2, ones, rs_sum[mi], false);
+              rs_sq[mi] = __builtin_amdgcn_fdot2(t2, t2, rs_sq[mi], false);
+            }
+          }
+        }
+      }
+      if (emit) {
+        // join the 4 lane groups of a row (lanes 16 apart), then the 4 column waves through LDS, then one coalesced
+        // 2 KiB store of the tile's 256 partial (sum, sum of squares) pairs
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          float v0 = rs_sum[mi], v1 = rs_sq[mi];
+          auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+          v0 = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+          auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+          v0 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+          s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+          v1 = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+          s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+          v1 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+          if (kg == 0) rowsum_lds[wc * 256 + wr * 128 + mi * 16 + l15] = float2{v0, v1};
+        }
+        SMI_LGKM0_BARRIER();
+        if (tid < 256) {
+          float2 a0 = lds_read_f2_asm(rowsum_lds + tid), a1 = lds_read_f2_asm(rowsum_lds + 256 + tid);
+          float2 a2 = lds_read_f2_asm(rowsum_lds + 512 + tid), a3 = lds_read_f2_asm(rowsum_lds + 768 + tid);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+          fold.part_out[(size_t)tile_n_cur * M + m0 + tid] = float2{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
         }
       }
     } else
@@ -476,25 +594,95 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       const int sw = tm_swz(l15);
       f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
                    (wr * 128 + l15) * 32 + ((cidx ^ sw) << 3);
+      // LayerNorm fold: acc holds x . (W (.) g)^T; out = rstd * (acc - mean * c1) + c2 per (row, column) -- or, with
+      // row-centred weights, rstd * acc + c2.  The store loop exists in three straight-line copies (MODE 0 plain, 1 exact
+      // fold, 2 centred fold) chosen by ONE wave-uniform branch per tile: with the mode tested inside the unrolled loop
+      // every iteration carried two or three scalar branches, the compiler could not overlap iterations across them, and
+      // the consuming GEMMs ran 6-9 % slower than the unfolded kernel (r03 experiments).  The loop runs k-block (j)
+      // outermost so that only the two 16-column blocks of a k-block have their c1 / c2 in registers.
+      auto store_tile = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        float rsall[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        float row_rs[2] = {1.f, 1.f}, row_nm[2] = {0.f, 0.f};
+        if constexpr (MODE != 0) {
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
+          for (int u = 0; u < 2; ++u) {
+            const float mean = row_sq[u].x * fold.inv_k;
+            const float var = fmaxf(row_sq[u].y * fold.inv_k - mean * mean, 0.f);
+            row_rs[u] = __builtin_amdgcn_rsqf(var + fold.eps);  // 1 ulp; the result is rounded to fp16 a few steps later
+            row_nm[u] = -row_rs[u] * mean;
+          }
+        }
+        if constexpr (MODE == 2) {  // row mi * 16 + l15 of the wave's 128: lane (mi * 16 + l15) & 63, register mi >> 2
+#pragma unroll
+          for (int mi = 0; mi < 8; ++mi)
+            rsall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(((mi & 3) * 16 + l15) * 4, __float_as_int(row_rs[mi >> 2])));
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          uint32_t h[2][2];
+          f32x4 c1v[2] = {}, c2v[2] = {};
+          if constexpr (MODE != 0) {  // columns (2j + nl) * 16 + 4 kg + r of the wave's 64: held by that lane
 #pragma unroll
-          for (int nl = 0; nl < 2; ++nl) {
-            const f32x4 v = acc.v[2 * j + nl][mi];
-            const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(v));
-            h[nl][0] = hp.x;
-            h[nl][1] = hp.y;
+            for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int src = ((2 * j + nl) * 16 + 4 * kg + r) * 4;
+                if constexpr (MODE == 1) c1v[nl][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(col_c1)));
+                c2v[nl][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(col_c2)));
+              }
           }
-          // rows 16..31 / 48..63 of h[0] <-> rows 0..15 / 32..47 of h[1]
-          const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-          store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
+#pragma unroll
+          for (int mi = 0; mi < 8; ++mi) {
+            float2 aff = {1.f, 0.f};
+            if constexpr (MODE == 2) aff.x = rsall[mi];
+            if constexpr (MODE == 1) {
+              const int src = ((mi & 3) * 16 + l15) * 4;
+              aff.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_rs[mi >> 2])));
+              aff.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_nm[mi >> 2])));
+            }
+            uint32_t h[2][2];
+#pragma unroll
+            for (int nl = 0; nl < 2; ++nl) {
+              f32x4 v = acc.v[2 * j + nl][mi];
+              if constexpr (MODE != 0) {
+                // v_pk_fma_f32: two values per instruction (a wave64 VALU instruction takes 4 cycles)
+                const f32x2 rs2 = {aff.x, aff.x}, nm2 = {aff.y, aff.y};
+#pragma unroll
+                for (int hp2 = 0; hp2 < 2; ++hp2) {
+                  const f32x2 c2p = {c2v[nl][2 * hp2], c2v[nl][2 * hp2 + 1]};
+                  f32x2 vp = {v[2 * hp2], v[2 * hp2 + 1]};
+                  if constexpr (MODE == 1) {
+                    const f32x2 c1p = {c1v[nl][2 * hp2], c1v[nl][2 * hp2 + 1]};
+                    vp = __builtin_elementwise_fma(rs2, vp, __builtin_elementwise_fma(nm2, c1p, c2p));
+                  } else {
+                    vp = __builtin_elementwise_fma(rs2, vp, c2p);
+                  }
+                  v[2 * hp2] = vp[0];
+                  v[2 * hp2 + 1] = vp[1];
+                }
+              }
+              const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(v));
+              h[nl][0] = hp.x;
+              h[nl][1] = hp.y;
+            }
+            // rows 16..31 / 48..63 of h[0] <-> rows 0..15 / 32..47 of h[1]
+            const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
+            store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
+          }
         }
+      };
+      if constexpr (FOLD_CONSUMER) {
+        if (!folded)
+          store_tile(std::integral_constant<int, 0>{});
+        else if (fold.centered)
+          store_tile(std::integral_constant<int, 2>{});
+        else
+          store_tile(std::integral_constant<int, 1>{});
+      } else {
+        store_tile(std::integral_constant<int, 0>{});
       }
     } else {
 #pragma unroll
@@ -551,7 +739,7 @@ static int num_cus() {
 template <int EPI, int LAYOUT>
 static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, void* out, int M,
                                 int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr,
-                                int ksplit = 1, size_t part_stride = 0) {
+                                int ksplit = 1, size_t part_stride = 0, const GemmLnFold* fold = nullptr) {
   static DeviceOnce attr_done;
   if (!attr_done.done()) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel<EPI, LAYOUT>,
@@ -571,7 +759,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
                          ? want_raster : 0;
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
                      stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0}, ksplit,
-                     part_stride, raster);
+                     part_stride, raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0});
   return hipGetLastError();
 }
 
@@ -613,7 +801,8 @@ static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void
 }
 
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out,
-                          int M, int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats) {
+                          int M, int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats,
+                          const GemmLnFold* fold) {
   // epi_sel = epilogue | (engine << 8) | layout flags: engine 0 auto, 1 force 128x128, 2 force
   // 256x256; GEMM_IN_TM = X and W tile-major, GEMM_OUT_TM = fp16 output tile-major (needs IN_TM)
   const int epi = epi_sel & 0xff, sel = (epi_sel >> 8) & 0xf;
@@ -627,6 +816,17 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // floor for a K = 1024 tile and one workgroup per CU; measured crossover (tools/probe_engines.py):
   // 128 tiles tie, 160 tiles win -> use it from 144 tiles (56 % of the CUs) up
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 144);
+  if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream; consumer = layouts 2 (bias / relu), producer = layout 3
+    if (!can256 || sel == 1 || !in_tm || !out_tm || stats) return hipErrorInvalidValue;
+    if (fold->part_in) {
+      if (!fold->c1 || fold->nparts < 1 || fold->nparts > 4) return hipErrorInvalidValue;
+      if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+      if (epi == EPI_RELU_F16) return launch_one256<EPI_RELU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+      return hipErrorInvalidValue;
+    }
+    if (epi != EPI_RESID_F16 || !fold->part_out) return hipErrorInvalidValue;
+    return launch_one256<EPI_RESID_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+  }
   if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
     if (epi != EPI_STORE_F32 || out_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
     return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, out, M, N, K, ldo, stream, stats)

@@ -71,9 +71,32 @@ struct GemmTileStats {
   int valid_n;
 };
 
+// LayerNorm folded into the GEMMs around it (256x256 engine, tile-major fp16 residual stream).
+// With h = LN(x) = (x - mean) * rstd * g + b,   h . W^T = rstd * (x . (W (.) g)^T - mean * c1) + c2,
+// c1[n] = sum_k g[k] W[n][k], c2[n] = sum_k b[k] W[n][k] + bias[n]: the consuming GEMM multiplies the residual stream x
+// ITSELF by the pre-scaled weights and applies the row statistics in its epilogue; the producing (residual) GEMM leaves
+// the per-row (sum, sum of squares) of the stream it has just written.  No LayerNorm launch, no `h` round trip.
+//  * producer (EPI_RESID_F16, tile-major stream): part_out[N/256][M] <- partial sums of the new rows over the tile's columns
+//  * consumer (EPI_BIAS_F16 / EPI_RELU_F16, tile-major in/out): X = the stream, W = the pre-scaled weights, bias = c2,
+//    part_in[nparts][M] = the partial sums of x's rows, c1 as above
+struct GemmLnFold {
+  float2* part_out;
+  const float2* part_in;
+  const float* c1;
+  int nparts;
+  float inv_k;  // 1 / (row width of the stream)
+  float eps;
+  // centered != 0: the pre-scaled weight rows were centred (W'' = W (.) g - c1 / K), which moves the "- mean * c1" term
+  // into the GEMM itself (sum_k x_k W''_nk = sum_k (x_k - mean) (W (.) g)_nk): the epilogue is out = rstd * acc + c2.
+  // Costs: the fp16 rounding of W'' leaves a residue r_n = sum_k W''_nk (~4.5e-3 of a weight's magnitude at K = 1024)
+  // that multiplies the row mean; relative to the signal that is ~1.4e-4 * |mean| / std.
+  int centered;
+};
+
 // C = X[M,K] * W[N,K]^T (+bias, epilogue).  M%128==0, N%128==0, K%64==0.
 hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* bias, void* out, int M,
-                          int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr);
+                          int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr,
+                          const GemmLnFold* fold = nullptr);
 
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
@@ -113,6 +136,12 @@ hipError_t launch_f32_to_f16(const float* src, f16* dst, size_t n, hipStream_t s
 // element-wise cast, dtypes 0 = fp32, 1 = fp16, 2 = bf16 (smi_dtype)
 hipError_t launch_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t n, hipStream_t stream);
 // x[i] += sum_z parts[z * part_elems + i], i < n (n % 8 == 0); x fp16 or fp32 (rowops.hip)
+// LayerNorm-fold helpers (rowops.hip): Wf = f16(W (.) g), c1 = row sums of Wf, c2 = W . b + bias  (W [N][K] row-major)
+// centered: Wf = f16(W (.) g - c1 / K) (row-centred), c1 = the rounding residue sum_k Wf[n][k]
+hipError_t launch_ln_fold_prep(const f16* W, const float* g, const float* b, const float* bias, f16* Wf, float* c1,
+                               float* c2, int N, int K, int centered, hipStream_t stream);
+// part[0][r] = (sum, sum of squares) of row r of the tile-major fp16 stream x [M][d]; part[1..nparts-1][r] = 0
+hipError_t launch_row_stats_tm(const f16* x_tm, float2* part, int M, int d, int nparts, hipStream_t stream);
 hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int nparts, size_t part_elems, size_t n,
                                 hipStream_t stream);
 // dst_f32[i] = float(src_f16[i])

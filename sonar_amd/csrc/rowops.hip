@@ -788,6 +788,72 @@ hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int npar
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------- LayerNorm folded into the GEMMs (kernels.hpp: GemmLnFold)
+// One wave per weight row n: Wf[n][k] = f16(W[n][k] * g[k]); c1[n] = sum_k float(Wf[n][k]) -- the ROUNDED values, because
+// that is what the GEMM multiplies --; c2[n] = sum_k b[k] * W[n][k] + bias[n].
+__global__ __launch_bounds__(256) void ln_fold_prep_kernel(const f16* __restrict__ W, const float* __restrict__ g,
+                                                           const float* __restrict__ b, const float* __restrict__ bias,
+                                                           f16* __restrict__ Wf, float* __restrict__ c1,
+                                                           float* __restrict__ c2, int N, int K, int centered) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float shift = 0.f;
+  if (centered) {  // row mean of the scaled weights (unrounded), subtracted from every element
+    float t = 0.f;
+    for (int k = lane; k < K; k += 64) t += (float)W[(size_t)n * K + k] * g[k];
+    shift = wave_sum(t) / K;
+  }
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = (float)W[(size_t)n * K + k];
+    const f16 wf = (f16)(w * g[k] - shift);
+    Wf[(size_t)n * K + k] = wf;
+    s1 += (float)wf;
+    s2 += b[k] * w;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    c1[n] = s1;
+    c2[n] = s2 + (bias ? bias[n] : 0.f);
+  }
+}
+
+hipError_t launch_ln_fold_prep(const f16* W, const float* g, const float* b, const float* bias, f16* Wf, float* c1,
+                               float* c2, int N, int K, int centered, hipStream_t stream) {
+  if (N <= 0 || K <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_fold_prep_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, W, g, b, bias, Wf, c1, c2, N, K, centered);
+  return hipGetLastError();
+}
+
+// (sum, sum of squares) of every row of the tile-major fp16 stream (the embedding output: the first LayerNorm of a
+// forward has no producing GEMM).  One wave per row, 16-B loads.
+__global__ __launch_bounds__(256) void row_stats_tm_kernel(const f16* __restrict__ x, float2* __restrict__ part, int M, int d,
+                                                           int nparts) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= M) return;
+  float s = 0.f, q = 0.f;
+  for (int c = lane * 8; c < d; c += 512) {
+    const half8 v = *(const half8*)(x + tm_offset(r, c, d));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = (float)v[i];
+      s += t;
+      q += t * t;
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (lane == 0) part[r] = float2{s, q};
+  if (lane >= 1 && lane < nparts) part[(size_t)lane * M + r] = float2{0.f, 0.f};
+}
+
+hipError_t launch_row_stats_tm(const f16* x_tm, float2* part, int M, int d, int nparts, hipStream_t stream) {
+  if (M <= 0 || d % 8 || nparts < 1 || nparts > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(row_stats_tm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x_tm, part, M, d, nparts);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------- conversions
 __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict__ s,
                                                          f16* __restrict__ d, size_t n) {
