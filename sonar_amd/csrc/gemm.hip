@@ -181,6 +181,35 @@ __device__ __forceinline__ f32x4 lds_read_f4_asm(const void* p) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
   return v;
 }
+// LDS stores the compiler does not see either (same reason: an ordinary LDS store after the fill has been issued is
+// guarded by vmcnt(0) -- write-after-write against the DMA as far as the alias tracking knows).  Completion: the
+// lgkmcnt(0) of SMI_LGKM0_BARRIER, which every staged pass runs before anyone reads.
+__device__ __forceinline__ void lds_write_f4_asm(void* p, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+template <typename T8>
+__device__ __forceinline__ void lds_write_b64_asm(void* p, T8 v) {
+  static_assert(sizeof(T8) == 8, "8-byte value");
+  asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory");
+}
+// N 16-B reads and their wait in ONE statement (issue and wait must not be separable: between them the compiler may
+// copy a destination register that the LDS has not written yet -- r03 experiment 4, attempt 4).  Used by the staged
+// epilogues, whose ordinary LDS loads each drew a vmcnt(0): the staging buffers are ring slot 3 and the LDS above the
+// ring, never a target of the next tile's fill, so nothing has to be waited for.
+template <int N>
+__device__ __forceinline__ void lds_read_stage(const char* const (&p)[N], f32x4 (&v)[N]) {
+  static_assert(N == 2 || N == 4, "2 or 4 reads");
+  if constexpr (N == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"((unsigned)(size_t)p[0]), "v"((unsigned)(size_t)p[1]), "v"((unsigned)(size_t)p[2]), "v"((unsigned)(size_t)p[3])
+                 : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1])
+                 : "v"((unsigned)(size_t)p[0]), "v"((unsigned)(size_t)p[1])
+                 : "memory");
+}
 
 // Same epilogues on the 256x256 ping-pong tile engine (gemm_tile256.hpp).
 #ifdef SMI_GEMM_TRACE
@@ -402,11 +431,19 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             for (int r = 0; r < 4; ++r) se += __builtin_amdgcn_exp2f(t[ni][r] - ms);
           se += __shfl_xor(se, 16, 64);
           se += __shfl_xor(se, 32, 64);
-          if (kg == 0) red[(wr * 128 + mi * 16 + l15) * 4 + wc] = float2{mx, se};
+          if (kg == 0) lds_write_b64_asm(&red[(wr * 128 + mi * 16 + l15) * 4 + wc], float2{mx, se});
         }
         SMI_LGKM0_BARRIER();
         if (tid < 256) {
-          const float2 a0 = red[tid * 4], a1 = red[tid * 4 + 1], a2 = red[tid * 4 + 2], a3 = red[tid * 4 + 3];
+          f32x4 r01, r23;  // (max, sum) of column waves 0, 1 and 2, 3: two 16-B reads through the asm helper
+          {
+            const char* rp[2] = {(const char*)&red[tid * 4], (const char*)&red[tid * 4 + 2]};
+            f32x4 rv[2];
+            lds_read_stage<2>(rp, rv);
+            r01 = rv[0];
+            r23 = rv[1];
+          }
+          const float2 a0 = {r01[0], r01[1]}, a1 = {r01[2], r01[3]}, a2 = {r23[0], r23[1]}, a3 = {r23[2], r23[3]};
           const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
           const float ms = m == -INFINITY ? 0.f : m;
           const float sum = a0.y * __builtin_amdgcn_exp2f(a0.x - ms) + a1.y * __builtin_amdgcn_exp2f(a1.x - ms) +
@@ -483,7 +520,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           v1 = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
           s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
           v1 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-          if (kg == 0) rowsum_lds[wc * 256 + wr * 128 + mi * 16 + l15] = float2{v0, v1};
+          if (kg == 0) lds_write_b64_asm(&rowsum_lds[wc * 256 + wr * 128 + mi * 16 + l15], float2{v0, v1});
         }
         SMI_LGKM0_BARRIER();
         if (tid < 256) {
@@ -535,14 +572,24 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             if constexpr (HALF_STEP) v = v * 0.5f;
             const int lr = lr_w(mi);
             // 16-B chunk (4 floats) of the 128 staged columns: wc*8 + nl*4 + kg
-            *(f32x4*)(st + lr * 512 + (((wc * 8 + nl * 4 + kg) ^ g2_stage_swz(lr)) << 4)) = v;
+            lds_write_f4_asm(st + lr * 512 + (((wc * 8 + nl * 4 + kg) ^ g2_stage_swz(lr)) << 4), v);
           }
         SMI_LGKM0_BARRIER();
+        f32x4 sv[4];
+        {
+          const char* sp_[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int lr = wave * 8 + it * 2 + hi;
+            sp_[it] = st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4);
+          }
+          lds_read_stage<4>(sp_, sv);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
-          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          const f32x4 v = sv[it];
           if constexpr (F16_RESID) {
             const f32x4 sum = old[sp & 1][it] + v;
             half4 hv;
@@ -571,15 +618,25 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
               h[e] = (f16)(acc.v[nl][mi][e] * sigmoid_f(acc.v[nl + 2][mi][e]));
             const int lr = lr_w(mi);
             // 16-B chunk (8 channels) of the 128 staged channels: wc*4 + nl*2 + (kg>>1), half kg&1
-            *(half4*)(st + lr * 512 + (((wc * 4 + nl * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
+            lds_write_b64_asm(st + lr * 512 + (((wc * 4 + nl * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8, h);
           }
         SMI_LGKM0_BARRIER();
         const int c = lane & 15;  // 16 lanes x 16 B = one 256-B output row
+        f32x4 sv[2];
+        {
+          const char* sp_[2];
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int lr = wave * 8 + it * 4 + (lane >> 4);
+            sp_[it] = st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4);
+          }
+          lds_read_stage<2>(sp_, sv);
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int lr = wave * 8 + it * 4 + (lane >> 4);
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
-          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          const f32x4 v = sv[it];
           *(f32x4*)((f16*)out + (size_t)row * ldo + n0 / 2 + c * 8) = v;
         }
       }
@@ -697,15 +754,25 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             const half4 h = epi_act_pack<EPI>(v);
             const int lr = lr_w(mi);
             // 16-B chunk (8 columns) of the 256 staged columns: wc*8 + ni*2 + (kg>>1), half kg&1
-            *(half4*)(st + lr * 512 + (((wc * 8 + ni * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8) = h;
+            lds_write_b64_asm(st + lr * 512 + (((wc * 8 + ni * 2 + (kg >> 1)) ^ g2_stage_swz(lr)) << 4) + (kg & 1) * 8, h);
           }
         SMI_LGKM0_BARRIER();
         const int c = lane & 31;
+        f32x4 sv[4];
+        {
+          const char* sp_[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int lr = wave * 8 + it * 2 + hi;
+            sp_[it] = st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4);
+          }
+          lds_read_stage<4>(sp_, sv);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
           const int lr = wave * 8 + it * 2 + hi;
           const int row = m0 + (lr >> 5) * 128 + p * 32 + (lr & 31);
-          const f32x4 v = *(const f32x4*)(st + lr * 512 + ((c ^ g2_stage_swz(lr)) << 4));
+          const f32x4 v = sv[it];
           *(f32x4*)((f16*)out + (size_t)row * ldo + n0 + c * 8) = v;
         }
       }
