@@ -436,9 +436,17 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     while (ffn2_ks < 8 && tiles * ffn2_ks * 2 <= e->num_cus && f % (ffn2_ks * 2 * 512) == 0) ffn2_ks *= 2;
     if (d % 256 || ffn2_ks < 2) ffn2_ks = 1;
   }
-  if (ffn2_ks > 1 && e->parts.bytes < (size_t)ffn2_ks * rows * d * 4) {
+  // In that mode the whole layer takes the decoder's shape (6 launches instead of 8; SMI_ENC_SB=0 keeps the round-2
+  // schedule for A/B runs): the attention output projection is split-K too (every 128x128 unit on a CU of its own, the
+  // lone-tile ring engine), and the slabs of both projections are folded into the residual stream by the fused
+  // sum + LayerNorm kernel that produces the next GEMM's input -- no separate fold, no separate LayerNorm.
+  static const bool sb_env = [] { const char* v = getenv("SMI_ENC_SB"); return !(v && v[0] == '0'); }();
+  const bool sb = sb_env && ffn2_ks > 1 && c.num_layers > 0;
+  const int out_ks = sb ? gemm_splitk_parts((int)rows, d, d, 8) : 1;
+  const int max_ks = std::max(ffn2_ks, out_ks);
+  if (ffn2_ks > 1 && e->parts.bytes < (size_t)max_ks * rows * d * 4) {
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(e->parts.alloc((size_t)ffn2_ks * rows * d * 4));
+    HIP_TRY(e->parts.alloc((size_t)max_ks * rows * d * 4));
   }
   const int x_tm = x_tm_enabled && e->tile_major && x16 && d == 1024 && !out_encoded && ffn2_ks == 1;
   if (rows > total) {
@@ -474,7 +482,30 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     ProfScope ps(e, SMI_PROF_LAYERNORM, stream);  // the first LayerNorm's statistics have no producing GEMM
     HIP_TRY(launch_row_stats_tm((const f16*)x, e->rowpart.as<float2>(), M, d, nparts, stream));
   }
-  for (int l = 0; l < c.num_layers; ++l) {
+  for (int l = 0; l < c.num_layers && sb; ++l) {  // small batches: the decoder-shaped layer (see above)
+    Layer& L = e->layers[l];
+    float* parts = e->parts.as<float>();
+    const size_t ps = (size_t)M * d;
+    { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += FFN-output slabs of the previous layer; h = LN1(x)
+    HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ffn2_ks, ps, nullptr, 1, L.ln1_w.as<float>(), L.ln1_b.as<float>(),
+                                 c.ln_eps, h, M, d, stream, tm, x16)); }
+    { ProfScope ps_(e, SMI_PROF_GEMM_QKV, stream);
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d, 3 * d, stream)); }
+    { ProfScope ps_(e, SMI_PROF_ATTENTION, stream);
+    HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
+    { ProfScope ps_(e, SMI_PROF_GEMM_OUT, stream);
+    HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, M, d, d, out_ks, stream, tm)); }
+    { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += attention-output slabs; h = LN2(x)
+    HIP_TRY(launch_sum_layernorm(x, parts, out_ks, ps, nullptr, 1, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d,
+                                 stream, tm, x16)); }
+    { ProfScope ps_(e, SMI_PROF_GEMM_FFN1, stream);
+    HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream)); }
+    { ProfScope ps_(e, SMI_PROF_GEMM_FFN2, stream);
+    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, M, d, f, ffn2_ks, stream, tm));
+    if (l + 1 == c.num_layers)  // the last layer's slabs meet the stream before the final LayerNorm + pooling
+      HIP_TRY(launch_fold_residual(x, x16, parts, ffn2_ks, ps, ps, stream)); }
+  }
+  for (int l = 0; l < c.num_layers && !sb; ++l) {
     Layer& L = e->layers[l];
     if (lnfold) {
       ProfScope ps(e, SMI_PROF_GEMM_QKV, stream);

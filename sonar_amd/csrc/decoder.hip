@@ -63,8 +63,8 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 // ---------------------- x += sum_z parts[z] (+ c[row / group]); h = LN(x)  (fused)
 // parts: split-K slabs of the preceding projection GEMM (fp32 [nparts][rows_pad][d]); c: the
 // per-sentence cross-attention constant.  Either may be null.
-template <int NV>
-__global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, const float* __restrict__ parts,
+template <int NV, typename XT>
+__global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const float* __restrict__ parts,
                                                      int nparts, size_t part_stride,
                                                      const float* __restrict__ c, int group,
                                                      const float* __restrict__ w,
@@ -74,14 +74,21 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
-  float* xr = x + (size_t)r * D;
+  XT* xr = x + (size_t)r * D;
   // The kernel is one dependent chain per wave (loads -> two wave reductions -> store) at ~1 wave per
   // SIMD, so every load is issued before the first add: x, the constant, then the slabs eight at a time.
-  // The summation order (x, slabs ascending, constant) is fixed.
+  // The summation order (x, slabs ascending, constant) is fixed.  XT = f16: the residual stream is fp16 (the text
+  // encoder's small-batch path): fp32 adds, ONE rounding when the row is written back; LayerNorm sees the rounded row.
   f32x4 v[NV], cv[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    if constexpr (sizeof(XT) == 2) {
+      const half4 xv = *(const half4*)(xr + k * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[k][i] = (float)xv[i];
+    } else {
+      v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+    }
     cv[k] = c ? *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float* pr = parts + (size_t)r * D + lane * 4;
@@ -103,7 +110,17 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     v[k] += cv[k];
-    *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    if constexpr (sizeof(XT) == 2) {
+      half4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o[i] = (f16)v[k][i];
+        v[k][i] = (float)o[i];
+      }
+      *(half4*)(xr + k * 256 + lane * 4) = o;
+    } else {
+      *(f32x4*)(xr + k * 256 + lane * 4) = v[k];
+    }
     s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
   }
   constexpr float inv_d = 1.0f / D;
@@ -132,15 +149,19 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(float* __restrict__ x, cons
   }
 }
 
-hipError_t launch_sum_layernorm(float* x, const float* parts, int nparts, size_t part_stride,
+hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
-                                f16* h, int rows, int d, hipStream_t stream, int h_tm) {
+                                f16* h, int rows, int d, hipStream_t stream, int h_tm, int x_f16) {
   const int blocks = (rows + 3) / 4;
   if (!parts) nparts = 0;
-#define SMI_AL_CASE(NV)                                                                            \
-  case NV * 256:                                                                                   \
-    hipLaunchKernelGGL(sum_ln_kernel<NV>, dim3(blocks), dim3(256), 0, stream, x, parts, nparts,    \
-                       part_stride, c, group, w, b, eps, h, rows, h_tm);                           \
+#define SMI_AL_CASE(NV)                                                                                     \
+  case NV * 256:                                                                                            \
+    if (x_f16)                                                                                              \
+      hipLaunchKernelGGL((sum_ln_kernel<NV, f16>), dim3(blocks), dim3(256), 0, stream, (f16*)x, parts, nparts, \
+                         part_stride, c, group, w, b, eps, h, rows, h_tm);                                  \
+    else                                                                                                    \
+      hipLaunchKernelGGL((sum_ln_kernel<NV, float>), dim3(blocks), dim3(256), 0, stream, (float*)x, parts,  \
+                         nparts, part_stride, c, group, w, b, eps, h, rows, h_tm);                          \
     break;
   switch (d) {
     SMI_AL_CASE(1)

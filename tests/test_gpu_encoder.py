@@ -259,3 +259,26 @@ def test_bf16_model_at_the_boundary():
     m16 = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float16)
     o16 = m16(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
     assert (out.float() - o16.float()).abs().max().item() <= 2 ** -7 * o16.float().abs().max().item()
+
+
+@pytest.mark.parametrize("fp16_residual", [True, False])
+def test_small_batch_layer_schedule_vs_oracle(fp16_residual):
+    """Small batches (a handful of row tiles, F a multiple of 1024) take the decoder-shaped layer: split-K attention-output
+    and FFN-output projections whose slabs the fused sum + LayerNorm kernel folds into the (fp16 or fp32) residual stream.
+    The reference's default call (`batch_size=5`, text.py:178) lives on this path."""
+    from oracle import text_encoder as O
+    from sonar_amd.text_encoder import (PaddingMask, SequenceBatch, SonarTextEncoderConfig,
+                                        SonarTextTransformerEncoderModel, VocabularyInfo)
+
+    ocfg = O.OracleTextEncoderConfig(model_dim=256, num_layers=3, num_heads=4, ffn_inner_dim=2048, vocab_size=500)
+    cfg = SonarTextEncoderConfig(model_dim=256, num_encoder_layers=3, num_encoder_attn_heads=4, ffn_inner_dim=2048,
+                                 vocab_info=VocabularyInfo(size=500), _from_fairseq=True)
+    params = O.make_synthetic_params(ocfg, seed=21, std=0.06)
+    model = SonarTextTransformerEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32, fp16_residual=fp16_residual)
+    for n, lo, hi in ((5, 8, 64), (1, 3, 3), (40, 2, 30)):
+        ids, lens = O.synthetic_batch(n, lo, hi, ocfg.vocab_size, seed=n)
+        _, ref = O.text_encoder_forward(params, ocfg, ids, lens)
+        emb = model(SequenceBatch(ids.cuda(), PaddingMask(lens, ids.shape[1]))).sentence_embeddings
+        err = (1 - F.cosine_similarity(emb.float().cpu(), ref, dim=-1)).abs().max().item()
+        assert err <= 1e-3, (n, err)
+        assert (emb.float().cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item()
