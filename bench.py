@@ -424,7 +424,10 @@ def main():
                 "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_PEAK_TFLOPS if achieved else None, "traffic": traffic,
                 "traffic_source": traffic_src, "avg_launch_ms": ffn1_ms, "launches": ffn1["launches"],
-                "flops_per_launch": FFN1_FLOPS_PER_LAUNCH}
+                "flops_per_launch": FFN1_FLOPS_PER_LAUNCH,
+                "note": "since round 3 this kernel also applies the LayerNorm that precedes it (LayerNorm folded into the GEMMs, "
+                        "DESIGN.md 3.1: +2.6 % of its time, measured same-box, for 48 LayerNorm launches = 4.5 ms less per step; "
+                        "SMI_ENC_LNFOLD=0 restores the separate launches); `achieved` counts the GEMM's flops only"}
     kernels = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps} for k, v in prof.items()}
     # HBM-bound kernels of the step: algorithmic bytes per launch (fp16 residual stream and operands,
     # T = 131072 tokens, d = 1024) / mean HIP-event time of the launches inside the timed region

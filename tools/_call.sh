@@ -1,6 +1,4 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_fullsize.py tests/test_gpu_decoder.py tests/test_gpu_twin.py -m gpu -q -x -k "not speech" 2>&1 | tail -4
-bash tools/gpu_exp.sh r03t_c1 python tools/bench_c1.py -- "SMI_ENC_SB=0" "SMI_ENC_SB=1" "SMI_ENC_SB=0" "SMI_ENC_SB=1"
-bash tools/gpu_exp.sh r03t_b5 python tools/bench_c1.py 5 100 -- "SMI_ENC_SB=0" "SMI_ENC_SB=1"
-bash tools/gpu_exp.sh r03t_b128 python tools/bench_c1.py 128 30 -- "SMI_ENC_SB=0" "SMI_ENC_SB=1"
+V=$PWD/gpurun_variants
+bash tools/gpu_exp.sh r03v_enc python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-xsim --no-extras -- "SMI_ENC_LNFOLD=0" "SMI_ENC_LNFOLD=2" "SMI_LIB=$V/fold_plain.so" "SMI_ENC_LNFOLD=2" "SMI_LIB=$V/fold_plain.so"
