@@ -176,11 +176,6 @@ __device__ __forceinline__ float2 lds_read_f2_asm(const void* p) {
   asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
   return v;
 }
-__device__ __forceinline__ f32x4 lds_read_f4_asm(const void* p) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
-  return v;
-}
 // LDS stores the compiler does not see either (same reason: an ordinary LDS store after the fill has been issued is
 // guarded by vmcnt(0) -- write-after-write against the DMA as far as the alias tracking knows).  Completion: the
 // lgkmcnt(0) of SMI_LGKM0_BARRIER, which every staged pass runs before anyone reads.
@@ -489,9 +484,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           half8 o;
 #pragma unroll
           for (int i = 0; i < 8; ++i) o[i] = (f16)((float)oldv[mi][j][i] + c8[i]);
-#ifdef SMI_FOLD_PLAIN_STORE
-          if (emit) *(half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = o; else
-#endif
           store_nt((half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), o);
           if (emit) {
             // of the ROUNDED values (what the consuming GEMM will read), two per v_dot2_f32_f16: exact fp16 products,
