@@ -167,18 +167,12 @@ __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const
   }
 }
 
-// LDS reads the compiler must NOT see as LDS reads: after the next tile's LDS-DMA pipeline fill has been issued, hipcc
-// puts `s_waitcnt vmcnt(0)` in front of every ordinary LDS load (its alias tracking cannot tell the ring slots from the
-// small constant area these helpers read), which would drain the fill AND serialise the epilogue's global stores.
-// The caller waits with lds_wait(...), which carries the values as operands.
-__device__ __forceinline__ float2 lds_read_f2_asm(const void* p) {
-  float2 v;
-  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
-  return v;
-}
-// LDS stores the compiler does not see either (same reason: an ordinary LDS store after the fill has been issued is
-// guarded by vmcnt(0) -- write-after-write against the DMA as far as the alias tracking knows).  Completion: the
-// lgkmcnt(0) of SMI_LGKM0_BARRIER, which every staged pass runs before anyone reads.
+// LDS accesses the compiler must NOT see as LDS accesses: after the next tile's LDS-DMA pipeline fill has been issued,
+// hipcc guards every ordinary LDS load and store with `s_waitcnt vmcnt(0)` (its alias tracking cannot tell the ring slots
+// the fill is landing in from the staging buffers / constant area next to them), which drains the fill and serialises the
+// epilogue's global stores.  The staging buffers are ring slot 3 and the LDS above the ring -- never a target of the fill
+// -- so nothing has to be waited for.  Stores complete at the lgkmcnt(0) of SMI_LGKM0_BARRIER, which every staged pass
+// runs before anyone reads; loads are issued AND waited for in one asm statement (lds_read_stage).
 __device__ __forceinline__ void lds_write_f4_asm(void* p, f32x4 v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)p), "v"(v) : "memory");
 }
@@ -516,9 +510,12 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
         SMI_LGKM0_BARRIER();
         if (tid < 256) {
-          float2 a0 = lds_read_f2_asm(rowsum_lds + tid), a1 = lds_read_f2_asm(rowsum_lds + 256 + tid);
-          float2 a2 = lds_read_f2_asm(rowsum_lds + 512 + tid), a3 = lds_read_f2_asm(rowsum_lds + 768 + tid);
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+          float2 a0, a1, a2, a3;  // issue and wait in ONE statement (see lds_read_stage)
+          asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:2048\n\tds_read_b64 %2, %4 offset:4096\n\t"
+                       "ds_read_b64 %3, %4 offset:6144\n\ts_waitcnt lgkmcnt(0)"
+                       : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                       : "v"((unsigned)(size_t)(rowsum_lds + tid))
+                       : "memory");
           fold.part_out[(size_t)tile_n_cur * M + m0 + tid] = float2{(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y)};
         }
       }
