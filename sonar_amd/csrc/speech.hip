@@ -617,10 +617,17 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
   }
   stage(0, 0);
   half8 rf[4];  // the position rows of the NEXT block travel through the softmax / PV half of this one
+  // ... and the first key block's SECOND half (rho 32..63), requested here with everything else: loaded inside the
+  // `kb == 0` branch, hipcc issued the four 16-B loads one at a time, each behind its own `s_waitcnt vmcnt(0)`
+  // (one register quad, LDS-DMA in flight): four exposed memory latencies per workgroup, ~15 % of its life
+  half8 rf_hi[4];
   {
     const f16* rrow = rp_row(0, 0);
+    const f16* rrow1 = rp_row(0, 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rf[ks] = *(const half8*)(rrow + (ks * 2 + hi) * 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rf_hi[ks] = *(const half8*)(rrow1 + (ks * 2 + hi) * 8);
   }
 
   for (int j0 = 0, kb = 0; j0 < len; j0 += RA_KB, ++kb) {
@@ -655,12 +662,8 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
       f32x16 g;
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[r] = 0.f;
-      const f16* rrow = rp_row(0, 1);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const half8 r1 = *(const half8*)(rrow + (ks * 2 + hi) * 8);
-        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(r1, qv[ks], g, 0, 0, 0);
-      }
+      for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf_hi[ks], qv[ks], g, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Gold[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
     }
