@@ -1,5 +1,6 @@
-export TMPDIR=/tmp
-mkdir -p gpurun_out
-V=$PWD/gpurun_variants
-timeout 900 python -m pytest tests/test_gpu_speech.py tests/test_gpu_fullsize.py -m gpu -q -x -k "speech" 2>&1 | tail -3
-bash tools/gpu_exp.sh r03x_speech python tools/bench_speech.py -- "SMI_LIB=$V/prev.so" "SMI_X=1" "SMI_LIB=$V/prev.so" "SMI_X=1"
+bash tools/gpu_round.sh r03z pmc > gpurun_out/r03z_round.log 2>&1
+bash tools/gpu_prof_legs.sh r03z > gpurun_out/r03z_legs.log 2>&1
+python tools/bench_c1.py > gpurun_out/r03z_c1.log 2>&1
+python tools/bench_c1.py 5 100 >> gpurun_out/r03z_c1.log 2>&1
+python tools/bench_e2e.py > gpurun_out/r03z_e2e.log 2>&1
+tail -4 gpurun_out/r03z_pytest_gpu.log; tail -2 gpurun_out/r03z_smoke.log; head -8 gpurun_out/r03z_kernel_stats.txt; cat gpurun_out/r03z_mfma_util.txt | head -6; tail -3 gpurun_out/r03z_c1.log; tail -2 gpurun_out/r03z_e2e.log
