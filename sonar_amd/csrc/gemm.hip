@@ -781,251 +781,6 @@ extern "C" int smi_debug_gemm_trace(unsigned long long* host_out) {
 }
 #endif
 
-// ---- "duo" engine (round 3): the 256x256 engine's two row groups as INDEPENDENT workgroups ---------------------------
-// A K = 1024 tile of the 8-wave engine spends ~16 % of its time outside the K loop (tile-start drain + barrier, the
-// 16 x 1 KiB stores of every wave; r02 experiment 26: the stores alone are 9.5 % of the FFN-inner GEMM) and all 8 waves
-// of the CU are there at the same moment, so the matrix pipe idles.  Here a workgroup is 4 waves (one per SIMD) that own
-// a 128(m) x 256(n) tile -- exactly one row group of the big engine: the same 128 x 64 wave tile, the same 128
-// accumulator registers, the same 12 ds_read_b128 per 32 MFMAs -- and TWO such workgroups share a CU, started half a
-// tile apart: one workgroup's tile boundary falls into the other's K loop.  Each has its own 3-slot ring of K = 32
-// slices (X 8 KiB + W 16 KiB per slot, 72 KiB) with counted waits and one raw barrier per slice (the ring loop of
-// gemm_tile.hpp); the pair walks the same 256 x 256 tiles as the big engine (same XCD-owned raster), so the W panel is
-// fetched twice (from the XCD's L2, where the raster keeps it) and the X panel once.  The per-tile constants (bias or
-// c2, the fold's row partial sums) ride the same LDS-DMA queue as the pipeline fill: no registers held across the
-// epilogue, no conditional loads for hipcc to guard with vmcnt(0).
-// fp16 tile-major in / out (LAYOUT 2) with bias / relu and the centred LayerNorm fold only.
-constexpr int GD_BM = 128, GD_BN = 256, GD_THREADS = 256;
-constexpr int GD_SLOT_BYTES = (GD_BM + GD_BN) * G2_BK * 2;  // 24 KiB
-constexpr int GD_RING_BYTES = 3 * GD_SLOT_BYTES;            // 72 KiB
-constexpr int GD_LDS_BYTES = GD_RING_BYTES + 1024 + 4 * 1024;  // + c2 / bias slice + 4 row-partial slices (128 x float2)
-
-template <int EPI>
-__global__ __launch_bounds__(GD_THREADS, 2) void gemm_duo_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
-                                                                 const float* __restrict__ bias, f16* __restrict__ out,
-                                                                 int M, int N, int K, int raster, GemmLnFold fold,
-                                                                 int stagger) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const bool folded = fold.part_in != nullptr;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = column wave wc: columns wave * 64 .. + 63
-  const int l15 = lane & 15, kg = lane >> 4;
-  float* bias_lds = (float*)(smem + GD_RING_BYTES);           // bias (plain) or c2 (folded) of the tile's 256 columns
-  float2* stat_lds = (float2*)(smem + GD_RING_BYTES + 1024);  // [part][128 rows] (sum, sum of squares)
-  const float* colv = bias;                                   // folded: the caller passes c2 as the bias
-  if (!colv) bias_lds[tid] = 0.f;                             // published by the first tile-start barrier
-
-  // the pair (blockIdx, blockIdx + P) shares a 256 x 256 tile of the big engine's raster: rows h * 128 .. of it
-  const int P = gridDim.x >> 1;
-  const int h = blockIdx.x >= P;
-  const int ntm = M / G2_BM, ntn = N / G2_BN, nout = ntm * ntn;
-  const int nq = ntn / 4;
-  const int nvirt = raster ? ((ntm + 63) / 64) * nq * 256 : nout;
-  int tile_m = 0, tile_n = 0;
-  auto coords = [&](int t) -> bool {
-    if (raster == 0) {
-      g2_tile_coords_of(t, ntm, ntn, tile_m, tile_n);
-      return true;
-    }
-    const int q = t / 256, c = (t % 256) / 32, j = t % 32;
-    tile_m = (c + 8 * (q / nq)) * 8 + j % 8;
-    tile_n = ((q + (raster == 2 ? c : 0)) % nq) * 4 + j / 8;
-    return tile_m < ntm;
-  };
-  auto seek = [&](int t) {
-    while (t < nvirt && !coords(t)) t += P;
-    return t;
-  };
-  int tile = seek(xcd_remap(blockIdx.x - h * P, P));
-  if (tile >= nvirt) return;
-  if (h)
-    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
-
-  const int nt = K / G2_BK;
-  // DMA sources of this wave: X pieces 2 wave, 2 wave + 1 (of the tile's 8), W pieces 4 wave .. + 3 (of 16); a piece is
-  // 16 rows x 64 B = 1 KiB of a tile-major block, a slice of an operand TM_BLOCK elements further on
-  const f16* xg;
-  const f16* wg;
-  auto make_src = [&]() {
-    xg = X + (size_t)tile_m * (K >> 5) * TM_BLOCK + (h * 8 + wave * 2) * 512 + lane * 8;
-    wg = W + (size_t)tile_n * (K >> 5) * TM_BLOCK + wave * 4 * 512 + lane * 8;
-  };
-  auto issue = [&](int t) {
-    char* slot = smem + (t % 3) * GD_SLOT_BYTES;
-    const f16* xs = xg + (size_t)t * TM_BLOCK;
-    const f16* ws = wg + (size_t)t * TM_BLOCK;
-    glds16(xs, slot + wave * 2048);
-    glds16(xs + 512, slot + wave * 2048 + 1024);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(ws + q * 512, slot + GD_BM * G2_BK * 2 + wave * 4096 + q * 1024);
-  };
-  // tile constants + slices 0, 1, 2
-  auto prefetch = [&]() {
-    if (colv && wave == 0) glds16(colv + tile_n * G2_BN + lane * 4, bias_lds);
-    if (folded && wave < fold.nparts)
-      glds16(fold.part_in + (size_t)wave * M + tile_m * G2_BM + h * GD_BM + lane * 2, stat_lds + wave * 128);
-    issue(0);
-    issue(1);
-    issue(2);
-  };
-  make_src();
-  prefetch();
-
-  const int t_sw = (kg ^ tm_swz(l15)) << 4;
-  const int xoff = l15 * 64 + t_sw;
-  const int woff = GD_BM * G2_BK * 2 + (wave * 64 + l15) * 64 + t_sw;
-
-  while (tile < nvirt) {
-    const int m_blk = tile_m, n0 = tile_n * G2_BN;
-    // ---- tile start: the fill, the constants and the previous epilogue's stores retired; everyone's pieces in LDS ----
-    SMI_WAIT_VMCNT(0);
-    SMI_LGKM0_BARRIER();
-    GemmTile256Acc acc;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      f32x4 b = *(const f32x4*)(bias_lds + wave * 64 + ni * 16 + 4 * kg);
-      if (folded) b = f32x4{0.f, 0.f, 0.f, 0.f};  // c2 is added after the row scaling
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) acc.v[ni][mi] = b;
-    }
-    // fold: lane L keeps the (sum, sum of squares) of tile rows L and 64 + L and c2 of column wave * 64 + L (see the big
-    // engine: LDS may not be read once the next fill is in flight, so the epilogue fetches them with ds_bpermute)
-    float2 row_sq[2] = {{0.f, 0.f}, {0.f, 0.f}};
-    float col_c2 = 0.f;
-    if (folded) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        if (p < fold.nparts) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const float2 s = stat_lds[p * 128 + u * 64 + lane];
-            row_sq[u].x += s.x;
-            row_sq[u].y += s.y;
-          }
-        }
-      col_c2 = bias_lds[wave * 64 + lane];
-    }
-
-    // ---- K loop, software-pipelined inside the wave: interval t multiplies slice t from REGISTERS while it reads the
-    // fragments of slice t + 1 from LDS (the X fragment of row block mi right after that block's 4 MFMAs, into the same
-    // registers; the 4 W fragments into a second set), so one wave alone keeps the matrix pipe fed and the partner
-    // workgroup's wave covers barriers and tile boundaries.  Ring of 3: slot of t + 1 is being read, t + 2 is landing
-    // (waited for at the end of the interval), t + 3 is issued into the slot slice t was read from in interval t - 1.
-    half8 fx[8], fwa[4], fwb[4];
-    {
-      const char* slot = smem;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) fwa[ni] = *(const half8*)(slot + woff + ni * 1024);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
-      SMI_LGKM0_BARRIER();  // slot 0 read by everyone: interval 0 may refill it
-    }
-    auto interval = [&](int t, half8 (&fw)[4], half8 (&fwn)[4]) {
-      // (the reads of the last interval fetch a slot nobody filled: unconditional, the values are never used)
-      const char* nslot = smem + ((t + 1) % 3) * GD_SLOT_BYTES;
-      if (t + 3 < nt) issue(t + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc.v[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[ni], fx[mi], acc.v[ni][mi], 0, 0, 0);
-        // the W fragments of the next slice go out behind the first MFMA group: hipcc waits for the LDS counter to drain
-        // in front of the interval's first MFMA (it cannot see that the barrier retired the previous interval's reads)
-        if (mi == 0) {
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) fwn[ni] = *(const half8*)(nslot + woff + ni * 1024);
-        }
-        fx[mi] = *(const half8*)(nslot + xoff + mi * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (t + 3 < nt) {
-        SMI_WAIT_VMCNT(6);  // my pieces of slice t + 2 landed; t + 3 stays in flight
-      } else {
-        SMI_WAIT_VMCNT(0);
-      }
-      SMI_LGKM0_BARRIER();
-    };
-    for (int t = 0; t < nt; t += 2) {
-      interval(t, fwa, fwb);
-      interval(t + 1, fwb, fwa);
-    }
-
-    // ---- next tile's fill behind this tile's epilogue (every wave retired its reads of the last slice before the last
-    // barrier, so the whole ring is free) ----
-    tile = seek(tile + P);
-    if (tile < nvirt) {
-      make_src();
-      prefetch();
-    }
-
-    // ---- epilogue: fp16 tile-major straight from the accumulators (the big engine's LAYOUT 2 store) ----
-    const int cidx = (kg & 1) * 2 + (kg >> 1);
-    const int sw = tm_swz(l15);
-    f16* lane0 = out + ((size_t)m_blk * (N >> 5) + (n0 >> 5) + wave * 2) * TM_BLOCK + (h * 128 + l15) * 32 + ((cidx ^ sw) << 3);
-    auto store_tile = [&](auto mode_tag) {
-      constexpr int MODE = decltype(mode_tag)::value;  // 0 plain, 2 centred fold: out = rstd * acc + c2
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      float rsall[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-      if constexpr (MODE == 2) {
-        float row_rs[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const float mean = row_sq[u].x * fold.inv_k;
-          const float var = fmaxf(row_sq[u].y * fold.inv_k - mean * mean, 0.f);
-          row_rs[u] = __builtin_amdgcn_rsqf(var + fold.eps);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-          rsall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(((mi & 3) * 16 + l15) * 4, __float_as_int(row_rs[mi >> 2])));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f32x4 c2v[2] = {};
-        if constexpr (MODE == 2) {
-#pragma unroll
-          for (int nl = 0; nl < 2; ++nl)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              c2v[nl][r] = __int_as_float(__builtin_amdgcn_ds_bpermute(((2 * j + nl) * 16 + 4 * kg + r) * 4, __float_as_int(col_c2)));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          uint32_t hw[2][2];
-#pragma unroll
-          for (int nl = 0; nl < 2; ++nl) {
-            f32x4 v = acc.v[2 * j + nl][mi];
-            if constexpr (MODE == 2) {
-              const f32x2 rs2 = {rsall[mi], rsall[mi]};
-#pragma unroll
-              for (int hp2 = 0; hp2 < 2; ++hp2) {
-                const f32x2 c2p = {c2v[nl][2 * hp2], c2v[nl][2 * hp2 + 1]};
-                f32x2 vp = {v[2 * hp2], v[2 * hp2 + 1]};
-                vp = __builtin_elementwise_fma(rs2, vp, c2p);
-                v[2 * hp2] = vp[0];
-                v[2 * hp2 + 1] = vp[1];
-              }
-            }
-            const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(v));
-            hw[nl][0] = hp.x;
-            hw[nl][1] = hp.y;
-          }
-          const auto s0 = __builtin_amdgcn_permlane16_swap(hw[0][0], hw[1][0], false, false);
-          const auto s1 = __builtin_amdgcn_permlane16_swap(hw[0][1], hw[1][1], false, false);
-          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-          store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
-        }
-      }
-    };
-    if (folded)
-      store_tile(std::integral_constant<int, 2>{});
-    else
-      store_tile(std::integral_constant<int, 0>{});
-  }
-}
-
 static int num_cus() {
   static std::atomic<int> cached[64];
   const int dev = DeviceOnce::dev();
@@ -1062,46 +817,6 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
                      stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0}, ksplit,
                      part_stride, raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0});
   return hipGetLastError();
-}
-
-// SMI_G2_DUO=n (n >= 1): route the fp16 tile-major bias / relu GEMMs of full grids through the duo engine, the second
-// workgroup of a CU started n x ~4 us late; 0 = the 8-wave engine -- A/B switch
-static int g2_duo() {
-  static const int v = [] {
-    const char* e = getenv("SMI_G2_DUO");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
-template <int EPI>
-static hipError_t launch_duo(const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K,
-                             hipStream_t stream, const GemmLnFold* fold) {
-  static DeviceOnce attr_done;
-  if (!attr_done.done()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_duo_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       GD_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done.set();
-  }
-  static const int want_raster = [] {
-    const char* e = getenv("SMI_G2_RASTER");
-    return e ? atoi(e) : 2;
-  }();
-  const int ntm = M / G2_BM, ntn = N / G2_BN;
-  const int raster = (want_raster && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0) ? want_raster : 0;
-  hipLaunchKernelGGL((gemm_duo_kernel<EPI>), dim3(512), dim3(GD_THREADS), GD_LDS_BYTES, stream, X, W, bias, (f16*)out, M,
-                     N, K, raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0}, g2_duo());
-  return hipGetLastError();
-}
-// the duo engine takes: both operands and the fp16 output tile-major, >= 256 big tiles on a 256-CU chip, K a whole number
-// of slices >= 3, and -- folded -- the centred form
-static bool duo_takes(int M, int N, int K, const GemmLnFold* fold) {
-  if (g2_duo() <= 0 || num_cus() != 256) return false;
-  if (M % G2_BM || N % G2_BN || K % (2 * G2_BK) || K / G2_BK < 4) return false;  // an even number of slices, >= 4
-  if ((int64_t)(M / G2_BM) * (N / G2_BN) < 256) return false;
-  if (fold && fold->part_in && (!fold->centered || fold->nparts > 4)) return false;
-  return true;
 }
 
 // SMI_GT_RING: stages of the lone-tile ring (0 = never use it, 3, 4; default 4) -- A/B switch
@@ -1161,10 +876,6 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     if (!can256 || sel == 1 || !in_tm || !out_tm || stats) return hipErrorInvalidValue;
     if (fold->part_in) {
       if (!fold->c1 || fold->nparts < 1 || fold->nparts > 4) return hipErrorInvalidValue;
-      if (duo_takes(M, N, K, fold)) {
-        if (epi == EPI_BIAS_F16) return launch_duo<EPI_BIAS_F16>(X, W, bias, out, M, N, K, stream, fold);
-        if (epi == EPI_RELU_F16) return launch_duo<EPI_RELU_F16>(X, W, bias, out, M, N, K, stream, fold);
-      }
       if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
       if (epi == EPI_RELU_F16) return launch_one256<EPI_RELU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
       return hipErrorInvalidValue;
@@ -1182,10 +893,6 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \
                   : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
   if (out_tm) {  // fp16 outputs that feed the next GEMM; EPI_RESID_F16: the tile-major residual stream
-    if (sel == 0 && duo_takes(M, N, K, nullptr)) {
-      if (epi == EPI_BIAS_F16) return launch_duo<EPI_BIAS_F16>(X, W, bias, out, M, N, K, stream, nullptr);
-      if (epi == EPI_RELU_F16) return launch_duo<EPI_RELU_F16>(X, W, bias, out, M, N, K, stream, nullptr);
-    }
     switch (epi) {
       SMI_EPI_CASE(EPI_BIAS_F16, 2)
       SMI_EPI_CASE(EPI_RELU_F16, 2)
