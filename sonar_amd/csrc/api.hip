@@ -595,9 +595,9 @@ int smi_xsim_normalize(const void* src, int32_t src_dtype, int64_t rows, int32_t
   return SMI_OK;
 }
 
-int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k) {
-  if (nx <= 0 || ny <= 0 || k < 1 || k > 8) return 0;
-  return (int64_t)xsim_workspace_bytes(smi_xsim_padded_rows(nx), smi_xsim_padded_rows(ny), k);
+int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k, int32_t d) {
+  if (nx <= 0 || ny <= 0 || k < 1 || k > 8 || d <= 0) return 0;
+  return (int64_t)xsim_workspace_bytes(smi_xsim_padded_rows(nx), smi_xsim_padded_rows(ny), k, d);
 }
 
 int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_t d, int32_t k,

@@ -150,7 +150,7 @@ hipError_t launch_f16_to_f32(const f16* src, float* dst, size_t n, hipStream_t s
 // xsim: row-normalise then mine top-k cosine neighbours of each X row among Y rows.
 hipError_t launch_l2_normalize(const void* src, int src_is_f32, f16* dst, int64_t rows, int d,
                                hipStream_t stream);
-size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k);
+size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k, int d);
 hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16* Yn, int64_t ny,
                             int64_t ny_pad, int d, int k, int64_t y_index_offset, int32_t* idx,
                             float* score, void* workspace, hipStream_t stream);

@@ -11,6 +11,9 @@
 // its chunk.  The grouped XCD raster makes the ~64 workgroups resident on one
 // XCD an 8(x) x 8(chunk) block: its 8 X panels stay L2-resident for the whole
 // walk and every streamed Y tile is shared by 8 workgroups.
+#include <algorithm>
+#include <cstdlib>
+
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -130,7 +133,10 @@ __global__ __launch_bounds__(GT_THREADS, 2) void xsim_tile_kernel(const f16* __r
 // ALL y tiles of the chunk form one continuous DMA stream through the 4-slot LDS ring:
 // the pipeline is filled once per workgroup, not once per y tile; at every tile
 // boundary the accumulators are folded into the running top-k and cleared.
-template <int K>
+// TM: Xn / Yn are TILE-MAJOR copies (common.hpp; packed into the workspace by xsim_run): a K slice of an operand is one
+// contiguous 16 KiB block and the Y stream of a chunk one linear walk, instead of 256 pieces of 64 B a row apart -- the
+// layout that bought the GEMMs +7 % end to end and +26 % on the bare operand stream.
+template <int K, bool TM>
 __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __restrict__ Xn,
                                                                   const f16* __restrict__ Yn, int d,
                                                                   int ntx, int nty, int nchunks,
@@ -172,24 +178,38 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     const f16* yg[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int row = (wave * 2 + q) * 16 + (lane >> 2);
-      const int chunk16 = (lane & 3) ^ tm_swz(row);
-      xg[q] = Xn + (size_t)(m0 + row) * d + chunk16 * 8;
-      yg[q] = Yn + ((size_t)t_begin * G2_BN + row) * d + chunk16 * 8;
+      if constexpr (TM) {  // piece (wave * 2 + q) of a 16 KiB block: 16 rows x 64 B = 1 KiB, linear
+        xg[q] = Xn + (size_t)tile_m * nt * TM_BLOCK + (wave * 2 + q) * 512 + lane * 8;
+        yg[q] = Yn + (size_t)t_begin * nt * TM_BLOCK + (wave * 2 + q) * 512 + lane * 8;
+      } else {
+        const int row = (wave * 2 + q) * 16 + (lane >> 2);
+        const int chunk16 = (lane & 3) ^ tm_swz(row);
+        xg[q] = Xn + (size_t)(m0 + row) * d + chunk16 * 8;
+        yg[q] = Yn + ((size_t)t_begin * G2_BN + row) * d + chunk16 * 8;
+      }
     }
     int ik = 0, is = 0;
     auto issue = [&]() {
       char* slot = smem + (is & 3) * G2_SLOT_BYTES + wave * 2048;
-      const int koff = ik * G2_BK;
+      const size_t koff = TM ? (size_t)ik * TM_BLOCK : (size_t)ik * G2_BK;
       glds16(xg[0] + koff, slot);
       glds16(xg[1] + koff, slot + 1024);
-      glds16(yg[0] + koff, slot + G2_BM * G2_BK * 2);
-      glds16(yg[1] + koff, slot + G2_BM * G2_BK * 2 + 1024);
-      ++is;
-      if (++ik == nt) {
-        ik = 0;
-        yg[0] += (size_t)G2_BN * d;
-        yg[1] += (size_t)G2_BN * d;
+      if constexpr (TM) {  // block (tile, k) of Y sits at (tile * nt + k) * TM_BLOCK: the chunk's slices are consecutive
+        glds16(yg[0], slot + G2_BM * G2_BK * 2);
+        glds16(yg[1], slot + G2_BM * G2_BK * 2 + 1024);
+        yg[0] += TM_BLOCK;
+        yg[1] += TM_BLOCK;
+        ++is;
+        if (++ik == nt) ik = 0;
+      } else {
+        glds16(yg[0] + koff, slot + G2_BM * G2_BK * 2);
+        glds16(yg[1] + koff, slot + G2_BM * G2_BK * 2 + 1024);
+        ++is;
+        if (++ik == nt) {
+          ik = 0;
+          yg[0] += (size_t)G2_BN * d;
+          yg[1] += (size_t)G2_BN * d;
+        }
       }
     };
     const int t_sw = (kg ^ tm_swz(l15)) << 4;
@@ -251,6 +271,9 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
       SMI_BARRIER();
       if (++k == nt) {  // y tile finished: fold the 128x64 scores of this wave into the top-k
         k = 0;
+        // (a rewrite of this fold with v_permlane16/32_swap joins instead of the two ds_bpermute shuffles and v_max3_f32
+        // chains in asm instead of fmaxf measured 1.5 % SLOWER, r03 experiment 10: the fold runs in the wave's read segment
+        // under its SIMD partner's multiply segment and is not what the pipe waits for)
         float rowthr[8];
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
@@ -532,9 +555,23 @@ hipError_t launch_margin_select(const float* fs, const int32_t* fi, int64_t nx, 
 static int xsim_chunks(int64_t nty) { return (int)(nty < 8 ? nty : 8); }
 static int round_k(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8)); }
 
-size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k) {
-  const int K = round_k(k);
+// SMI_XSIM_TM=0: mine on the row-major normalised matrices (rounds 1-2) instead of tile-major copies -- A/B switch
+static bool xsim_tm() {
+  static const bool v = [] {
+    const char* e = getenv("SMI_XSIM_TM");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+// per-chunk partial lists: [chunks][nx_pad][K] scores + indices
+static size_t xsim_lists_bytes(int64_t nx_pad, int64_t ny_pad, int K) {
   return (size_t)xsim_chunks(ny_pad / GT_BN) * nx_pad * K * 8;
+}
+// ... followed (256x256 engine, k <= 4) by the tile-major copies of Xn and Yn
+size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k, int d) {
+  const int K = round_k(k);
+  const size_t tm = K <= 4 ? (size_t)(nx_pad + ny_pad) * d * sizeof(f16) : 0;
+  return xsim_lists_bytes(nx_pad, ny_pad, K) + tm;
 }
 
 template <int K>
@@ -555,7 +592,10 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
     // 256x256 tiles, continuous slice stream
     static DeviceOnce attr256_done;
     if (!attr256_done.done()) {
-      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K>,
+      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + 4096);
+      if (e != hipSuccess) return e;
+      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + 4096);
       if (e != hipSuccess) return e;
       attr256_done.set();
@@ -564,8 +604,25 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
     nchunks = xsim_chunks(nty);
     const int tpc = (nty + nchunks - 1) / nchunks;
     int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
-    hipLaunchKernelGGL(xsim_tile256_kernel<K>, dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
-                       stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+    if (xsim_tm()) {
+      // tile-major copies of both operands behind the partial lists (one pass over each: ~1.5 ms of the 1.8 s at 1 M x 1 M)
+      f16* xtm = (f16*)((char*)ws + xsim_lists_bytes(nx_pad, ny_pad, K));
+      f16* ytm = xtm + (size_t)nx_pad * d;
+      const f16* src[2] = {Xn, Yn};
+      f16* dst[2] = {xtm, ytm};
+      const int64_t rows[2] = {nx_pad, ny_pad};
+      for (int o = 0; o < 2; ++o)
+        for (int64_t r0 = 0; r0 < rows[o]; r0 += 65535LL * TM_ROWS) {  // grid.y limit of the pack kernel
+          const int64_t nr = std::min<int64_t>(rows[o] - r0, 65535LL * TM_ROWS);
+          e = launch_pack_tile_major(src[o] + r0 * d, dst[o] + r0 * d, (int)nr, d, 0, stream);
+          if (e != hipSuccess) return e;
+        }
+      hipLaunchKernelGGL((xsim_tile256_kernel<K, true>), dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
+                         stream, xtm, ytm, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+    } else {
+      hipLaunchKernelGGL((xsim_tile256_kernel<K, false>), dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
+                         stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+    }
   } else {
     const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
     nchunks = xsim_chunks(nty);

@@ -55,7 +55,7 @@ def topk_normalized(xn: torch.Tensor, nx: int, yn: torch.Tensor, ny: int, k: int
         raise ValueError("x and y must have the same dimension")
     if not 1 <= k <= 8:
         raise ValueError("k must be in [1, 8]")
-    ws_bytes = int(lib.smi_xsim_workspace_bytes(nx, ny, k))
+    ws_bytes = int(lib.smi_xsim_workspace_bytes(nx, ny, k, d))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xn.device)
     idx = torch.empty((nx, k), dtype=torch.int32, device=xn.device)
     score = torch.empty((nx, k), dtype=torch.float32, device=xn.device)
