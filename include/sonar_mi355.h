@@ -275,7 +275,7 @@ int smi_text_decoder_last_margins(smi_text_decoder* dec, float* out_margins, int
 /* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
  * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).
  * Per step: probs = softmax(logits / temperature) in fp32, pad -> 0, EOS -> 0 before min_seq_len,
- * EOS forced at max_seq_len - 1; TopKSampler keeps the k most probable tokens, TopPSampler the sorted
+ * probs[unk] -= unk_penalty (a result <= 0 removes the token), EOS forced at max_seq_len - 1; TopKSampler keeps the k most probable tokens, TopPSampler the sorted
  * prefix whose exclusive cumulative probability stays <= p; one token is drawn from the renormalised
  * kept set; the step score is log(probs[token]).  The draw is a counter-based hash of
  * (seed, sentence, step): a call is reproducible, and independent of the batch it runs in. */
@@ -291,6 +291,7 @@ typedef struct smi_sampling_params {
   int32_t normalize_scores; /* 1: score / (len - 1)^len_penalty */
   float len_penalty;        /* 1.0 */
   uint64_t seed;
+  float unk_penalty;        /* 0.0; subtracted from the PROBABILITY of the UNK token (fairseq2's sampling generator) */
 } smi_sampling_params;
 
 /* Outputs (device): out_tokens int32 [n, max_seq_len] generated tokens after the prompt incl. the final
@@ -306,8 +307,8 @@ int smi_text_decoder_sample(smi_text_decoder* dec, const void* emb, int32_t emb_
  * Q40 fixed point relative to exp(max scaled logit). */
 int smi_sample_rows(const float* logits, int64_t ld, int32_t rows, int32_t vocab, int32_t sampler, int32_t top_k,
                     float top_p, float temperature, int32_t pad_idx, int32_t eos_idx, int32_t block_eos,
-                    const uint64_t* z, int32_t* out_token, float* out_logprob, uint64_t* out_kept_mass,
-                    int32_t* out_kept_count, void* stream);
+                    int32_t unk_idx, float unk_penalty, const uint64_t* z, int32_t* out_token, float* out_logprob,
+                    uint64_t* out_kept_mass, int32_t* out_kept_count, void* stream);
 
 /* Speech encoder -------------------------------------------------------------------
  * Stands in for: WaveformToFbankConverter(num_mel_bins=80, waveform_scale=2**15,

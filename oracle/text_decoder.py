@@ -393,12 +393,15 @@ _MASK64 = (1 << 64) - 1
 
 
 def sampling_probs(logits: torch.Tensor, temperature: float = 1.0, pad_idx: int = 0, eos_idx: int = 3,
-                   block_eos: bool = False) -> torch.Tensor:
-    """probs = softmax(logits / T, fp32); pad (and EOS before min_len) zeroed, NOT renormalised."""
+                   block_eos: bool = False, unk_idx: int = 1, unk_penalty: float = 0.0) -> torch.Tensor:
+    """probs = softmax(logits / T, fp32); pad (and EOS before min_len) zeroed, probs[unk] -= unk_penalty
+    (fs2-recall; held at >= 0: a negative probability would make the reference's multinomial raise), NOT renormalised."""
     probs = torch.softmax(logits.float() / temperature, dim=-1, dtype=torch.float32).clone()
     probs[..., pad_idx] = 0.0
     if block_eos:
         probs[..., eos_idx] = 0.0
+    if unk_penalty != 0.0:
+        probs[..., unk_idx] = torch.clamp(probs[..., unk_idx] - unk_penalty, min=0.0)
     return probs
 
 
@@ -417,21 +420,26 @@ def top_k_mask(probs: torch.Tensor, k: int) -> torch.Tensor:
 
 
 def sample_filter(logits: torch.Tensor, sampler: Tuple[str, float], temperature: float = 1.0, pad_idx: int = 0,
-                  eos_idx: int = 3, block_eos: bool = False) -> torch.Tensor:
+                  eos_idx: int = 3, block_eos: bool = False, unk_idx: int = 1, unk_penalty: float = 0.0) -> torch.Tensor:
     """Kept set of one sampling step ([..., V] bool; masked tokens are never kept)."""
-    probs = sampling_probs(logits, temperature, pad_idx, eos_idx, block_eos)
+    probs = sampling_probs(logits, temperature, pad_idx, eos_idx, block_eos, unk_idx, unk_penalty)
+    unk_dead = unk_penalty != 0.0 and bool((probs[..., unk_idx] <= 0).all())
     if sampler[0] == "top_k":
         # rank the maskable tokens last even when their zero ties with underflowed probabilities
         ranked = probs.clone()
         ranked[..., pad_idx] = -1.0
         if block_eos:
             ranked[..., eos_idx] = -1.0
+        if unk_dead:
+            ranked[..., unk_idx] = -1.0
         keep = top_k_mask(ranked, int(sampler[1]))
     else:
         keep = top_p_mask(probs, float(sampler[1]))
     keep[..., pad_idx] = False
     if block_eos:
         keep[..., eos_idx] = False
+    if unk_dead:
+        keep[..., unk_idx] = False
     return keep
 
 
@@ -443,14 +451,19 @@ def splitmix_word(seed: int, row: int, step: int) -> int:
     return z ^ (z >> 31)
 
 
-def q40_masses(logits: torch.Tensor, temperature: float = 1.0):
-    """Integer token masses floor(exp(l/T - max) * 2^40) of one row (numpy uint64) and the max."""
+def q40_masses(logits: torch.Tensor, temperature: float = 1.0, unk_idx: int = 1, unk_penalty: float = 0.0):
+    """Integer token masses floor(exp(l/T - max) * 2^40) of one row (numpy uint64) and the max; with an UNK penalty
+    mass[unk] -= int(penalty * Z) (never below 0), Z = the sum of the untouched masses (csrc/sampling.hip)."""
     import numpy as np
 
     t = (logits.float() * np.float32(1.0 / temperature)).numpy().astype(np.float32)
     m = t.max()
     e = np.exp2(((t - m) * np.float32(1.4426950408889634)).astype(np.float32)).astype(np.float32)
-    return (e * np.float32(2.0 ** 40)).astype(np.uint64), float(m)
+    w = (e * np.float32(2.0 ** 40)).astype(np.uint64)
+    if unk_penalty != 0.0:
+        z = int(w.astype(object).sum())
+        w[unk_idx] = max(int(w[unk_idx]) - int(float(np.float32(unk_penalty)) * float(z)), 0)
+    return w, float(m)
 
 
 def sample_draw(masses, keep, z: int) -> Tuple[int, float]:
@@ -478,7 +491,8 @@ def sampling_generate(params, cfg: OracleTextDecoderConfig, embeddings: torch.Te
                       sampler: Tuple[str, float], seed: int, min_gen_len: int = 1,
                       max_gen_len: Tuple[int, int] = (1, 128), max_seq_len: Optional[int] = None,
                       normalize_scores: bool = True, len_penalty: float = 1.0, temperature: float = 1.0,
-                      pad_idx: int = 0, eos_idx: int = 3, row_offset: int = 0, source_len: Optional[int] = None):
+                      pad_idx: int = 0, eos_idx: int = 3, row_offset: int = 0, source_len: Optional[int] = None,
+                      unk_idx: int = 1, unk_penalty: float = 0.0):
     """SamplingSeq2SeqGenerator, one hypothesis per embedding; sampler = ("top_k", k) | ("top_p", p).
     Returns [(tokens after the prompt, score, step log-probs)] per embedding."""
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
@@ -501,9 +515,11 @@ def sampling_generate(params, cfg: OracleTextDecoderConfig, embeddings: torch.Te
             if step_nr == max_len - 1:
                 tok = eos_idx
             else:
-                keep = sample_filter(logits, sampler, temperature, pad_idx, eos_idx, block_eos=step_nr < min_len)
-                masses, _ = q40_masses(logits, temperature)
+                keep = sample_filter(logits, sampler, temperature, pad_idx, eos_idx, step_nr < min_len, unk_idx, unk_penalty)
+                masses, _ = q40_masses(logits, temperature, unk_idx, unk_penalty)
                 tok, _ = sample_draw(masses, keep.numpy(), splitmix_word(seed, row_offset + r, step_nr))
+                if unk_penalty != 0.0 and tok == unk_idx:   # the step score is log(probs[token]) of the penalised probs
+                    lprobs = torch.log(sampling_probs(logits, temperature, pad_idx, eos_idx, False, unk_idx, unk_penalty))
             seq.append(tok)
             cum += float(lprobs[tok])
             steps.append(float(lprobs[tok]))

@@ -182,6 +182,7 @@ class smi_sampling_params(C.Structure):
         ("normalize_scores", C.c_int32),
         ("len_penalty", C.c_float),
         ("seed", C.c_uint64),
+        ("unk_penalty", C.c_float),
     ]
 
 
@@ -258,8 +259,8 @@ SYMBOLS = {
     "smi_text_decoder_last_margins": (C.c_int, [_vp, _vp, _i32, _vp]),
     "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                           C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
-    "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _vp, _vp, _vp,
-                                  _vp, _vp, _vp]),
+    "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp,
+                                  _vp, _vp, _vp, _vp, _vp]),
     "smi_speech_encoder_create": (C.c_int, [C.POINTER(smi_speech_encoder_config),
                                             C.POINTER(smi_speech_encoder_weights), C.POINTER(_vp)]),
     "smi_speech_encoder_destroy": (None, [_vp]),

@@ -575,6 +575,7 @@ int smi_text_decoder_sample(smi_text_decoder* D, const void* emb, int32_t emb_dt
     a.logits = D->logits.as<float>(); a.ld = D->vocab_pad; a.rows = n; a.vocab = (int)c.vocab_size;
     a.inv_temp = 1.0f / sp->temperature; a.pad_idx = c.pad_idx; a.eos_idx = c.eos_idx;
     a.block_eos = !forced_prompt && !force_eos && step_nr < min_len;
+    a.unk_idx = c.unk_idx; a.unk_penalty = sp->unk_penalty;
     a.forced_tok = forced_prompt ? (int)prompt[step_nr] : (force_eos ? c.eos_idx : -1);
     a.mode = sp->sampler; a.top_k = sp->top_k; a.top_p = sp->top_p; a.z = nullptr; a.seed = sp->seed; a.step = step_nr;
     a.done = D->done.as<int32_t>(); a.out_tok = D->new_tok.as<int32_t>(); a.out_logp = D->new_cum.as<float>();

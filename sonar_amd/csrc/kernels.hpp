@@ -241,6 +241,8 @@ struct SampleRowsArgs {
   int rows, vocab;
   float inv_temp;
   int pad_idx, eos_idx, block_eos;
+  int unk_idx;        // with unk_penalty != 0: probs[unk] -= unk_penalty before the filter (never below 0: masked then)
+  float unk_penalty;
   int forced_tok;  // >= 0: no draw, the token is given (prompt forcing, forced EOS)
   int mode, top_k;
   float top_p;

@@ -3,6 +3,7 @@
 //   sonar/inference_pipelines/text.py:315-320 builds fairseq2's SamplingSeq2SeqGenerator with a
 //   TopKSampler / TopPSampler; their published behaviour (fairseq2 ~= 0.4, un-vendored):
 //     probs = softmax(logits / temperature, fp32); probs[pad] = 0; probs[eos] = 0 before min_len;
+//     probs[unk] -= unk_penalty;
 //     top-p: sort descending, keep rank r while (cumsum - prob)[r] <= p; top-k: keep the k largest;
 //     renormalise the kept set, draw one token; step score = log(probs[token]) (not renormalised).
 // Arithmetic: a token's mass is exp(l/T - M) in Q40 fixed point (u64), so every sum is an integer and
@@ -96,7 +97,15 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
   const int V = a.vocab;
   const int niter = (V + SMP_THREADS * 4 - 1) / (SMP_THREADS * 4);
   const float it = a.inv_temp;
-  auto masked = [&](int idx) { return idx == a.pad_idx || (a.block_eos && idx == a.eos_idx); };
+  // UNK penalty (probs[unk] -= unk_penalty, in the Q40 domain: mass[unk] -= floor(penalty * Z)): the token keeps an exact
+  // integer mass w_unk and takes the rank of a logit with that mass; a mass <= 0 leaves the kept set like pad.
+  const bool pen = a.unk_penalty != 0.f && a.forced_tok < 0 && a.unk_idx >= 0 && a.unk_idx < V;
+  bool unk_dead = false;
+  u64 w_unk = 0;
+  uint32_t key_unk = 0;
+  auto masked = [&](int idx) {
+    return idx == a.pad_idx || (a.block_eos && idx == a.eos_idx) || (unk_dead && idx == a.unk_idx);
+  };
   // element visitor: f(idx, raw logit) for every idx < V this thread owns (iteration-major, coalesced)
   auto for_each = [&](auto&& f) {
     for (int i0 = 0; i0 < niter; i0 += 4) {  // four 16-B loads in flight per thread
@@ -126,6 +135,24 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
 #pragma unroll
   for (int w = 1; w < SMP_WAVES; ++w) M = fmaxf(M, s_f[w]);
 
+  u64 z_orig = 0;
+  if (pen) {  // Z of the untouched distribution first (one more pass over the row, this mode only)
+    u64 zloc = 0;
+    for_each([&](int, float v) { zloc += smp_mass(v * it - M); });
+    (void)block_scan_excl(zloc, s_w, &z_orig);
+    const u64 w0 = smp_mass(lg[a.unk_idx] * it - M);
+    const double d = (double)a.unk_penalty * (double)z_orig;
+    const long long delta = (long long)d;  // toward zero, as the oracle's int()
+    const long long w1 = (long long)w0 - delta;
+    unk_dead = w1 <= 0;
+    w_unk = unk_dead ? 0 : (u64)w1;
+    // rank: the logit whose softmax mass is w_unk (approximate; only its ORDER among the other tokens is used)
+    key_unk = smp_key((__logf((float)w_unk * (1.0f / 1099511627776.0f)) + M) / it);
+    __syncthreads();
+  }
+  auto mass_of = [&](int idx, float v) { return (pen && idx == a.unk_idx) ? w_unk : smp_mass(v * it - M); };
+  auto key_of = [&](int idx, float v) { return (pen && idx == a.unk_idx) ? key_unk : smp_key(v); };
+
   if (a.forced_tok >= 0) {  // prompt forcing / forced EOS: only the step score is needed
     u64 zloc = 0, zf;
     for_each([&](int, float v) { zloc += smp_mass(v * it - M); });
@@ -152,10 +179,10 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
     __syncthreads();
     u64 zloc = 0;
     for_each([&](int idx, float v) {
-      const u64 w = smp_mass(v * it - M);
-      if (level == 0) zloc += w;
+      if (level == 0) zloc += smp_mass(v * it - M);  // Z: the untouched distribution (the reference does not renormalise)
       if (masked(idx)) return;
-      const uint32_t key = smp_key(v);
+      const u64 w = mass_of(idx, v);
+      const uint32_t key = key_of(idx, v);
       if (level > 0 && (key >> (shift + bits)) != prefix) return;
       const int b = (key >> shift) & ((1 << bits) - 1);
       atomicAdd(&h_mass[b], w);
@@ -237,10 +264,10 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
       }
       __syncthreads();
       for_each([&](int idx, float v) {
-        if (masked(idx) || smp_key(v) != kstar) return;
+        if (masked(idx) || key_of(idx, v) != kstar) return;
         if (level == 1 && (uint32_t)(idx >> 9) != idp) return;
         atomicAdd(&h_cnt[(idx >> shift) & 511], 1u);
-        atomicAdd(&h_mass[1024 + ((idx >> shift) & 511)], smp_mass(v * it - M));
+        atomicAdd(&h_mass[1024 + ((idx >> shift) & 511)], mass_of(idx, v));
       });
       __syncthreads();
       // thread t < 512 owns bucket t (ascending ids)
@@ -276,14 +303,14 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
   // ---- F. draw: integer target in [0, kept_mass); order = thread-major over the coalesced ownership
   auto kept = [&](int idx, float v) {
     if (masked(idx)) return false;
-    const uint32_t key = smp_key(v);
+    const uint32_t key = key_of(idx, v);
     return key > kstar || (key == kstar && idx <= id_thr);
   };
   const u64 zr = a.z ? a.z[row] : smp_hash(a.seed, row, a.step);
   const u64 target = __umul64hi(zr, kept_mass);
   u64 mine = 0;
   for_each([&](int idx, float v) {
-    if (kept(idx, v)) mine += smp_mass(v * it - M);
+    if (kept(idx, v)) mine += mass_of(idx, v);
   });
   u64 tot;
   const u64 ex = block_scan_excl(mine, s_w, &tot);
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (e0 + c < V && kept(e0 + c, v[c])) {
-          w4[c] = smp_mass(v[c] * it - M);
+          w4[c] = mass_of(e0 + c, v[c]);
           wsum += w4[c];
         }
     }
@@ -316,7 +343,8 @@ __global__ __launch_bounds__(SMP_THREADS) void sample_rows_kernel(SampleRowsArgs
       for (int c = 0; c < 4; ++c) {
         if (w4[c] > 0 && run <= target && target < run + w4[c]) {
           a.out_tok[row] = e0 + c;
-          a.out_logp[row] = (v[c] * it - M) - logz;
+          a.out_logp[row] = (pen && e0 + c == a.unk_idx) ? __logf((float)w_unk * (1.0f / 1099511627776.0f)) - logz
+                                                        : (v[c] * it - M) - logz;
         }
         run += w4[c];
       }
@@ -367,8 +395,9 @@ hipError_t launch_sample_rows(const SampleRowsArgs& a, hipStream_t stream) {
 
 extern "C" int smi_sample_rows(const float* logits, int64_t ld, int32_t rows, int32_t vocab, int32_t sampler,
                                int32_t top_k, float top_p, float temperature, int32_t pad_idx, int32_t eos_idx,
-                               int32_t block_eos, const uint64_t* z, int32_t* out_token, float* out_logprob,
-                               uint64_t* out_kept_mass, int32_t* out_kept_count, void* stream) {
+                               int32_t block_eos, int32_t unk_idx, float unk_penalty, const uint64_t* z,
+                               int32_t* out_token, float* out_logprob, uint64_t* out_kept_mass, int32_t* out_kept_count,
+                               void* stream) {
   if (!logits || !z || !out_token || !out_logprob) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (rows <= 0 || vocab <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
   if (vocab > (1 << 18)) return fail(SMI_ERR_UNSUPPORTED, "vocab %d: sampling covers up to 2^18 tokens", vocab);
@@ -385,6 +414,7 @@ extern "C" int smi_sample_rows(const float* logits, int64_t ld, int32_t rows, in
   SampleRowsArgs a{};
   a.logits = logits; a.ld = ld; a.rows = rows; a.vocab = vocab; a.inv_temp = 1.0f / temperature;
   a.pad_idx = pad_idx; a.eos_idx = eos_idx; a.block_eos = block_eos; a.forced_tok = -1;
+  a.unk_idx = unk_idx; a.unk_penalty = unk_penalty;
   a.mode = sampler; a.top_k = top_k; a.top_p = top_p; a.z = (const unsigned long long*)z;
   a.out_tok = out_token; a.out_logp = out_logprob; a.out_kept_mass = (unsigned long long*)out_kept_mass;
   a.out_kept_count = out_kept_count;

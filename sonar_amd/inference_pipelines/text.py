@@ -241,7 +241,8 @@ class EmbeddingToTextModelPipeline(torch.nn.Module):
     """sonar/inference_pipelines/text.py:270-346 on the MI355X engine: embeddings -> texts by
     beam search (fairseq2 BeamSearchSeq2SeqGenerator defaults; `generator_kwargs` accepts
     beam_size, min_gen_len, max_gen_len, max_seq_len, normalize_scores, len_penalty,
-    unk_penalty, temperature).  Sampling generators are not covered."""
+    unk_penalty, temperature), or -- with `sampler=TopKSampler(k) / TopPSampler(p)` (sonar_amd.generation) -- by
+    fairseq2's SamplingSeq2SeqGenerator (same kwargs minus beam_size)."""
 
     def __init__(self, decoder, tokenizer: Union[str, Path, NllbTokenizer], device: torch.device = CPU,
                  dtype: Optional[torch.dtype] = None) -> None:

@@ -295,14 +295,13 @@ class TextDecoderEngine:
                source_len: Optional[int] = None):
         """fairseq2's SamplingSeq2SeqGenerator (one hypothesis per sentence) with a TopKSampler /
         TopPSampler (sonar_amd.generation).  Returns (tokens int32 [n, L] (-1 padded), lens int32 [n],
-        scores fp32 [n]).  `seed` None draws one from torch's global CPU generator, so
+        scores fp32 [n]).  `unk_penalty` is subtracted from the UNK token's probability before the filter, as the
+        reference's generator does.  `seed` None draws one from torch's global CPU generator, so
         `torch.manual_seed` makes a run repeatable as it does for the reference; the random stream of a
         sentence depends on (seed, sentence_offset + its index, step) only, not on the batch."""
         from .generation import resolve_sampler
 
         kind, k, p = resolve_sampler(sampler)
-        if unk_penalty != 0.0:
-            raise NotImplementedError("unk_penalty is not covered by the sampling path of the MI355X engine")
         e = self._emb(embeddings)
         n = e.shape[0]
         plen = len(prompt)
@@ -312,7 +311,7 @@ class TextDecoderEngine:
         seed = (int(seed) + 0x9E3779B97F4A7C15 * 65536 * int(sentence_offset)) & 0xFFFFFFFFFFFFFFFF
         sp = _lib.smi_sampling_params(sampler=kind, top_k=k, top_p=p, temperature=temperature, max_seq_len=max_len,
                                       min_seq_len=min_len, normalize_scores=1 if normalize_scores else 0,
-                                      len_penalty=len_penalty, seed=seed)
+                                      len_penalty=len_penalty, seed=seed, unk_penalty=unk_penalty)
         toks = torch.empty((n, max_len), dtype=torch.int32, device=self.device)
         lens = torch.empty((n,), dtype=torch.int32, device=self.device)
         scores = torch.empty((n,), dtype=torch.float32, device=self.device)

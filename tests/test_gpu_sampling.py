@@ -11,7 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _sample_rows(logits, sampler, z, temperature=1.0, pad=0, eos=3, block_eos=False):
+def _sample_rows(logits, sampler, z, temperature=1.0, pad=0, eos=3, block_eos=False, unk=1, unk_penalty=0.0):
     from sonar_amd import _lib
 
     lib = _lib.load()
@@ -28,7 +28,7 @@ def _sample_rows(logits, sampler, z, temperature=1.0, pad=0, eos=3, block_eos=Fa
     kind = _lib.SMI_SAMPLER_TOP_K if sampler[0] == "top_k" else _lib.SMI_SAMPLER_TOP_P
     _lib.check(lib.smi_sample_rows(buf.data_ptr(), ld, rows, v, kind, int(sampler[1]) if kind == 0 else 1,
                                    float(sampler[1]) if kind == 1 else 1.0, temperature, pad, eos, int(block_eos),
-                                   zt.data_ptr(), tok.data_ptr(), lp.data_ptr(), mass.data_ptr(), cnt.data_ptr(),
+                                   unk, unk_penalty, zt.data_ptr(), tok.data_ptr(), lp.data_ptr(), mass.data_ptr(), cnt.data_ptr(),
                                    _lib.current_stream_ptr()))
     torch.cuda.synchronize()
     return tok.cpu().tolist(), lp.cpu(), mass.cpu().tolist(), cnt.cpu().tolist()
@@ -101,6 +101,43 @@ def test_value_ties_at_the_threshold_keep_the_lowest_ids():
     tok, _, _, cnt = _sample_rows(flat[:50], ("top_p", 0.5), z[:50])
     # exclusive mass i/64 <= 0.5 over the 63 unmasked tokens in id order (pad's 1/64 stays in the normaliser)
     assert set(cnt) == {33} and max(tok) <= 33 and min(tok) >= 1
+
+
+def test_unk_penalty_lowers_the_unk_probability():
+    """probs[unk] -= unk_penalty before the filter (fairseq2's sampling generator; fs2-recall): the kept set, its
+    integer mass, the draw and the step score against the oracle, incl. a penalty that removes the token."""
+    from oracle import text_decoder as OD
+
+    g = torch.Generator().manual_seed(31)
+    logits = torch.randn(16, 3001, generator=g) * 2.0
+    logits[:, 1] = logits.max(dim=-1).values + 1.0          # UNK is the most probable token of every row
+    z = [OD.splitmix_word(7, r, 2) for r in range(16)]
+    p_unk = torch.softmax(logits, -1)[:, 1]
+    for sampler in (("top_k", 4), ("top_p", 0.7)):
+        for pen in (0.05, float(p_unk.min()) * 0.5, 2.0, -0.1):
+            tok, lp, mass, cnt = _sample_rows(logits, sampler, z, unk_penalty=pen)
+            checked = 0
+            for r in range(16):
+                probs = OD.sampling_probs(logits[r], unk_penalty=pen)
+                masses, _ = OD.q40_masses(logits[r], unk_penalty=pen)
+                keep = OD.sample_filter(logits[r], sampler, unk_penalty=pen).numpy()
+                if sampler[0] == "top_p":          # the nucleus edge: judge the draw on the engine's own count
+                    keep = OD.sample_filter(logits[r], ("top_k", cnt[r]), unk_penalty=pen).numpy()
+                if pen >= 1.0:
+                    assert tok[r] != 1 and not keep[1]
+                assert cnt[r] == int(keep.sum()), (sampler, pen, r, cnt[r], int(keep.sum()))
+                want_mass = int(masses[keep].astype(object).sum())
+                assert abs(mass[r] - want_mass) <= 4e-6 * want_mass + 64
+                assert lp[r].item() == pytest.approx(float(torch.log(probs[tok[r]])), abs=3e-4)
+                want_tok, margin = OD.sample_draw(masses, keep, z[r])
+                if margin > 2e-6:
+                    assert tok[r] == want_tok, (sampler, pen, r, tok[r], want_tok)
+                    checked += 1
+            assert checked >= 8
+    # the penalty moves the draw: with top-1 the UNK (most probable) is drawn without it and cannot be once it is removed
+    tok0, *_ = _sample_rows(logits, ("top_k", 1), z)
+    tok1, *_ = _sample_rows(logits, ("top_k", 1), z, unk_penalty=2.0)
+    assert set(tok0) == {1} and 1 not in tok1
 
 
 def test_draw_frequencies_follow_the_kept_probabilities():
