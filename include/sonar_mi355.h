@@ -487,6 +487,12 @@ int smi_host_collate_nllb(const int32_t* pieces, const int64_t* piece_offsets, c
  * writes float32 [frames, channels] (channel-last, integer PCM scaled by 2^-(bits-1)). */
 int smi_host_wav_info(const uint8_t* bytes, int64_t nbytes, int32_t* channels, int32_t* sample_rate, int64_t* frames);
 int smi_host_wav_decode(const uint8_t* bytes, int64_t nbytes, float* out, int64_t frames, int32_t channels);
+/* The same pair for any covered container, sniffed from the file image: RIFF/WAVE as above, or a native FLAC stream
+ * (RFC 9639: every block-size / sample-size code, constant / verbatim / fixed / LPC subframes, Rice and Rice2
+ * residuals, wasted bits, left-side / side-right / mid-side stereo, 4-32 bits per sample, header CRC-8 and frame
+ * CRC-16 verified; an ID3v2 tag in front is skipped).  Ogg encapsulation returns SMI_ERR_UNSUPPORTED. */
+int smi_host_audio_info(const uint8_t* bytes, int64_t nbytes, int32_t* channels, int32_t* sample_rate, int64_t* frames);
+int smi_host_audio_decode(const uint8_t* bytes, int64_t nbytes, float* out, int64_t frames, int32_t channels);
 
 /* Building blocks (exported for the parity tests and microbenchmarks) ------ */
 /* TILE-MAJOR operand layout (SMI_GEMM_IN_TM / SMI_GEMM_OUT_TM, `tile_major` arguments): a K-major

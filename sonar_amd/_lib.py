@@ -284,6 +284,8 @@ SYMBOLS = {
     "smi_host_collate_nllb": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _i32, _i32, _i64, _vp, _i32, _i32]),
     "smi_host_wav_info": (C.c_int, [_vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "smi_host_wav_decode": (C.c_int, [_vp, _i64, _vp, _i64, _i32]),
+    "smi_host_audio_info": (C.c_int, [_vp, _i64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "smi_host_audio_decode": (C.c_int, [_vp, _i64, _vp, _i64, _i32]),
     "smi_pack_tile_major": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "smi_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),

@@ -12,8 +12,9 @@ launch per batch that already writes the collated, padded [n, T, 80] tensor, con
 attention pooler) runs on the caller's thread and stream, as the model does in the reference.
 
 Audio decoding: the reference uses fairseq2n's libsndfile AudioDecoder (speech.py:292-308);
-libsndfile is not in this image, so RIFF/WAVE (PCM 8/16/24/32, float 32/64, extensible) is decoded
-by the engine's own host code (`smi_host_wav_decode`); other containers raise a ValueError.
+libsndfile is not in this image, so RIFF/WAVE (PCM 8/16/24/32, float 32/64, extensible) and native FLAC
+streams are decoded by the engine's own host code (`smi_host_audio_decode`: csrc/host_input.cpp,
+csrc/host_audio.cpp); other containers (Ogg, MP3, ...) raise a ValueError.
 """
 from __future__ import annotations
 
@@ -36,19 +37,22 @@ from .utils import add_progress_bar
 CPU = torch.device("cpu")
 
 
-def decode_wav_bytes(data: bytes, name: str = "<bytes>") -> Tuple[torch.Tensor, int]:
-    """WAV file image -> (float32 [frames, channels] in [-1, 1), sample rate), decoded by the engine's host code."""
+def decode_audio_bytes(data: bytes, name: str = "<bytes>") -> Tuple[torch.Tensor, int]:
+    """WAV or FLAC file image -> (float32 [frames, channels] in [-1, 1), sample rate), decoded by the engine's host code."""
     lib = _lib.load()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     ch, rate, frames = C.c_int32(0), C.c_int32(0), C.c_int64(0)
     try:
-        _lib.check(lib.smi_host_wav_info(buf, len(data), C.byref(ch), C.byref(rate), C.byref(frames)))
+        _lib.check(lib.smi_host_audio_info(buf, len(data), C.byref(ch), C.byref(rate), C.byref(frames)))
         out = torch.empty((frames.value, ch.value), dtype=torch.float32)
         if frames.value:
-            _lib.check(lib.smi_host_wav_decode(buf, len(data), C.c_void_p(out.data_ptr()), frames.value, ch.value))
+            _lib.check(lib.smi_host_audio_decode(buf, len(data), C.c_void_p(out.data_ptr()), frames.value, ch.value))
     except _lib.SmiError as e:
         raise ValueError(f"{name}: {e}") from None
     return out, int(rate.value)
+
+
+decode_wav_bytes = decode_audio_bytes  # the name of rounds 1-2
 
 
 def read_wav(path: Union[str, Path]) -> torch.Tensor:
@@ -56,7 +60,7 @@ def read_wav(path: Union[str, Path]) -> torch.Tensor:
     (the reference asserts it in its tests, test_sonar_speech_pipeline_models.py:25-26)."""
     with open(str(path), "rb") as fh:
         data = fh.read()
-    wav, rate = decode_wav_bytes(data, str(path))
+    wav, rate = decode_audio_bytes(data, str(path))
     if rate != 16000:
         raise ValueError(f"{path}: sample rate {rate}, the SONAR speech encoders expect 16 kHz audio")
     return wav.t().contiguous()

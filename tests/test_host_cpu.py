@@ -72,7 +72,11 @@ def test_wav_decode_matches_stdlib_on_the_reference_clips(tmp_path):
     with pytest.raises(ValueError, match="16 kHz"):
         read_wav(p)
     q = tmp_path / "x.flac"
-    q.write_bytes(b"fLaC" + bytes(64))
+    q.write_bytes(b"fLaC" + bytes(64))            # a FLAC marker without a STREAMINFO block (real streams: test_audio_decode_cpu.py)
+    with pytest.raises(ValueError, match="STREAMINFO"):
+        read_wav(q)
+    q = tmp_path / "x.mp3"
+    q.write_bytes(b"\xff\xfb\x90\x00" + bytes(64))
     with pytest.raises(ValueError, match="RIFF"):
         read_wav(q)
     t = tmp_path / "trunc.wav"
