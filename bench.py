@@ -312,11 +312,22 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # SONAR_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, barriers, all-gathers, all-reduces) with whatever
+    # world size the launcher gave -- with one rank it runs every RCCL call of the multi-GPU path on a 1-GPU box
+    # (tests/test_gpu_rccl.py); the numbers of such a run are not the N = 1 bench line (no CPU baselines, no extra legs).
+    use_dist = world > 1 or os.environ.get("SONAR_BENCH_FORCE_DIST") == "1"
+    if use_dist and "MASTER_ADDR" not in os.environ:
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
+        sk.close()
     batch_n, seq = (BATCH, SEQ) if not DRYRUN else (8, 16)
     if DRYRUN:
         dev = torch.device("cpu")
         sync = lambda: None
-        if world > 1:
+        if use_dist:
             dist.init_process_group("gloo")
         xs_mod = _StubXsim()
         padded_rows = xs_mod.padded
@@ -326,13 +337,13 @@ def main():
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
-        if world > 1:
+        if use_dist:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             dist.init_process_group("nccl", device_id=dev)
         padded_rows = lambda n: int(xs_mod._lib.load().smi_xsim_padded_rows(n))
     # what the process group actually is (the first SCALE record must prove N ranks over RCCL)
-    collective = {"world_size": dist.get_world_size() if world > 1 else 1,
-                  "backend": (dist.get_backend() if world > 1 else None)}
+    collective = {"world_size": dist.get_world_size() if use_dist else 1,
+                  "backend": (dist.get_backend() if use_dist else None)}
     if not DRYRUN:
         try:
             collective["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -340,11 +351,11 @@ def main():
             collective["rccl_version"] = None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def max_over_ranks(seconds: float) -> float:
-        if world == 1:
+        if not use_dist:
             return seconds
         t = torch.tensor([seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -386,11 +397,11 @@ def main():
     ids[:, 0] = 256047  # __eng_Latn__
     ids[:, -1] = 3      # </s>
     batch = SequenceBatch(ids, None)
-    gathered = torch.empty((world * batch_n, D), dtype=torch.float16, device=dev) if world > 1 else None
+    gathered = torch.empty((world * batch_n, D), dtype=torch.float16, device=dev) if use_dist else None
 
     def step():
         emb = model(batch).sentence_embeddings
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, emb)  # assemble the embedding matrix over RCCL / xGMI
         return emb
 
@@ -500,12 +511,12 @@ def main():
         src_local = torch.randint(0, nloc, (nloc,), device=dev, generator=gx)
         x_local = (y_local[src_local].float() + 0.3 * torch.randn(nloc, D, device=dev, generator=gx)).half()
         dense = nloc == padded_rows(nloc)   # equal shards of whole 256-row tiles gather into a dense layout
-        yn_all = torch.empty((world * nloc, D), dtype=torch.float16, device=dev) if world > 1 and dense else None
+        yn_all = torch.empty((world * nloc, D), dtype=torch.float16, device=dev) if use_dist and dense else None
 
         def mine():
             xn = xs_mod.normalize_rows(x_local)
             yn = xs_mod.normalize_rows(y_local)
-            if world == 1:
+            if not use_dist:
                 return xs_mod.topk_normalized(xn, nloc, yn, nloc, 1)
             if dense:
                 dist.all_gather_into_tensor(yn_all, yn)  # assemble Y over RCCL / xGMI (2 KB per row)
@@ -523,7 +534,7 @@ def main():
         # correctness of the timed configuration itself: top-1 index == the constructed source row (global index)
         _, top_i = mine()
         hit = (top_i[:nloc, 0].long() == src_local + rank * nloc).sum().to(torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(hit)
         top1_agree = float(hit.item()) / n_total
         # the HBM-bound half of the leg on its own: L2 normalisation of one side (read fp16, write fp16)
@@ -596,7 +607,7 @@ def main():
             "kernels": kernels, "hbm_kernels": hbm_kernels, "xsim": xs, **extra,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -10,6 +10,7 @@ all-gather of 1M x 1024 fp16 (256 MB per rank) is a few ms next to the ~0.3 s of
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -20,6 +21,15 @@ def world() -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def _collectives(ws: int) -> bool:
+    """Whether the exchange steps run.  A single rank skips them -- unless SONAR_FORCE_COLLECTIVES=1 and a process
+    group exists: then every collective of the N > 1 path is issued with world size 1, which is how the RCCL calls
+    are executed on a 1-GPU box (tests/test_gpu_rccl.py)."""
+    if ws > 1:
+        return True
+    return os.environ.get("SONAR_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -47,7 +57,7 @@ def all_gather_rows(t: torch.Tensor) -> Tuple[torch.Tensor, List[int]]:
     """All-gather a [n_r, d] matrix whose row count differs per rank.
     Returns (concatenation in rank order [sum n_r, d], per-rank row counts)."""
     rank, ws = world()
-    if ws == 1:
+    if not _collectives(ws):
         return t, [t.shape[0]]
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
     counts = [torch.zeros_like(n) for _ in range(ws)]
@@ -71,7 +81,7 @@ def sharded_encode(encode_fn: Callable[[List[str]], torch.Tensor], texts: Sequen
     """Encode `texts` data-parallel: every rank runs `encode_fn` on its token-balanced share,
     one all-gather assembles the [len(texts), d] matrix in INPUT order on every rank."""
     rank, ws = world()
-    if ws == 1:
+    if not _collectives(ws):
         return encode_fn(list(texts))
     assignment = deal_by_length([len(t) for t in texts], ws)
     mine = assignment[rank]
@@ -139,7 +149,7 @@ def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, 
     rank, ws = world()
     nx_local, d = x_local.shape
     xn = be.normalize(x_local) if nx_local else None
-    if ws == 1:
+    if not _collectives(ws):
         return be.topk(xn, nx_local, be.normalize(y_local), y_local.shape[0], k)
     # normalise locally (fp16), gather the unpadded rows, then re-pad once
     if y_local.shape[0]:
@@ -173,7 +183,8 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
     # an empty shard is legal (fewer rows than ranks): it takes part in every collective with zero rows
     xn = be.normalize(x_local) if nx_local else _empty_normalized(be, x_local)
     yn_local = be.normalize(y_local) if ny_local else _empty_normalized(be, y_local)
-    if ws > 1:
+    coll = _collectives(ws)
+    if coll:
         yn_all, y_counts = all_gather_rows(yn_local[:ny_local])
         ny = sum(y_counts)
         yn = be.pad_rows(yn_all, ny)
@@ -206,7 +217,7 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
                 bs_part = torch.cat([bs_part, bs_part.new_full((ny, kk - kloc), float("-inf"))], dim=1)
         else:
             bs_part = torch.full((ny, kk), float("-inf"), dtype=torch.float32, device=dev)
-        if ws > 1:
+        if coll:
             parts = bs_part.new_empty((ws * bs_part.shape[0], bs_part.shape[1]))
             dist.all_gather_into_tensor(parts, bs_part.contiguous())
             bs, _ = be.merge_topk(parts.view(ws, bs_part.shape[0], bs_part.shape[1]), None)
@@ -216,6 +227,6 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
             fs, fi = be.topk(xn, nx_local, yn, ny, kk)
             pred, _ = be.margin_select(fs, fi, bs, margin, x_off, errs)
     total = errs.to(torch.int64)
-    if ws > 1:
+    if coll:
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
     return int(total.item()) / nx, pred

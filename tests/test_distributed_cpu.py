@@ -113,9 +113,11 @@ class TorchXsimBackend:
         return pred, m.gather(1, best).squeeze(1)
 
 
-def _xsim_worker(rank, world, port, q):
+def _xsim_worker(rank, world, port, q, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if force:
+        os.environ["SONAR_FORCE_COLLECTIVES"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import xsim as OX
@@ -175,3 +177,15 @@ def test_sharded_margin_xsim_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def test_forced_collectives_with_one_rank_gloo():
+    """SONAR_FORCE_COLLECTIVES=1: a single rank issues every collective of the N > 1 path (what tests/test_gpu_rccl.py
+    does over RCCL on the 1-GPU box) and still returns the single-process result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_xsim_worker, args=(0, 1, _free_port(), q, True))
+    p.start()
+    res = q.get(timeout=180)
+    p.join(timeout=60)
+    assert res == (0, "ok"), res

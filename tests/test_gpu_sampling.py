@@ -257,8 +257,9 @@ def test_sampling_argument_errors(setup):
 
     OD, ocfg, params, eng = setup
     emb = torch.zeros(2, ocfg.model_dim).cuda()
-    with pytest.raises(NotImplementedError):
-        eng.sample(emb, [3, 5], TopKSampler(2), unk_penalty=1.0)
+    # an UNK penalty that removes the token: generation runs and never emits UNK (id 1)
+    toks, lens, _ = eng.sample(emb, [3, 5], TopKSampler(50), unk_penalty=1.0, max_gen_len=(0, 12), seed=4)
+    assert int((toks == 1).sum()) == 0 and int(lens.min()) >= 1
     with pytest.raises(ValueError):
         eng.sample(emb, [3, 5], TopKSampler(2), max_seq_len=10 ** 6)
     with pytest.raises(RuntimeError):
