@@ -1,4 +1,6 @@
-mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_sampling.py -x -q -s 2>&1 | grep -v amdgpu.ids | tail -25 > gpurun_out/r03e1_tests.log
-cat gpurun_out/r03e1_tests.log
-timeout 900 python -m pytest tests -m gpu -x -q -k "xsim or mining or margin" 2>&1 | tail -3
+bash tools/gpu_round.sh r03zz pmc > gpurun_out/r03zz_round.log 2>&1
+bash tools/gpu_prof_legs.sh r03zz > gpurun_out/r03zz_legs.log 2>&1
+python tools/bench_c1.py > gpurun_out/r03zz_c1.log 2>&1
+python tools/bench_c1.py 5 100 >> gpurun_out/r03zz_c1.log 2>&1
+python tools/bench_e2e.py > gpurun_out/r03zz_e2e.log 2>&1
+tail -4 gpurun_out/r03zz_pytest_gpu.log; tail -2 gpurun_out/r03zz_smoke.log; head -8 gpurun_out/r03zz_kernel_stats.txt; cat gpurun_out/r03zz_mfma_util.txt | head -6; tail -3 gpurun_out/r03zz_c1.log; tail -2 gpurun_out/r03zz_e2e.log
