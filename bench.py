@@ -334,6 +334,9 @@ def main():
     else:
         from sonar_amd import xsim as xs_mod
 
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible "
+                             f"(--gpus {args.gpus} needs that many devices on this node)")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
