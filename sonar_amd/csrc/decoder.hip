@@ -320,13 +320,100 @@ __device__ __forceinline__ unsigned long long cand_key(float v, int idx) {
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
   return ((unsigned long long)u << 32) | (unsigned)(0xffffffffu - (unsigned)idx);
 }
+// Wave-wide arg-best reductions of the selection kernels on DPP row operations + v_permlane16/32_swap (VALU rate) instead of
+// __shfl_xor (= ds_bpermute, an LDS round trip per step and word: vocab_select ran 20 rounds x 12 of them back to back,
+// the beam step ~420 per sentence).  Step order as wave_max (common.hpp): xor 1, xor 2, half-row mirror, row mirror, then the
+// two lane swaps, whose both results are folded (one is the lane's own value, the other its partner's).  Every lane ends
+// with the same winner: the orders are total.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long other = __shfl_xor(k, o, 64);
-    k = other > k ? other : k;
+  auto fold = [&](unsigned lo, unsigned hi) {
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    k = o > k ? o : k;
+  };
+  fold(dpp_u<0xB1>((unsigned)k), dpp_u<0xB1>((unsigned)(k >> 32)));
+  fold(dpp_u<0x4E>((unsigned)k), dpp_u<0x4E>((unsigned)(k >> 32)));
+  fold(dpp_u<0x141>((unsigned)k), dpp_u<0x141>((unsigned)(k >> 32)));
+  fold(dpp_u<0x140>((unsigned)k), dpp_u<0x140>((unsigned)(k >> 32)));
+  {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)k, (unsigned)k, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    const unsigned long long a = ((unsigned long long)hi[0] << 32) | lo[0], b = ((unsigned long long)hi[1] << 32) | lo[1];
+    k = a > b ? a : b;
+  }
+  {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)k, (unsigned)k, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(k >> 32), (unsigned)(k >> 32), false, false);
+    const unsigned long long a = ((unsigned long long)hi[0] << 32) | lo[0], b = ((unsigned long long)hi[1] << 32) | lo[1];
+    k = a > b ? a : b;
   }
   return k;
+}
+// best (value desc, token asc) candidate of the wave, in every lane
+__device__ __forceinline__ void wave_best2(float& bv, int& bi) {
+  auto fold = [&](unsigned ov_, unsigned oi_) {
+    const float ov = __uint_as_float(ov_);
+    const int oi = (int)oi_;
+    if (cand_better(ov, oi, bv, bi)) {
+      bv = ov;
+      bi = oi;
+    }
+  };
+  fold(dpp_u<0xB1>(__float_as_uint(bv)), dpp_u<0xB1>((unsigned)bi));
+  fold(dpp_u<0x4E>(__float_as_uint(bv)), dpp_u<0x4E>((unsigned)bi));
+  fold(dpp_u<0x141>(__float_as_uint(bv)), dpp_u<0x141>((unsigned)bi));
+  fold(dpp_u<0x140>(__float_as_uint(bv)), dpp_u<0x140>((unsigned)bi));
+  {
+    const auto v = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto i = __builtin_amdgcn_permlane16_swap((unsigned)bi, (unsigned)bi, false, false);
+    bv = __uint_as_float(v[0]);
+    bi = (int)i[0];
+    fold(v[1], i[1]);
+  }
+  {
+    const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto i = __builtin_amdgcn_permlane32_swap((unsigned)bi, (unsigned)bi, false, false);
+    bv = __uint_as_float(v[0]);
+    bi = (int)i[0];
+    fold(v[1], i[1]);
+  }
+}
+// best (score desc, row asc, token asc) continuation of the wave, in every lane
+__device__ __forceinline__ void wave_best3(float& bv, int& br, int& bt) {
+  auto fold = [&](unsigned ov_, unsigned or_, unsigned ot_) {
+    const float ov = __uint_as_float(ov_);
+    const int orow = (int)or_, otok = (int)ot_;
+    if (ov > bv || (ov == bv && (orow < br || (orow == br && otok < bt)))) {
+      bv = ov;
+      br = orow;
+      bt = otok;
+    }
+  };
+  fold(dpp_u<0xB1>(__float_as_uint(bv)), dpp_u<0xB1>((unsigned)br), dpp_u<0xB1>((unsigned)bt));
+  fold(dpp_u<0x4E>(__float_as_uint(bv)), dpp_u<0x4E>((unsigned)br), dpp_u<0x4E>((unsigned)bt));
+  fold(dpp_u<0x141>(__float_as_uint(bv)), dpp_u<0x141>((unsigned)br), dpp_u<0x141>((unsigned)bt));
+  fold(dpp_u<0x140>(__float_as_uint(bv)), dpp_u<0x140>((unsigned)br), dpp_u<0x140>((unsigned)bt));
+  {
+    const auto v = __builtin_amdgcn_permlane16_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)br, (unsigned)br, false, false);
+    const auto t = __builtin_amdgcn_permlane16_swap((unsigned)bt, (unsigned)bt, false, false);
+    bv = __uint_as_float(v[0]);
+    br = (int)r[0];
+    bt = (int)t[0];
+    fold(v[1], r[1], t[1]);
+  }
+  {
+    const auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(bv), __float_as_uint(bv), false, false);
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)br, (unsigned)br, false, false);
+    const auto t = __builtin_amdgcn_permlane32_swap((unsigned)bt, (unsigned)bt, false, false);
+    bv = __uint_as_float(v[0]);
+    br = (int)r[0];
+    bt = (int)t[0];
+    fold(v[1], r[1], t[1]);
+  }
 }
 
 __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restrict__ logits, int ldl, int vocab,
@@ -600,15 +687,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
             bv = cv[q];
             bi = ci[q];
           }
-#pragma unroll
-        for (int of = 32; of > 0; of >>= 1) {
-          const float ov = __shfl_xor(bv, of, 64);
-          const int oi = __shfl_xor(bi, of, 64);
-          if (cand_better(ov, oi, bv, bi)) {
-            bv = ov;
-            bi = oi;
-          }
-        }
+        wave_best2(bv, bi);
         if (lane == 0) {
           c_val[r * VS_K2MAX + round] = bv == -INFINITY ? -INFINITY : st.cum[base + r] + bv - s_lse[r];
           c_tok[r * VS_K2MAX + round] = bi;
@@ -642,17 +721,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
         int u = (v2[1] > v2[0] || (v2[1] == v2[0] && (r2[1] < r2[0] || (r2[1] == r2[0] && k2t[1] < k2t[0])))) ? 1 : 0;
         float bv = v2[u];
         int br = r2[u], bt = k2t[u];
-#pragma unroll
-        for (int of = 32; of > 0; of >>= 1) {
-          const float ov = __shfl_xor(bv, of, 64);
-          const int orow = __shfl_xor(br, of, 64);
-          const int otok = __shfl_xor(bt, of, 64);
-          if (ov > bv || (ov == bv && (orow < br || (orow == br && otok < bt)))) {
-            bv = ov;
-            br = orow;
-            bt = otok;
-          }
-        }
+        wave_best3(bv, br, bt);
         if (bv == -INFINITY) break;
         if (lane == 0) {
           t_val[sel] = bv;

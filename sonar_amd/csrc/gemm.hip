@@ -410,16 +410,25 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
               t[ni][r] = v;
               mx = fmaxf(mx, v);
             }
-          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          // lanes 16 / 32 apart joined by v_permlane16/32_swap (VALU rate; __shfl_xor is an LDS round trip per step)
+          {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+          }
           const float ms = mx == -INFINITY ? 0.f : mx;
           float se = 0.f;
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) se += __builtin_amdgcn_exp2f(t[ni][r] - ms);
-          se += __shfl_xor(se, 16, 64);
-          se += __shfl_xor(se, 32, 64);
+          {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(se), __float_as_uint(se), false, false);
+            se = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(se), __float_as_uint(se), false, false);
+            se = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+          }
           if (kg == 0) lds_write_b64_asm(&red[(wr * 128 + mi * 16 + l15) * 4 + wc], float2{mx, se});
         }
         SMI_LGKM0_BARRIER();

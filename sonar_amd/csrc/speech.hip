@@ -693,7 +693,11 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;  // sl2e > 0: the scaled maximum
+    {  // the other half of the keys sits 32 lanes away: v_permlane32_swap (VALU) instead of __shfl_xor (an LDS round trip in
+       // the middle of the softmax chain, once per key block)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sl2e;  // sl2e > 0: the scaled maximum
+    }
     // Lazy rescale: the running reference m only moves when some query's block maximum exceeds it by
     // more than 2^8; until then p = exp2(x - m) <= 256 (exact in fp32, in range for the fp16 P operand)
     // and the 32 output accumulators, which live in AGPRs, are left alone.

@@ -1,6 +1,6 @@
-bash tools/gpu_round.sh r03zz pmc > gpurun_out/r03zz_round.log 2>&1
-bash tools/gpu_prof_legs.sh r03zz > gpurun_out/r03zz_legs.log 2>&1
-python tools/bench_c1.py > gpurun_out/r03zz_c1.log 2>&1
-python tools/bench_c1.py 5 100 >> gpurun_out/r03zz_c1.log 2>&1
-python tools/bench_e2e.py > gpurun_out/r03zz_e2e.log 2>&1
-tail -4 gpurun_out/r03zz_pytest_gpu.log; tail -2 gpurun_out/r03zz_smoke.log; head -8 gpurun_out/r03zz_kernel_stats.txt; cat gpurun_out/r03zz_mfma_util.txt | head -6; tail -3 gpurun_out/r03zz_c1.log; tail -2 gpurun_out/r03zz_e2e.log
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q -k "decoder or beam or attention or speech or kernels or sampling or encoder" 2>&1 | tail -3 > gpurun_out/r03f1_tests.log; cat gpurun_out/r03f1_tests.log
+V=$PWD/sonar_amd/lib/variant_head.so
+bash tools/gpu_exp.sh r03f1d timeout 300 python tools/bench_decoder.py 256 64 -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1"
+bash tools/gpu_exp.sh r03f1s timeout 300 python tools/bench_speech.py -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1"
+bash tools/gpu_exp.sh r03f1e timeout 300 python tools/probe_perf.py -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1"
