@@ -424,7 +424,6 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
                                                            float* __restrict__ pmax, float* __restrict__ psum,
                                                            float* __restrict__ pval, int* __restrict__ pidx) {
   __shared__ float s_f[4];
-  __shared__ unsigned long long s_k[4];
   __shared__ int s_sel[VSEL_SLOTS];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* tm = tile_max + row;  // [tile][stat_rows]
@@ -457,67 +456,67 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
     psum[row] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
   }
   if (k2 == 0) return;
+  // The two selections below are k2 rounds of "workgroup-wide maximum of a sortable key, then retire the winner".  The kernel is
+  // VALU-bound (1280 rows x 4 waves on 1024 SIMDs: a round used to rebuild and compare the keys of all of a thread's slots,
+  // ~230 VALU instructions, 20 rounds), so every thread now keeps its keys and its current best: a round is one wave reduction
+  // of the per-thread bests, one LDS exchange behind ONE barrier (the slots alternate between two buffers), and only the
+  // winner's thread rescans its slots.
+  __shared__ unsigned long long s_k2[2][4];
+  auto wg_max = [&](unsigned long long mine, int round) {
+    const unsigned long long w = wave_max_u64(mine);
+    if (lane == 0) s_k2[round & 1][wv] = w;
+    __syncthreads();
+    unsigned long long b = s_k2[round & 1][0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) b = s_k2[round & 1][q] > b ? s_k2[round & 1][q] : b;
+    return b;
+  };
   // ---- 2a. the k2 best tiles among tiles >= 1 (value desc, tile asc), plus tile 0
-  if (tid == 0) {
-    s_sel[0] = 0;
-    m[0] = -INFINITY;  // tile 0 is taken unconditionally
+  unsigned long long tk[TPT];
+  unsigned long long tbest = 0ull;
+#pragma unroll
+  for (int j = 0; j < TPT; ++j) {
+    const int t = tid + 256 * j;
+    tk[j] = (m[j] != -INFINITY && t != 0) ? cand_key(m[j], t) : 0ull;  // tile 0 is taken unconditionally
+    tbest = tk[j] > tbest ? tk[j] : tbest;
   }
+  if (tid == 0) s_sel[0] = 0;
   int nsel = 1;
   for (int round = 0; round < k2; ++round) {
-    unsigned long long best = 0ull;
-#pragma unroll
-    for (int j = 0; j < TPT; ++j)
-      if (m[j] != -INFINITY) {
-        const unsigned long long k = cand_key(m[j], tid + 256 * j);
-        best = k > best ? k : best;
-      }
-    best = wave_max_u64(best);
-    __syncthreads();
-    if (lane == 0) s_k[wv] = best;
-    __syncthreads();
-    unsigned long long b = s_k[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) b = s_k[w] > b ? s_k[w] : b;
+    const unsigned long long b = wg_max(tbest, round);
     if (b == 0ull) break;  // fewer than k2 tiles
-    const int t = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
-    if (tid == 0) s_sel[nsel] = t;
+    if (tid == 0) s_sel[nsel] = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
     ++nsel;
-    if ((t & 255) == tid) m[t >> 8] = -INFINITY;
-  }
-  __syncthreads();
-  // ---- 2b. thread t owns column t of every selected tile
-  float v[VSEL_SLOTS];
-  int id[VSEL_SLOTS];
-  const float* lp = logits + (size_t)row * ldl;
+    if (b == tbest) {  // keys are unique (the tile index is part of them): exactly one thread
+      tbest = 0ull;
 #pragma unroll
-  for (int j = 0; j < VSEL_SLOTS; ++j) {
-    v[j] = -INFINITY;
-    id[j] = 0x7fffffff;
-    if (j < nsel) {
-      const int tok = s_sel[j] * 256 + tid;
-      id[j] = tok;
-      if (tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
-        v[j] = lp[tok] * inv_temp;
-        if (tok == unk_idx) v[j] -= unk_penalty;
+      for (int j = 0; j < TPT; ++j) {
+        if (tk[j] == b) tk[j] = 0ull;
+        tbest = tk[j] > tbest ? tk[j] : tbest;
       }
     }
   }
+  __syncthreads();
+  // ---- 2b. thread t owns column t of every selected tile
+  unsigned long long ck[VSEL_SLOTS];
+  unsigned long long cbest = 0ull;
+  const float* lp = logits + (size_t)row * ldl;
+#pragma unroll
+  for (int j = 0; j < VSEL_SLOTS; ++j) {
+    ck[j] = 0ull;
+    if (j < nsel) {
+      const int tok = s_sel[j] * 256 + tid;
+      if (tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
+        float v = lp[tok] * inv_temp;
+        if (tok == unk_idx) v -= unk_penalty;
+        if (v != -INFINITY) ck[j] = cand_key(v, tok);
+      }
+    }
+    cbest = ck[j] > cbest ? ck[j] : cbest;
+  }
   // ---- 2c. ordered top-k2 by k2 workgroup-wide arg-max rounds
   for (int round = 0; round < k2; ++round) {
-    unsigned long long best = 0ull;
-#pragma unroll
-    for (int j = 0; j < VSEL_SLOTS; ++j)
-      if (v[j] != -INFINITY) {
-        const unsigned long long k = cand_key(v[j], id[j]);
-        best = k > best ? k : best;
-      }
-    best = wave_max_u64(best);
-    __syncthreads();
-    if (lane == 0) s_k[wv] = best;
-    __syncthreads();
-    unsigned long long b = s_k[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) b = s_k[w] > b ? s_k[w] : b;
+    const unsigned long long b = wg_max(cbest, round + k2);
     float val = -INFINITY;
     int idx = 0x7fffffff;
     if (b != 0ull) {
@@ -530,9 +529,14 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
       pval[(size_t)row * VS_K2MAX + round] = val;
       pidx[(size_t)row * VS_K2MAX + round] = idx;
     }
+    if (b != 0ull && b == cbest) {
+      cbest = 0ull;
 #pragma unroll
-    for (int j = 0; j < VSEL_SLOTS; ++j)
-      if (id[j] == idx) v[j] = -INFINITY;
+      for (int j = 0; j < VSEL_SLOTS; ++j) {
+        if (ck[j] == b) ck[j] = 0ull;
+        cbest = ck[j] > cbest ? ck[j] : cbest;
+      }
+    }
   }
 }
 
@@ -664,6 +668,15 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     // One wave per row; its <= 1024 partial candidates sit in registers (16 per lane).
     for (int r = wv; r < na; r += 4) {
       const size_t o = (size_t)(base + r) * nchunks * VS_K2MAX;
+      if (nchunks == 1) {  // the tile-statistics selection already leaves ONE ordered list per row: nothing to merge
+        if (lane < k2) {
+          const float v = pval[o + lane];
+          c_val[r * VS_K2MAX + lane] = v == -INFINITY ? -INFINITY : st.cum[base + r] + v - s_lse[r];
+          c_tok[r * VS_K2MAX + lane] = pidx[o + lane];
+          c_row[r * VS_K2MAX + lane] = base + r;
+        }
+        continue;
+      }
       const int total = nchunks * k2;
       float cv[16];
       int ci[16];

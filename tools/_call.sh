@@ -1,3 +1,5 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q -k "decoder or beam or generat or lowdim or twin" 2>&1 | tail -3 > gpurun_out/r03g1_tests.log; cat gpurun_out/r03g1_tests.log
-bash tools/gpu_exp.sh r03g1d timeout 300 python tools/bench_decoder.py 256 64 -- "SMI_DEC_STATS_TR=0" "SMI_DEC_STATS_TR=1" "SMI_DEC_STATS_TR=0" "SMI_DEC_STATS_TR=1"
+V=$PWD/sonar_amd/lib/variant_head.so
+bash tools/gpu_exp.sh r03h1d timeout 300 python tools/bench_decoder.py 256 64 -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1"
+cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03h1_prof -o h1 --output-format csv -- python $OLDPWD/tools/bench_decoder.py 256 64 > /dev/null 2>&1; cd $OLDPWD
+python tools/summarize_prof.py gpurun_out/r03h1_prof > gpurun_out/r03h1_decoder_kernel_stats.txt 2>&1; find gpurun_out/r03h1_prof -name "*kernel_trace*" -delete; grep "vocab_select\|beam_step" gpurun_out/r03h1_decoder_kernel_stats.txt | cut -c1-150
