@@ -133,6 +133,48 @@ __global__ __launch_bounds__(GT_THREADS, 2) void xsim_tile_kernel(const f16* __r
 // ALL y tiles of the chunk form one continuous DMA stream through the 4-slot LDS ring:
 // the pipeline is filled once per workgroup, not once per y tile; at every tile
 // boundary the accumulators are folded into the running top-k and cleared.
+#ifdef SMI_XSIM_TRACE
+// development aid (-DSMI_XSIM_TRACE, tools/xsim_trace.py): per workgroup and ping-pong group, the 100 MHz wall-clock ticks of the
+// whole slice stream, of the folds inside it and the number of folds (lane 0 of waves 0 and 4 of the first 256 workgroups)
+__device__ unsigned long long xs_trace_buf[256 * 2 * 4];
+#endif
+
+// The fold of a finished y tile (n0f = its first y row), as a macro: top-1 calls it through a lambda from two places (below),
+// and a lambda around it costs top-4, which has no register to spare, 76 bytes of spills.
+#define XS_FOLD(n0f)                                                                                                         \
+  do {                                                                                                                       \
+    float rowthr[8];                                                                                                         \
+    _Pragma("unroll")                                                                                                        \
+    for (int mi = 0; mi < 8; ++mi) {                                                                                         \
+      float my = best[mi].s[K - 1];                                                                                          \
+      my = fmaxf(my, __shfl_xor(my, 16, 64));                                                                                \
+      my = fmaxf(my, __shfl_xor(my, 32, 64));                                                                                \
+      if (kg == 0) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = my;                                                            \
+    }                                                                                                                        \
+    _Pragma("unroll")                                                                                                        \
+    for (int mi = 0; mi < 8; ++mi) {                                                                                         \
+      const f32x4 t4 = *(const f32x4*)(thr + (wr * 128 + mi * 16 + l15) * 4);                                                \
+      rowthr[mi] = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));                                                          \
+    }                                                                                                                        \
+    _Pragma("unroll")                                                                                                        \
+    for (int mi = 0; mi < 8; ++mi) {                                                                                         \
+      float vmax = -INFINITY;                                                                                                \
+      _Pragma("unroll")                                                                                                      \
+      for (int ni = 0; ni < 4; ++ni)                                                                                         \
+        _Pragma("unroll")                                                                                                    \
+        for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);                                                    \
+      if (vmax >= rowthr[mi]) {                                                                                              \
+        _Pragma("unroll")                                                                                                    \
+        for (int ni = 0; ni < 4; ++ni)                                                                                       \
+          _Pragma("unroll")                                                                                                  \
+          for (int r = 0; r < 4; ++r) {                                                                                      \
+            const int n = n0f + wc * 64 + ni * 16 + 4 * kg + r;                                                              \
+            if (n < ny) best[mi].push(acc.v[ni][mi][r], n);                                                                  \
+          }                                                                                                                  \
+      }                                                                                                                      \
+    }                                                                                                                        \
+  } while (0)
+
 // TM: Xn / Yn are TILE-MAJOR copies (common.hpp; packed into the workspace by xsim_run): a K slice of an operand is one
 // contiguous 16 KiB block and the Y stream of a chunk one linear walk, instead of 256 pieces of 64 B a row apart -- the
 // layout that bought the GEMMs +7 % end to end and +26 % on the bare operand stream.
@@ -232,22 +274,82 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     if (wr == 1) SMI_BARRIER();
 
     int k = 0, n0 = t_begin * G2_BN;
+#ifdef SMI_XSIM_TRACE
+    unsigned long long tr_t0 = wall_clock64(), tr_fold = 0, tr_n = 0, tr_max = 0;
+#endif
+    // y tile finished: fold the 128x64 scores of this wave into the top-k (n0f = first y row of that tile).
+    // (v_permlane16/32_swap joins instead of the two ds_bpermute shuffles measured SLOWER twice: r03 experiments 10 and 14)
+    auto fold = [&](int n0f) {
+#ifdef SMI_XSIM_TRACE
+      const unsigned long long tr_f0 = wall_clock64();
+#endif
+      XS_FOLD(n0f);
+#ifdef SMI_XSIM_TRACE
+      const unsigned long long dt = wall_clock64() - tr_f0;
+      tr_fold += dt;
+      tr_max = dt > tr_max ? dt : tr_max;
+      ++tr_n;
+#endif
+    };
+    // A fold makes its interval ~5x longer, and the OTHER group waits for it at the barrier.  Left where each group
+    // finishes its tile (after its last MFMA segment) the two groups fold in DIFFERENT intervals, one after the other:
+    // two long intervals per tile (the trace: 1.95 us per fold and group = 3.4 of a 29.6 us tile period at top-1).
+    // Group 0 therefore DEFERS its fold by one interval -- it first reads the next tile's first slice, then folds in front
+    // of that slice's MFMAs (which start from C = 0 and do not read the accumulators) -- so both groups fold in the same
+    // interval and a tile has one long interval instead of two.
+    // top-1 keeps the 12 fragments of the next tile's first slice in registers across the deferred fold; top-2 has no registers
+    // for that (it spills) and reads them AFTER the fold, in the same interval; top-4 (64 list registers) spills either way and
+    // ran 60 % slower deferred: it keeps the two-interval schedule.  Same box, 262 144 x 1 M: top-1 443.5 / 445.6 -> 434.9 /
+    // 434.2 ms, top-2 493.2 / 492.6 -> 474.0 / 473.1 ms (r03 experiment 14).
+    constexpr bool DEFER = K <= 2;
+    constexpr bool LATE_READ = K == 2;
+    bool pending = false;
+    int n0_pending = 0;
     for (int s = 0; s < S; ++s) {
       const char* slot = smem + (s & 3) * G2_SLOT_BYTES;
       half8 fx[8], fw[4];
+      auto read_frags = [&]() {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const half8*)(slot + woff + ni * 1024);
+        for (int ni = 0; ni < 4; ++ni) fw[ni] = *(const half8*)(slot + woff + ni * 1024);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
-      if (s + 3 < S) {
-        issue();
-        SMI_WAIT_VMCNT(8);
-      } else if (s + 2 < S) {
-        SMI_WAIT_VMCNT(4);
+        for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
+      };
+      auto issue_and_wait = [&]() {
+        if (s + 3 < S) {
+          issue();
+          SMI_WAIT_VMCNT(8);
+        } else if (s + 2 < S) {
+          SMI_WAIT_VMCNT(4);
+        } else {
+          SMI_WAIT_VMCNT(0);
+        }
+        SMI_LGKM0_BARRIER();
+      };
+      if (LATE_READ && pending) {  // group 0, first slice of the next tile: no fragment is live across the fold
+        issue_and_wait();
+        fold(n0_pending);
+        pending = false;
+        // The reads follow this interval's LDS-DMA issue: as C++ loads each would get `s_waitcnt vmcnt(0)` from hipcc's alias
+        // tracking (gemm.hip) and wait for the slice that was just requested.  One asm statement issues and retires them.
+        const unsigned wa = (unsigned)(size_t)(slot + woff), xa = (unsigned)(size_t)(slot + xoff);
+        asm volatile(
+            "ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:1024\n\tds_read_b128 %2, %12 offset:2048\n\t"
+            "ds_read_b128 %3, %12 offset:3072\n\tds_read_b128 %4, %13\n\tds_read_b128 %5, %13 offset:1024\n\t"
+            "ds_read_b128 %6, %13 offset:2048\n\tds_read_b128 %7, %13 offset:3072\n\tds_read_b128 %8, %13 offset:4096\n\t"
+            "ds_read_b128 %9, %13 offset:5120\n\tds_read_b128 %10, %13 offset:6144\n\tds_read_b128 %11, %13 offset:7168\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(fw[0]), "=&v"(fw[1]), "=&v"(fw[2]), "=&v"(fw[3]), "=&v"(fx[0]), "=&v"(fx[1]), "=&v"(fx[2]), "=&v"(fx[3]),
+              "=&v"(fx[4]), "=&v"(fx[5]), "=&v"(fx[6]), "=&v"(fx[7])
+            : "v"(wa), "v"(xa)
+            : "memory");
       } else {
-        SMI_WAIT_VMCNT(0);
+        read_frags();
+        issue_and_wait();
+        if (DEFER && pending) {  // top-1, group 0
+          fold(n0_pending);
+          pending = false;
+        }
       }
-      SMI_LGKM0_BARRIER();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       if (k == 0) {
@@ -269,44 +371,35 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       SMI_BARRIER();
-      if (++k == nt) {  // y tile finished: fold the 128x64 scores of this wave into the top-k
+      if (++k == nt) {
         k = 0;
-        // (a rewrite of this fold with v_permlane16/32_swap joins instead of the two ds_bpermute shuffles and v_max3_f32
-        // chains in asm instead of fmaxf measured 1.5 % SLOWER, r03 experiment 10: the fold runs in the wave's read segment
-        // under its SIMD partner's multiply segment and is not what the pipe waits for)
-        float rowthr[8];
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          float my = best[mi].s[K - 1];
-          my = fmaxf(my, __shfl_xor(my, 16, 64));
-          my = fmaxf(my, __shfl_xor(my, 32, 64));
-          if (kg == 0) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = my;
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          const f32x4 t4 = *(const f32x4*)(thr + (wr * 128 + mi * 16 + l15) * 4);
-          rowthr[mi] = fmaxf(fmaxf(t4[0], t4[1]), fmaxf(t4[2], t4[3]));
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-          float vmax = -INFINITY;
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);
-          if (vmax >= rowthr[mi]) {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wc * 64 + ni * 16 + 4 * kg + r;
-                if (n < ny) best[mi].push(acc.v[ni][mi][r], n);
-              }
+        if constexpr (DEFER) {
+          if (wr == 0) {
+            pending = true;
+            n0_pending = n0;
+          } else {
+            fold(n0);
           }
+        } else {
+#ifdef SMI_XSIM_TRACE
+          fold(n0);
+#else
+          XS_FOLD(n0);
+#endif
         }
         n0 += G2_BN;
       }
     }
+    if (DEFER && pending) fold(n0_pending);
+#ifdef SMI_XSIM_TRACE
+    if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {
+      unsigned long long* o = xs_trace_buf + (blockIdx.x * 2 + wr) * 4;
+      o[0] = wall_clock64() - tr_t0;
+      o[1] = tr_fold;
+      o[2] = tr_n;
+      o[3] = tr_max;
+    }
+#endif
     if (wr == 0) SMI_BARRIER();
   }
 
@@ -654,3 +747,9 @@ hipError_t launch_xsim_topk(const f16* Xn, int64_t nx, int64_t nx_pad, const f16
 }
 
 }  // namespace smi
+
+#ifdef SMI_XSIM_TRACE
+extern "C" int smi_debug_xsim_trace(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(smi::xs_trace_buf), sizeof(smi::xs_trace_buf));
+}
+#endif

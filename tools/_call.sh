@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q -k "xsim or mining or margin or fullsize" 2>&1 | tail -3
 V=$PWD/sonar_amd/lib/variant_head.so
-bash tools/gpu_exp.sh r03h1d timeout 300 python tools/bench_decoder.py 256 64 -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1"
-cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/r03h1_prof -o h1 --output-format csv -- python $OLDPWD/tools/bench_decoder.py 256 64 > /dev/null 2>&1; cd $OLDPWD
-python tools/summarize_prof.py gpurun_out/r03h1_prof > gpurun_out/r03h1_decoder_kernel_stats.txt 2>&1; find gpurun_out/r03h1_prof -name "*kernel_trace*" -delete; grep "vocab_select\|beam_step" gpurun_out/r03h1_decoder_kernel_stats.txt | cut -c1-150
+for k in 1 2 4; do bash tools/gpu_exp.sh r03k$k timeout 300 python tools/probe_xsim.py 262144 1048576 $k -- "SMI_LIB=$V" "SMI_X=1" | grep -v amdgpu; done
+bash tools/gpu_exp.sh r03kf timeout 300 python tools/probe_xsim.py 1048576 1048576 1 -- "SMI_LIB=$V" "SMI_X=1" | grep -v amdgpu
