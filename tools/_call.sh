@@ -1,3 +1,4 @@
-bash tools/gpu_round.sh r03zx pmc > gpurun_out/r03zx_round.log 2>&1
-bash tools/gpu_prof_legs.sh r03zx > gpurun_out/r03zx_legs.log 2>&1
-tail -4 gpurun_out/r03zx_pytest_gpu.log; tail -2 gpurun_out/r03zx_smoke.log; head -6 gpurun_out/r03zx_kernel_stats.txt; cat gpurun_out/r03zx_mfma_util.txt | head -5; tail -1 gpurun_out/r03zx_decoder.log; tail -1 gpurun_out/r03zx_speech.log
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q -k "xsim or mining or margin or fullsize" 2>&1 | tail -3
+V=$PWD/sonar_amd/lib/variant_head.so
+for k in 1 2 4; do bash tools/gpu_exp.sh r03l$k timeout 300 python tools/probe_xsim.py 262144 1048576 $k -- "SMI_LIB=$V" "SMI_X=1" "SMI_LIB=$V" "SMI_X=1" | grep -v amdgpu; done
