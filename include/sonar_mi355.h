@@ -139,6 +139,11 @@ typedef struct smi_text_encoder smi_text_encoder; /* opaque */
 
 /* Library / device ------------------------------------------------------- */
 const char* smi_version(void);
+/* ABI revision of this header: bumped whenever a struct grows, an argument list changes or a workspace formula
+ * changes (round 2 = 2, round 3 = 3, ...).  A binding compares it with SMI_ABI_VERSION at load time and refuses a
+ * library built from another revision (the structs carry no size field). */
+#define SMI_ABI_VERSION 4
+int smi_abi_version(void);
 const char* smi_last_error(void);
 /* Selects the HIP device for this thread (hipSetDevice). */
 int smi_init(int device_id);
@@ -271,6 +276,14 @@ int smi_text_decoder_generate(smi_text_decoder* dec, const void* emb, int32_t em
  * "Exact token-id match for greedy decode" (BASELINE north_star) is tested as: every token equal to the
  * fp32 CPU oracle's unless [s][0] is below the epsilon stated in the test. */
 int smi_text_decoder_last_margins(smi_text_decoder* dec, float* out_margins, int32_t n, void* stream);
+
+/* Independent decode chains of smi_text_decoder_generate (round 4).  Sentences do not interact in
+ * EmbeddingToTextModelPipeline.predict (sonar/inference_pipelines/text.py:329-346 decodes buckets of sentences), so a
+ * large batch may run as `chains` sentence groups, each with its own workspace, KV cache, beam state, stream and host
+ * thread: one group's per-launch fixed costs fall under the other's K loops.  0 = the engine's choice (environment
+ * SMI_DEC_CHAINS, else the built-in default), 1 = one chain, up to 4.  Hypotheses equal the single chain's up to the
+ * fp32 summation order of split-K slabs. */
+int smi_text_decoder_set_chains(smi_text_decoder* dec, int32_t chains);
 
 /* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
  * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).

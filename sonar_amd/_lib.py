@@ -234,10 +234,13 @@ class smi_mlp_head_layer(C.Structure):
     _fields_ = [("w", smi_tensor), ("b", smi_tensor), ("out_dim", C.c_int32), ("reserved", C.c_int32)]
 
 
+ABI_VERSION = 4  # SMI_ABI_VERSION of include/sonar_mi355.h
+
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = {
     "smi_version": (C.c_char_p, []),
+    "smi_abi_version": (C.c_int, []),
     "smi_last_error": (C.c_char_p, []),
     "smi_init": (C.c_int, [C.c_int]),
     "smi_device_count": (C.c_int, []),
@@ -257,6 +260,7 @@ SYMBOLS = {
     "smi_text_decoder_generate": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                             C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
     "smi_text_decoder_last_margins": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "smi_text_decoder_set_chains": (C.c_int, [_vp, _i32]),
     "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                           C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
     "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp,
@@ -312,6 +316,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.smi_abi_version() != ABI_VERSION:  # the structs carry no size field: refuse a library of another revision
+        raise RuntimeError(f"{LIB_PATH} has ABI revision {lib.smi_abi_version()}, this binding speaks {ABI_VERSION}: "
+                           "rebuild with `python -m sonar_amd.build --force`")
     _lib = lib
     return lib
 

@@ -209,6 +209,7 @@ int check_cfg(const smi_text_encoder_config& c) {
 extern "C" {
 
 const char* smi_version(void) { return "sonar_mi355 0.1.0 (gfx950)"; }
+int smi_abi_version(void) { return SMI_ABI_VERSION; }
 const char* smi_last_error(void) { return smi_host::last_error().c_str(); }
 
 int smi_device_count(void) {

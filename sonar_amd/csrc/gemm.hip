@@ -790,6 +790,11 @@ extern "C" int smi_debug_gemm_trace(unsigned long long* host_out) {
 }
 #endif
 
+// Persistent-grid cap of the calling thread's next 256x256 launches (0 = none): a decode chain that shares the chip with
+// other chains leaves CUs to them during its one throughput-bound launch (the logits GEMM)
+static thread_local int g2_grid_cap = 0;
+void set_gemm_grid_cap(int workgroups) { g2_grid_cap = workgroups; }
+
 static int num_cus() {
   static std::atomic<int> cached[64];
   const int dev = DeviceOnce::dev();
@@ -812,7 +817,8 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
     if (e != hipSuccess) return e;
     attr_done.set();
   }
-  const int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
+  int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
+  if (g2_grid_cap > 0) grid = std::min(grid, g2_grid_cap);
   static const int want_raster = [] {  // SMI_G2_RASTER=0 restores the id-order raster everywhere (A/B measurements)
     const char* e = getenv("SMI_G2_RASTER");
     return e ? atoi(e) : 2;
@@ -948,7 +954,9 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
   // 160 tiles on 256 CUs still beat 640 small tiles); use it when the units roughly fill the chip once
   // and every unit has a real K loop (its K parts may be unequal)
   const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
-  if (M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= 96 && units256 <= num_cus())
+  const char* mu = getenv("SMI_G2_SPLITK_MIN");  // A/B switch, read per launch (decode-time path: ~50 launches per step)
+  const int min_units = mu && *mu ? atoi(mu) : 96;
+  if (M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= min_units && units256 <= num_cus())
     return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4)
                  : launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
   if (K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly

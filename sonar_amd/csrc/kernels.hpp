@@ -101,6 +101,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
                                  int N, int K, int ksplit, hipStream_t stream, int in_tm = 0);
+// cap the persistent grid of the calling thread's next 256x256-engine launches (0 = no cap)
+void set_gemm_grid_cap(int workgroups);
 // number of K parts for a decode-time split-K projection (gemm.hip): every unit on its own CU, <= max_parts
 int gemm_splitk_parts(int M, int N, int K, int max_parts);
 

@@ -254,6 +254,10 @@ class TextDecoderEngine:
             raise ValueError("`max_seq_len` leaves no room for generation after the prompt")
         return max_len, min(plen + min_gen_len, max_len)
 
+    def set_chains(self, chains: int) -> None:
+        """Independent decode chains of generate() (smi_text_decoder_set_chains): 0 = the engine's choice."""
+        _lib.check(self.lib.smi_text_decoder_set_chains(self._handle, int(chains)))
+
     def last_margins(self, n: int) -> torch.Tensor:
         """Decision margins fp32 [n, 2] of the last generate() call (smi_text_decoder_last_margins)."""
         out = torch.empty((n, 2), dtype=torch.float32, device=self.device)

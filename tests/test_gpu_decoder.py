@@ -172,6 +172,51 @@ def test_generate_is_repeatable_across_calls(setup):
     assert not torch.equal(first[0], other[0])
 
 
+@pytest.mark.parametrize("chains", [2, 3])
+def test_independent_chains_return_the_single_chain_hypotheses(setup, chains):
+    """smi_text_decoder_set_chains: a batch decoded as 2 / 3 independent sentence groups (own workspace, KV cache,
+    beam state, stream and host thread each) must return what the single chain returns -- hypotheses, lengths,
+    scores, decision margins -- sentence for sentence and in input order; natural EOS (sentences finish at
+    different steps, the groups stop polling at different times) and an uneven last group included.  The only
+    licence is the fp32 summation order of the split-K slabs (the number of K parts follows a group's row count):
+    a sentence may differ only where the engine's own decision margin is below 1e-4."""
+    OD, ocfg, params, eng = setup
+    n, beam = 301, 5          # 1505 rows; 2 chains: 151 + 150 sentences, 3 chains: 101 + 101 + 99
+    emb = (torch.randn(n, ocfg.model_dim, generator=torch.Generator().manual_seed(99)) * 0.3).cuda()
+    kw = dict(beam_size=beam, max_gen_len=(0, 30))
+    try:
+        eng.set_chains(1)
+        one = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
+        m_one = eng.last_margins(n).cpu()
+        eng.set_chains(chains)
+        got = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
+        m_got = eng.last_margins(n).cpu()
+        again = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]   # chain workspaces are reused
+    finally:
+        eng.set_chains(0)
+    assert len(set(one[1][:, 0].tolist())) > 3                 # the sentences really stop at different lengths
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+    differ = [i for i in range(n) if not (torch.equal(one[0][i], got[0][i]) and torch.equal(one[1][i], got[1][i]))]
+    for i in differ:
+        assert min(m_one[i].min().item(), m_got[i].min().item()) < 1e-4, (i, m_one[i].tolist(), m_got[i].tolist())
+    same = [i for i in range(n) if i not in differ]
+    print(f"chains {chains}: {len(same)}/{n} sentences identical to the single chain")
+    assert len(differ) <= n // 50
+    assert (one[2][same] - got[2][same]).abs().max().item() <= 2e-4
+    assert (m_one[same] - m_got[same])[torch.isfinite(m_one[same])].abs().max().item() <= 2e-3
+    # a small batch is never split (a chain keeps >= 384 hypothesis rows): same call path as chains = 1
+    try:
+        eng.set_chains(1)
+        small_one = [t.cpu() for t in eng.generate(emb[:20], [3, 702], **kw)]
+        eng.set_chains(chains)
+        small = [t.cpu() for t in eng.generate(emb[:20], [3, 702], **kw)]
+    finally:
+        eng.set_chains(0)
+    for a, b in zip(small, small_one):
+        assert torch.equal(a, b)
+
+
 def test_beam_search_forced_eos_and_min_len(setup):
     OD, ocfg, params, eng = setup
     emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3
