@@ -395,6 +395,9 @@ def main():
         torch.cuda.empty_cache()
     log(f"[rank {rank}] engine ready in {time.time() - t0:.1f}s, {model.engine.device_bytes / 1e9:.2f} GB in HBM")
 
+    # like predict(): batches are queued, the out-of-vocabulary check (one stream synchronisation) runs once, below
+    if hasattr(model, "deferred_check"):
+        model.deferred_check = True
     g = torch.Generator(device=dev).manual_seed(100 + rank)
     ids = torch.randint(4, 256001, (batch_n, seq), device=dev, generator=g)
     ids[:, 0] = 256047  # __eng_Latn__
@@ -501,6 +504,9 @@ def main():
                                        "randint(8,65) seed 1, fp16 (text.py:178)",
                            "tokens": int(b5_lens.sum()), "ms": b5_t / 50 * 1e3, "sentences_per_s": 5 * 50 / b5_t}
 
+    if hasattr(model, "deferred_check"):
+        model.engine.check()  # IndexError if any of the batches above held ids outside the embedding table
+
     # ------------------------------------------------------------ xsim leg (BASELINE configs[2])
     xs = None
     if not args.no_xsim:
@@ -524,8 +530,10 @@ def main():
             if dense:
                 dist.all_gather_into_tensor(yn_all, yn)  # assemble Y over RCCL / xGMI (2 KB per row)
                 return xs_mod.topk_normalized(xn, nloc, yn_all, n_total, 1)
+            from sonar_amd import distributed as sdist
             from sonar_amd.distributed import all_gather_rows
 
+            sdist.force_collectives(world == 1)  # a forced one-rank run issues the collectives too
             ya, _ = all_gather_rows(yn[:nloc])
             pad = padded_rows(n_total) - n_total
             if pad:

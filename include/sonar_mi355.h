@@ -417,14 +417,15 @@ int smi_fbank_batch(const float* waves, const int64_t* offsets, int32_t n, float
  * smi_xsim_topk: Xn/Yn are such normalised, padded matrices.  idx [nx,k] int32
  *   (row index in Y plus y_index_offset; -1 if fewer than k candidates),
  *   score [nx,k] fp32.  workspace: smi_xsim_workspace_bytes() bytes of device memory (the per-chunk partial
- *   lists and, for k <= 4, tile-major copies of both matrices: the mining kernel streams those). */
+ *   lists and, for k <= 4, tile-major copies of both matrices: the mining kernel streams those); workspace_bytes =
+ *   what the caller allocated -- a buffer smaller than the formula of THIS library is refused, not overrun. */
 int64_t smi_xsim_padded_rows(int64_t rows);
 int smi_xsim_normalize(const void* src, int32_t src_dtype, int64_t rows, int32_t d, void* dst_f16,
                        void* stream);
 int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k, int32_t d);
 int smi_xsim_topk(const void* xn_f16, int64_t nx, const void* yn_f16, int64_t ny, int32_t d,
                   int32_t k, int64_t y_index_offset, int32_t* idx, float* score, void* workspace,
-                  void* stream);
+                  int64_t workspace_bytes, void* stream);
 
 /* k-way merge of `parts` per-shard top-k lists (device fp32 / int32 [parts, n, k], each sorted as
  * smi_xsim_topk returns them) into the k best of their union, same total order (score desc, index asc).

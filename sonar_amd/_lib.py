@@ -275,7 +275,7 @@ SYMBOLS = {
     "smi_xsim_padded_rows": (_i64, [_i64]),
     "smi_xsim_normalize": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "smi_xsim_workspace_bytes": (_i64, [_i64, _i64, _i32, _i32]),
-    "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "smi_xsim_topk": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _i64, _vp]),
     "smi_xsim_merge_topk": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "smi_xsim_margin_select": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

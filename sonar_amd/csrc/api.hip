@@ -102,7 +102,8 @@ struct smi_text_encoder {
   int cu_next = 0;
   int64_t weight_bytes = 0;
   // out-of-vocabulary token ids: the embedding kernel raises this flag (host-mapped, device-visible);
-  // it is reported by smi_text_encoder_status() and by the next forward call (sticky until then)
+  // it is reported -- and cleared -- by smi_text_encoder_status() only (sticky until then); the Python model object
+  // calls that after every forward() unless its caller defers the check to the end of a queue of batches
   int32_t* bad_ids = nullptr;      // pinned host word
   int32_t* bad_ids_dev = nullptr;  // its device address
   // every GEMM operand (weights, h, ctx, ffn) in the tile-major layout of common.hpp
@@ -602,11 +603,14 @@ int64_t smi_xsim_workspace_bytes(int64_t nx, int64_t ny, int32_t k, int32_t d) {
 }
 
 int smi_xsim_topk(const void* xn, int64_t nx, const void* yn, int64_t ny, int32_t d, int32_t k,
-                  int64_t y_off, int32_t* idx, float* score, void* ws, void* stream) {
+                  int64_t y_off, int32_t* idx, float* score, void* ws, int64_t ws_bytes, void* stream) {
   if (!xn || !yn || !idx || !score || !ws) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (k < 1 || k > 8) return fail(SMI_ERR_UNSUPPORTED, "k=%d outside [1,8]", k);
   if (d <= 0 || d % 64) return fail(SMI_ERR_UNSUPPORTED, "d=%d must be a multiple of 64", d);
   if (nx <= 0 || ny <= 0) return fail(SMI_ERR_INVALID_ARG, "empty input");
+  if (ws_bytes < smi_xsim_workspace_bytes(nx, ny, k, d))
+    return fail(SMI_ERR_INVALID_ARG, "workspace of %lld bytes, smi_xsim_workspace_bytes(nx, ny, k, d) = %lld",
+                (long long)ws_bytes, (long long)smi_xsim_workspace_bytes(nx, ny, k, d));
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_xsim_topk((const f16*)xn, nx, smi_xsim_padded_rows(nx), (const f16*)yn, ny,
                            smi_xsim_padded_rows(ny), d, k, y_off, idx, score, ws, (hipStream_t)stream));

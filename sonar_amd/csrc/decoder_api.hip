@@ -62,7 +62,6 @@ struct DecWork {
 };
 
 constexpr int kMaxChains = 4;
-constexpr int kDefaultChains = 1;  // until measured (SMI_DEC_CHAINS)
 
 struct smi_text_decoder {
   smi_text_decoder_config cfg;
@@ -204,7 +203,9 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
   // Attention output (K = d): as many parts as keep every 128x128 unit on a CU of its own (2 at 1280 rows: 160 units
   // on the lone-tile ring engine); SMI_DEC_KS_OUT overrides for A/B runs, 1 = no split, residual epilogue.
   const DecTuning& tu = S.tuning;
-  const int ks_out = tu.ks_out > 0 ? tu.ks_out : gemm_splitk_parts(rows_pad, d, d, kMaxParts);
+  // (an override the slab buffer or the K split cannot take falls back to the automatic choice)
+  const bool ks_out_ok = tu.ks_out >= 1 && tu.ks_out <= kMaxParts && d % (64 * tu.ks_out) == 0;
+  const int ks_out = ks_out_ok ? tu.ks_out : gemm_splitk_parts(rows_pad, d, d, kMaxParts);
   const int ks_ffn = tu.ks_ffn > 0 && tu.ks_ffn <= kMaxParts && f % (256 * tu.ks_ffn) == 0
                          ? tu.ks_ffn : (f % 512 == 0 ? 8 : (f % 256 == 0 ? 4 : 1));
   // A chain of a split call (S.chained) has too few FFN-inner tiles for the automatic engine choice (3 x 32 at 768
@@ -313,11 +314,17 @@ int grow_kv(smi_text_decoder* D, DecWork& S, int rows_pad, int positions, hipStr
 
 constexpr int kKvInitialPositions = 160;
 
-// Number of independent chains for a beam-search call (SMI_DEC_CHAINS overrides; 1 = the single chain).
+// Number of independent chains for a beam-search call (smi_text_decoder_set_chains / SMI_DEC_CHAINS override).
+// Measured on the `basic` decoder, beam 5 (profiles/r04_experiments.txt, experiment 1): 256 sentences = 1280 rows are
+// 160 lone FFN tiles -- one round on 256 CUs -- and two 640-row chains are SLOWER (3.88 -> 4.16-4.25 ms per step: every
+// co-running launch takes 20-30 % longer, the row-bound kernels' gain does not pay for it); 512 sentences = 2560 rows
+// are 320 tiles -- two rounds -- and two 1280-row chains are 19 % FASTER (7.71 -> 6.23 ms per step).  So a call is
+// split when its FFN tiles no longer fit the chip in one round: chains = ceil(rows_pad / 2048), at most kMaxChains.
 int decode_chains(const smi_text_decoder* D, int n, int beam) {
   const int env = DecTuning::env_int("SMI_DEC_CHAINS", 0);
   if (D->flex) return 1;
-  int g = D->chains > 0 ? D->chains : (env > 0 ? env : kDefaultChains);
+  const int64_t rows_pad = round_up((int64_t)n * beam, 256);
+  int g = D->chains > 0 ? D->chains : (env > 0 ? env : (int)((rows_pad + 2047) / 2048));
   g = std::min(g, kMaxChains);
   // every chain keeps at least two 256-row tiles of hypotheses: below that a chain's launches are all fixed cost
   while (g > 1 && (int64_t)((n + g - 1) / g) * beam < 384) --g;

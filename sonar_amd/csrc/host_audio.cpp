@@ -143,6 +143,12 @@ int flac_header(const uint8_t* b, int64_t n, FlacInfo& f) {
   if (!have_info) return fail(SMI_ERR_INVALID_ARG, "FLAC: no STREAMINFO block");
   if (f.bps < 4 || f.bps > 32 || f.rate <= 0) return fail(SMI_ERR_UNSUPPORTED, "FLAC: %d bits, %lld Hz", f.bps, (long long)f.rate);
   f.first_frame = p;
+  // STREAMINFO's 36-bit sample count comes from an untrusted header and sizes the caller's output buffer: refuse a
+  // count the stream cannot hold.  The smallest frame (5-byte header + 1 CRC-8, one constant subframe per channel,
+  // CRC-16) is >= 9 bytes and carries at most 65535 samples per channel.
+  if (f.total > ((n - p) / 9 + 1) * 65535)
+    return fail(SMI_ERR_INVALID_ARG, "FLAC: STREAMINFO claims %lld samples, the stream has %lld bytes of frames",
+                (long long)f.total, (long long)(n - p));
   return SMI_OK;
 }
 
@@ -192,11 +198,14 @@ int flac_subframe(BitReader& br, int64_t* s, int block, int bps) {
     if (order > block) return fail(SMI_ERR_INVALID_ARG, "FLAC: predictor order exceeds the block");
     for (int i = 0; i < order; ++i) s[i] = br.read_signed(bps);
     if (int rc = flac_residual(br, s, block, order)) return rc;
+    // (unsigned arithmetic: a crafted residual may overflow 64 bits before the frame CRC is checked; wrapping is
+    //  defined for uint64_t, the garbage is rejected by the CRC-16 / range checks afterwards)
+    auto U = [&](int i) { return (uint64_t)s[i]; };
     switch (order) {
-      case 1: for (int i = 1; i < block; ++i) s[i] += s[i - 1]; break;
-      case 2: for (int i = 2; i < block; ++i) s[i] += 2 * s[i - 1] - s[i - 2]; break;
-      case 3: for (int i = 3; i < block; ++i) s[i] += 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-      case 4: for (int i = 4; i < block; ++i) s[i] += 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+      case 1: for (int i = 1; i < block; ++i) s[i] = (int64_t)(U(i) + U(i - 1)); break;
+      case 2: for (int i = 2; i < block; ++i) s[i] = (int64_t)(U(i) + 2 * U(i - 1) - U(i - 2)); break;
+      case 3: for (int i = 3; i < block; ++i) s[i] = (int64_t)(U(i) + 3 * U(i - 1) - 3 * U(i - 2) + U(i - 3)); break;
+      case 4: for (int i = 4; i < block; ++i) s[i] = (int64_t)(U(i) + 4 * U(i - 1) - 6 * U(i - 2) + 4 * U(i - 3) - U(i - 4)); break;
       default: break;
     }
   } else if (type >= 32) {  // LPC, order type - 31
@@ -211,9 +220,9 @@ int flac_subframe(BitReader& br, int64_t* s, int block, int bps) {
     for (int j = 0; j < order; ++j) coef[j] = br.read_signed(prec);
     if (int rc = flac_residual(br, s, block, order)) return rc;
     for (int i = order; i < block; ++i) {
-      int64_t acc = 0;
-      for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-      s[i] += acc >> shift;
+      uint64_t acc = 0;  // wrap-safe (see the fixed predictors)
+      for (int j = 0; j < order; ++j) acc += (uint64_t)coef[j] * (uint64_t)s[i - 1 - j];
+      s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)acc >> shift));
     }
   } else {
     return fail(SMI_ERR_INVALID_ARG, "FLAC: reserved subframe type %d", type);
@@ -314,7 +323,16 @@ int flac_decode_stream(const uint8_t* b, int64_t n, const FlacInfo& f, float* ou
   return SMI_OK;
 }
 
-bool is_flac(const uint8_t* b, int64_t n) { return n >= 4 && (!memcmp(b, "fLaC", 4) || !memcmp(b, "ID3", 3)); }
+// native FLAC, optionally behind an ID3v2 tag (an MP3 file starts with the same tag: look for the marker after it)
+bool is_flac(const uint8_t* b, int64_t n) {
+  if (n >= 4 && !memcmp(b, "fLaC", 4)) return true;
+  if (n >= 10 && !memcmp(b, "ID3", 3)) {
+    int64_t p = 10 + (((int64_t)(b[6] & 0x7f) << 21) | ((b[7] & 0x7f) << 14) | ((b[8] & 0x7f) << 7) | (b[9] & 0x7f));
+    if (b[5] & 0x10) p += 10;
+    return p + 4 <= n && !memcmp(b + p, "fLaC", 4);
+  }
+  return false;
+}
 
 }  // namespace
 
@@ -325,6 +343,8 @@ int smi_host_audio_info(const uint8_t* bytes, int64_t nbytes, int32_t* channels,
   if (!bytes || !channels || !sample_rate || !frames) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (!is_flac(bytes, nbytes)) {
     if (nbytes >= 4 && !memcmp(bytes, "OggS", 4)) return fail(SMI_ERR_UNSUPPORTED, "Ogg containers are not covered (WAV and native FLAC are)");
+    if (nbytes >= 3 && (!memcmp(bytes, "ID3", 3) || (bytes[0] == 0xff && (bytes[1] & 0xe0) == 0xe0)))
+      return fail(SMI_ERR_UNSUPPORTED, "MPEG audio is not covered (WAV and native FLAC are)");
     return smi_host_wav_info(bytes, nbytes, channels, sample_rate, frames);
   }
   FlacInfo f;

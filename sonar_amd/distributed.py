@@ -23,13 +23,23 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+_force_collectives = False
+
+
+def force_collectives(enable: bool = True) -> None:
+    """Test hook: make a SINGLE rank issue every collective of the N > 1 path (world size 1) -- how the RCCL calls are
+    executed on a 1-GPU box (tests/test_gpu_rccl.py) and under gloo (tests/test_distributed_cpu.py).  A switch the
+    test sets on the module, not an environment variable production control flow would depend on."""
+    global _force_collectives
+    _force_collectives = bool(enable)
+
+
 def _collectives(ws: int) -> bool:
-    """Whether the exchange steps run.  A single rank skips them -- unless SONAR_FORCE_COLLECTIVES=1 and a process
-    group exists: then every collective of the N > 1 path is issued with world size 1, which is how the RCCL calls
-    are executed on a 1-GPU box (tests/test_gpu_rccl.py)."""
+    """Whether the exchange steps run: always with more than one rank; with one rank only under force_collectives()
+    and an initialised process group."""
     if ws > 1:
         return True
-    return os.environ.get("SONAR_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
+    return _force_collectives and dist.is_available() and dist.is_initialized()
 
 
 def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
@@ -149,7 +159,11 @@ def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, 
     rank, ws = world()
     nx_local, d = x_local.shape
     xn = be.normalize(x_local) if nx_local else None
+    empty = (torch.zeros((0, k), dtype=torch.float32, device=x_local.device),
+             torch.zeros((0, k), dtype=torch.int32, device=x_local.device))
     if not _collectives(ws):
+        if not nx_local or not y_local.shape[0]:
+            return empty
         return be.topk(xn, nx_local, be.normalize(y_local), y_local.shape[0], k)
     # normalise locally (fp16), gather the unpadded rows, then re-pad once
     if y_local.shape[0]:
@@ -158,9 +172,8 @@ def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, 
         yn_local = _empty_normalized(be, y_local)
     yn_all, counts = all_gather_rows(yn_local)
     ny = sum(counts)
-    if not nx_local:
-        return (torch.zeros((0, k), dtype=torch.float32, device=x_local.device),
-                torch.zeros((0, k), dtype=torch.int32, device=x_local.device))
+    if not nx_local or not ny:
+        return empty
     return be.topk(xn, nx_local, be.pad_rows(yn_all, ny), ny, k)
 
 
@@ -197,6 +210,8 @@ def sharded_xsim_error(x_local: torch.Tensor, y_local: torch.Tensor, margin: str
     nx = sum(x_counts)
     if nx != ny:
         raise ValueError(f"xsim expects aligned x and y ({nx} vs {ny} rows in total)")
+    if nx == 0:  # nothing to align on any rank: no error rate to speak of (every collective above has been joined)
+        return float("nan"), torch.zeros(0, dtype=torch.int32, device=dev)
     x_off = _row_offsets(x_counts)[rank]
     errs = torch.zeros(1, dtype=torch.int32, device=dev)
     pred = torch.zeros(0, dtype=torch.int32, device=dev)

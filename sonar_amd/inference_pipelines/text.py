@@ -6,6 +6,8 @@ to-device -> prefetch(2) -> model) is restated with a plain background thread.
 """
 from __future__ import annotations
 
+import contextlib
+
 import queue
 import threading
 import warnings
@@ -216,14 +218,14 @@ class TextToEmbeddingModelPipeline(torch.nn.Module):
             pipeline = add_progress_bar(pipeline, inputs=texts,
                                         batch_size=batch_size if batch_max_tokens is None else None)
         results: List[torch.Tensor] = []
-        with precision_context(self.model.dtype):
+        # the engine's model object checks for out-of-vocabulary ids inside every forward() (one stream
+        # synchronisation each); this loop queues its batches and checks once, when the last one has been launched
+        defer = getattr(self.model, "deferring_check", None)
+        with precision_context(self.model.dtype), (defer() if defer is not None else contextlib.nullcontext()):
             for batch in pipeline:
                 out = self.model(batch)
                 results.append(out.sentence_embeddings.to(target_device or self.device))
-
-        engine = getattr(self.model, "engine", None)
-        if engine is not None and hasattr(engine, "check"):
-            engine.check()  # out-of-vocabulary ids raise IndexError here, as the reference's embedding does
+            # leaving the block: out-of-vocabulary ids raise IndexError here, as the reference's embedding does
         n_truncated += stats["n_truncated"]
         if n_truncated:
             warnings.warn(f"For {n_truncated} input tensors for SONAR text encoder, "

@@ -12,6 +12,8 @@ all arithmetic runs in the hand-written gfx950 kernels.
 """
 from __future__ import annotations
 
+import contextlib
+
 import ctypes as C
 import math
 import re
@@ -104,8 +106,8 @@ def check_supported(cfg: SonarTextEncoderConfig) -> None:
         bad.append(f"activation_fn={cfg.activation_fn}")
     if cfg.pooling not in ("mean", "max", "last", "attention"):
         bad.append(f"pooling={cfg.pooling}")
-    if cfg.embedding_dim not in (None, cfg.model_dim) and cfg.pooling != "attention":
-        bad.append("embedding_dim != model_dim without attention pooling")
+    # (embedding_dim is read by the attention pooler only; with mean / max / last pooling the reference's factory never
+    #  looks at it -- factory.py:108-112 -- and neither does the engine)
     if cfg.model_dim % max(cfg.num_encoder_attn_heads, 1) or cfg.model_dim // max(cfg.num_encoder_attn_heads, 1) > 256:
         bad.append("model_dim must be a multiple of the head count with head_dim <= 256")
     if bad:
@@ -417,8 +419,9 @@ class SonarTextTransformerEncoderModel:
         if dtype not in (torch.float16, torch.bfloat16, torch.float32):
             raise ValueError(f"unsupported model dtype {dtype} (float16, bfloat16 or float32)")
         if fp16_residual is None:
-            # a bf16 model runs the fast path too: its weights are exactly representable as fp16 operands, its
-            # embeddings are rounded to bf16 on the way out (include/sonar_mi355.h, SMI_BF16)
+            # a bf16 model runs the fast path too: its weights are exactly representable as fp16 operands as long as
+            # they lie in fp16's exponent range (|w| in [6.1e-5, 65504]; smaller ones lose mantissa bits as fp16
+            # subnormals), its embeddings are rounded to bf16 on the way out (include/sonar_mi355.h, SMI_BF16)
             fp16_residual = dtype in (torch.float16, torch.bfloat16)
         self.config = cfg
         self.dtype = dtype
@@ -428,9 +431,25 @@ class SonarTextTransformerEncoderModel:
         self.encoder_frontend = _FrontendInfo(cfg.model_max_seq_len)
         self.engine = TextEncoderEngine(cfg, state_dict, device, max_tokens_hint, fp16_residual)
         self.device = self.engine.device
+        # Out-of-vocabulary token ids: the reference's embedding lookup raises IndexError inside forward().  The engine
+        # raises a sticky device flag instead and reports it from `engine.check()` (one stream synchronisation).
+        # forward() runs that check before it returns, so a direct caller never gets embeddings computed from a
+        # wrong table row silently; a caller that queues many batches (predict(), sharded_encode, bench.py) sets
+        # `deferred_check` for its loop and calls `engine.check()` once at the end.
+        self.deferred_check = False
 
     def eval(self):
         return self
+
+    @contextlib.contextmanager
+    def deferring_check(self):
+        """Queue forward() calls without a per-call synchronisation; the out-of-vocabulary check runs once on exit."""
+        prev, self.deferred_check = self.deferred_check, True
+        try:
+            yield self
+        finally:
+            self.deferred_check = prev
+        self.engine.check()
 
     def __call__(self, batch: SequenceBatch) -> SonarEncoderOutput:
         return self.forward(batch)
@@ -444,6 +463,8 @@ class SonarTextTransformerEncoderModel:
             if batch.seqs.is_cuda:  # allocated on the producer's stream: this stream reads it too (allocator reuse)
                 batch.seqs.record_stream(cur)
         emb, enc = self.engine.forward(batch.seqs, lens, self.dtype, self.return_encoded_seqs)
+        if not self.deferred_check:
+            self.engine.check()  # IndexError for out-of-vocabulary ids, as the reference's embedding lookup
         return SonarEncoderOutput(encoded_seqs=enc, sentence_embeddings=emb, padding_mask=batch.padding_mask)
 
 

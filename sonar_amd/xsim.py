@@ -61,7 +61,7 @@ def topk_normalized(xn: torch.Tensor, nx: int, yn: torch.Tensor, ny: int, k: int
     score = torch.empty((nx, k), dtype=torch.float32, device=xn.device)
     with torch.cuda.device(xn.device):
         _lib.check(lib.smi_xsim_topk(xn.data_ptr(), nx, yn.data_ptr(), ny, d, k, y_index_offset,
-                                     idx.data_ptr(), score.data_ptr(), ws.data_ptr(),
+                                     idx.data_ptr(), score.data_ptr(), ws.data_ptr(), ws_bytes,
                                      _lib.current_stream_ptr()))
     return score, idx
 

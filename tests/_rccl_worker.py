@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_rccl.py: ONE rank on cuda:0 with the "nccl" (= RCCL) backend and SONAR_FORCE_COLLECTIVES=1,
+"""Worker of tests/test_gpu_rccl.py: ONE rank on cuda:0 with the "nccl" (= RCCL) backend and distributed.force_collectives(),
 so that every collective of sonar_amd.distributed's N > 1 path is issued through RCCL on the GPU box."""
 import json
 import os
@@ -14,8 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1",
-                      SONAR_FORCE_COLLECTIVES="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sk.close()
     dev = torch.device("cuda", 0)
@@ -23,6 +22,8 @@ def main():
     dist.init_process_group("nccl", device_id=dev)
     from sonar_amd import distributed as D
     from sonar_amd import xsim
+
+    D.force_collectives(True)
 
     res = {"backend": dist.get_backend(), "world": dist.get_world_size(),
            "rccl": ".".join(str(v) for v in torch.cuda.nccl.version())}

@@ -119,6 +119,22 @@ def test_flac_errors_are_reported():
         _decode(b"OggS" + b"\x00" * 64)
     with pytest.raises(_lib.SmiError, match="RIFF"):
         _decode(b"\x00" * 64)
+    # an ID3v2 tag in front of something that is not FLAC (an MP3 file) is not claimed as FLAC
+    with pytest.raises(_lib.SmiError, match="MPEG"):
+        _decode(b"ID3\x04\x00\x00\x00\x00\x00\x10" + b"\x00" * 16 + b"\xff\xfb\x90\x00" + b"\x00" * 64)
+    # STREAMINFO's sample count sizes the caller's buffer: a count the stream cannot hold is refused up front
+    # (2^36 - 1 samples claimed by a 600-byte file would otherwise be a terabyte-sized allocation)
+    huge = bytearray(good)
+    huge[4 + 4 + 13] |= 0x0f
+    huge[4 + 4 + 14: 4 + 4 + 18] = b"\xff\xff\xff\xff"
+    with pytest.raises(_lib.SmiError, match="STREAMINFO claims"):
+        _decode(bytes(huge))
+    # a crafted residual that overflows the predictor is arithmetic garbage, not undefined behaviour: reported
+    wild = bytearray(good)
+    for i in range(60, len(wild) - 4):
+        wild[i] = 0x00
+    with pytest.raises(_lib.SmiError):
+        _decode(bytes(wild))
 
 
 def test_pipeline_reads_flac_files(tmp_path):

@@ -117,7 +117,9 @@ def _xsim_worker(rank, world, port, q, force=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if force:
-        os.environ["SONAR_FORCE_COLLECTIVES"] = "1"
+        from sonar_amd import distributed as _D
+
+        _D.force_collectives(True)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import xsim as OX
@@ -180,7 +182,7 @@ def test_sharded_margin_xsim_gloo(world):
 
 
 def test_forced_collectives_with_one_rank_gloo():
-    """SONAR_FORCE_COLLECTIVES=1: a single rank issues every collective of the N > 1 path (what tests/test_gpu_rccl.py
+    """distributed.force_collectives(): a single rank issues every collective of the N > 1 path (what tests/test_gpu_rccl.py
     does over RCCL on the 1-GPU box) and still returns the single-process result."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -189,3 +191,22 @@ def test_forced_collectives_with_one_rank_gloo():
     res = q.get(timeout=180)
     p.join(timeout=60)
     assert res == (0, "ok"), res
+
+
+def test_empty_inputs_single_process():
+    """Edge cases of the sharded xsim entry points without a process group: no rows at all is not a
+    ZeroDivisionError, and an empty X shard never reaches the mining backend."""
+    import math
+
+    from sonar_amd.distributed import sharded_xsim_error, sharded_xsim_topk
+
+    be = TorchXsimBackend()
+    e0 = torch.zeros((0, 16))
+    for margin in ("cosine", "ratio"):
+        err, pred = sharded_xsim_error(e0, e0, margin, 4, backend=be)
+        assert math.isnan(err) and pred.numel() == 0
+    y = torch.randn(7, 16)
+    s, i = sharded_xsim_topk(e0, y, 2, backend=be)
+    assert s.shape == (0, 2) and i.shape == (0, 2)
+    s, i = sharded_xsim_topk(y, e0, 2, backend=be)
+    assert s.shape == (0, 2) and i.shape == (0, 2)

@@ -1,5 +1,5 @@
 """The N > 1 code path over RCCL on the GPU box.  One GPU per box means one rank -- but with the collectives FORCED
-(SONAR_FORCE_COLLECTIVES / SONAR_BENCH_FORCE_DIST) every all-gather, all-reduce and barrier of sonar_amd.distributed and
+(distributed.force_collectives() / SONAR_BENCH_FORCE_DIST) every all-gather, all-reduce and barrier of sonar_amd.distributed and
 of bench.py's multi-GPU branch is issued through the "nccl" backend on device tensors, and the results must equal the
 single-process ones.  (The multi-rank arithmetic -- uneven shards, merges -- is covered by the gloo tests on CPU.)"""
 import json
