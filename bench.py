@@ -123,6 +123,26 @@ def xsim_cpu_baseline(nx=8192, ny=32768):
                       f"best of 2 ({', '.join(f'{t:.1f}' for t in ts)} s), extrapolated per pair"}
 
 
+def xsim_margin_cpu_baseline(n=8192):
+    """LASER's margin xsim (the oracle's `laser_xsim`: forward + backward k-NN, k = 4, ratio margin) on the host."""
+    import torch
+
+    from oracle import xsim as OX
+
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(n, D, generator=g)
+    x = y + 0.3 * torch.randn(n, D, generator=g)
+    res = {}
+
+    def run():
+        res["err"] = OX.laser_xsim(x, y, "ratio", 4)[0]
+
+    best, ts = best_of(run, reps=2)
+    return {"value": n * n / best, "unit": "pairs/s", "cores": cpu_threads(), "kind": "port", "errors": res["err"],
+            "sample": f"{n} x {n} x {D} fp32 aligned slice, oracle/xsim.py laser_xsim(ratio, k = 4), warm-up 1 + best of 2 "
+                      f"({', '.join(f'{t:.1f}' for t in ts)} s), extrapolated per pair"}
+
+
 def decoder_leg(dev, n=256, steps=64, cpu=True):
     """BASELINE configs[4]: text_sonar_basic_decoder, beam 5, fp16, batch 256, `steps` forced steps; CPU baseline:
     the oracle's incremental beam search (the reference's evaluation order) on a bounded sample, same weights."""
@@ -271,6 +291,43 @@ class _StubXsim:
         return v, (i + y_index_offset).int()
 
 
+def _with_rccl_log(collective: dict, path) -> dict:
+    """RCCL's own init lines (NCCL_DEBUG=INFO, subsystem INIT, written to a file): the `nranks` of the communicator."""
+    if path and os.path.exists(path):
+        try:
+            with open(path, "r", errors="replace") as fh:
+                lines = [ln.strip() for ln in fh if "nranks" in ln or "NCCL version" in ln or "RCCL version" in ln]
+            collective["rccl_init_lines"] = [ln[-220:] for ln in lines[:4]]
+        except OSError:
+            pass
+    return collective
+
+
+class _StubBackend:
+    """The five-method xsim backend of sonar_amd.distributed on the CPU stub (dry run of --xsim-ring)."""
+
+    def __init__(self, xs):
+        self.xs = xs
+
+    def normalize(self, t):
+        return self.xs.normalize_rows(t)
+
+    def pad_rows(self, tn, n):
+        import torch
+
+        pad = self.xs.padded(n) - tn.shape[0]
+        return torch.cat([tn, tn.new_zeros((pad, tn.shape[1]))]) if pad > 0 else tn
+
+    def topk(self, xn, nx, yn, ny, k, y_index_offset=0):
+        return self.xs.topk_normalized(xn, nx, yn, ny, k, y_index_offset)
+
+    def merge_topk(self, part_scores, part_idx=None):
+        p, n, k = part_scores.shape
+        flat = part_scores.permute(1, 0, 2).reshape(n, p * k)
+        v, o = flat.topk(k, dim=1)
+        return v, (part_idx.permute(1, 0, 2).reshape(n, p * k).gather(1, o) if part_idx is not None else None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,6 +335,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-xsim", action="store_true")
+    ap.add_argument("--xsim-ring", action="store_true",
+                    help="N > 1: rotate the Y shards around the ranks under the mining (sonar_amd.distributed, ring=True) "
+                         "instead of all-gathering Y first")
     ap.add_argument("--no-extras", action="store_true", help="skip the varlen / C1 / decoder (C5) / speech (C4) legs")
     ap.add_argument("--xsim-n", type=int, default=1 << 20,
                     help="rows of X and of Y IN TOTAL (BASELINE configs[2]: 1M x 1M); both are sharded over the ranks")
@@ -324,6 +384,7 @@ def main():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1")
         sk.close()
     batch_n, seq = (BATCH, SEQ) if not DRYRUN else (8, 16)
+    rccl_log = None
     if DRYRUN:
         dev = torch.device("cpu")
         sync = lambda: None
@@ -342,6 +403,9 @@ def main():
         sync = torch.cuda.synchronize
         if use_dist:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if "NCCL_DEBUG" not in os.environ:  # RCCL's own account of the communicator ("... nranks N ... Init COMPLETE")
+                rccl_log = f"/tmp/sonar_bench_rccl_{os.getpid()}.log"
+                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=rccl_log)
             dist.init_process_group("nccl", device_id=dev)
         padded_rows = lambda n: int(xs_mod._lib.load().smi_xsim_padded_rows(n))
     # what the process group actually is (the first SCALE record must prove N ranks over RCCL)
@@ -352,6 +416,19 @@ def main():
             collective["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             collective["rccl_version"] = None
+
+    if use_dist:  # one fact sheet per rank, gathered on every rank, printed by rank 0
+        import socket as _socket
+
+        me = {"rank": rank, "local_rank": local_rank, "host": _socket.gethostname(), "pid": os.getpid()}
+        if not DRYRUN:
+            props = torch.cuda.get_device_properties(dev)
+            me.update(device=str(dev), name=props.name, cus=props.multi_processor_count,
+                      hbm_gb=round(props.total_memory / 2**30, 1),
+                      pci=getattr(props, "pci_bus_id", None), uuid=str(getattr(props, "uuid", "")))
+        facts = [None] * (dist.get_world_size())
+        dist.all_gather_object(facts, me)
+        collective["ranks"] = facts
 
     def barrier():
         if use_dist:
@@ -527,6 +604,12 @@ def main():
             yn = xs_mod.normalize_rows(y_local)
             if not use_dist:
                 return xs_mod.topk_normalized(xn, nloc, yn, nloc, 1)
+            if args.xsim_ring:  # Y shards rotate around the ranks under the mining; per-shard lists merged at the end
+                from sonar_amd import distributed as sdist
+
+                sdist.force_collectives(world == 1)
+                return sdist.sharded_xsim_topk(x_local, y_local, 1, backend=_StubBackend(xs_mod) if DRYRUN else None,
+                                               ring=True)
             if dense:
                 dist.all_gather_into_tensor(yn_all, yn)  # assemble Y over RCCL / xGMI (2 KB per row)
                 return xs_mod.topk_normalized(xn, nloc, yn_all, n_total, 1)
@@ -557,13 +640,43 @@ def main():
               "d": D, "k": 1, "tflops": pairs * 2 * D / xt / 1e12,
               "frac_of_mfma_peak": pairs * 2 * D / xt / 1e12 / (MFMA_PEAK_TFLOPS * world),
               "includes": "row normalisation of X and Y, Y all-gather (N>1), top-1 mining + chunk merge",
+              "y_exchange": ("ring rotation under the mining (--xsim-ring)" if use_dist and args.xsim_ring else
+                             ("all-gather" if use_dist else None)),
               "top1_agreement_with_constructed_neighbours": top1_agree,
               "normalise": {"ms": nt_ * 1e3, "bytes": nloc * D * 4, "achieved_GBs": nloc * D * 4 / nt_ / 1e9,
                             "frac_of_hbm_peak": nloc * D * 4 / nt_ / 1e9 / 8000.0},
               "scaling": "strong (the 1M x 1M problem is fixed, X rows are split over the ranks)"}
+        # xsim as LASER defines it (source/xsim.py, margin "ratio", k = 4): forward top-4 (x -> y), backward top-4
+        # (y -> x), margin re-scoring of the forward candidates; N = 1 only.  The error is counted against the
+        # constructed neighbours (x_i was built from y_src(i)), so it must be 0.
+        if world == 1 and not args.no_extras and not DRYRUN:
+            def margin_mine():
+                xn = xs_mod.normalize_rows(x_local)
+                yn = xs_mod.normalize_rows(y_local)
+                fs, fi = xs_mod.topk_normalized(xn, nloc, yn, nloc, 4)
+                bs, _ = xs_mod.topk_normalized(yn, nloc, xn, nloc, 4)
+                return xs_mod.margin_select(fs, fi, bs, "ratio")
+
+            mreps = 2
+            mt = timed(margin_mine, mreps, 1) / mreps
+            mpred, _ = margin_mine()
+            merr = float((mpred.long() != src_local).sum().item()) / nloc
+            t4 = timed(lambda: xs_mod.topk_normalized(xs_mod.normalize_rows(x_local), nloc,
+                                                      xs_mod.normalize_rows(y_local), nloc, 4), 1, 0)
+            xs["margin"] = {"workload": f"xsim, ratio margin, k = 4 (LASER xsim.py): {n_total} x {n_total} x {D} fp16 on one "
+                                        "GPU -- forward top-4 + backward top-4 + margin select, normalisation included",
+                            "ms": mt * 1e3, "pairs_per_s": pairs / mt, "tflops": 2 * pairs * 2 * D / mt / 1e12,
+                            "frac_of_mfma_peak": 2 * pairs * 2 * D / mt / 1e12 / MFMA_PEAK_TFLOPS,
+                            "error_rate_vs_constructed_neighbours": merr,
+                            "top4_one_direction_ms": t4 * 1e3,
+                            "top4_frac_of_mfma_peak": pairs * 2 * D / t4 / 1e12 / MFMA_PEAK_TFLOPS,
+                            "note": "pairs_per_s counts each (x, y) pair once; the margin needs the score matrix in both "
+                                    "directions, so tflops = 2 x 2 d flop per pair"}
         del x_local, y_local, yn_all, src_local
         if rank == 0 and world == 1 and not args.no_cpu_baseline and not DRYRUN:
             xs["cpu_baseline"] = xsim_cpu_baseline()
+            if "margin" in xs:
+                xs["margin"]["cpu_baseline"] = xsim_margin_cpu_baseline()
 
     # ------------------------------------------------- secondary configs (BASELINE C4 / C5), N = 1 only
     if world == 1 and not args.no_extras and not DRYRUN:
@@ -612,7 +725,7 @@ def main():
                        "c2_max_1_minus_cos_vs_cpu_oracle": cb.get("c2_max_1_minus_cos_vs_gpu") if cb else None,
                        "c1_max_1_minus_cos_vs_cpu_oracle": extra.get("c1", {}).get("max_1_minus_cos_vs_cpu_oracle"),
                        "xsim_top1_agreement": xs.get("top1_agreement_with_constructed_neighbours") if xs else None},
-            "collective": collective,
+            "collective": _with_rccl_log(collective, rccl_log),
             "encoder_tflops": value * FLOPS_PER_SENTENCE / 1e12,
             "encoder_frac_of_mfma_peak": value * FLOPS_PER_SENTENCE / 1e12 / (MFMA_PEAK_TFLOPS * world),
             "kernels": kernels, "hbm_kernels": hbm_kernels, "xsim": xs, **extra,

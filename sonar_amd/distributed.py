@@ -152,15 +152,63 @@ def _row_offsets(counts: Sequence[int]) -> List[int]:
     return offs
 
 
-def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, backend=None):
+def _ring_xsim_topk(be, xn, nx_local: int, y_local: torch.Tensor, k: int):
+    """Forward mining with the Y shards ROTATED around the ranks instead of all-gathered: in step s a rank mines its X
+    rows against the shard of rank (rank - s) mod ws while that shard travels on to rank + 1 (one isend + one irecv
+    per step, posted BEFORE the mining call, so on RCCL the transfer runs on the communicator's stream under the
+    mining kernel); the per-shard top-k lists are k-way merged at the end (same total order: score desc, index asc).
+    A rank holds two shards instead of all of Y, and no step waits for more than one neighbour."""
+    rank, ws = world()
+    dev = y_local.device
+    d = y_local.shape[1]
+    cnt = torch.tensor([y_local.shape[0]], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(ws)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    offs = _row_offsets(counts)
+    ny = offs[-1]
+    # one fixed-size, zero-padded buffer per shard (the engine's row multiple): what arrives can be mined as it is
+    yn_local = be.normalize(y_local)[: y_local.shape[0]] if y_local.shape[0] else _empty_normalized(be, y_local)[:0]
+    n_pad = be.pad_rows(yn_local.new_zeros((max(max(counts), 1), d)), max(max(counts), 1)).shape[0]
+    cur = yn_local.new_zeros((n_pad, d))
+    cur[: yn_local.shape[0]] = yn_local
+    nxt = torch.empty_like(cur)
+    part_s, part_i = [], []
+    for s in range(ws):
+        owner = (rank - s) % ws
+        reqs = []
+        if s + 1 < ws:  # pass the shard on while it is mined
+            ops = [dist.P2POp(dist.isend, cur, (rank + 1) % ws), dist.P2POp(dist.irecv, nxt, (rank - 1) % ws)]
+            reqs = dist.batch_isend_irecv(ops)
+        if nx_local and counts[owner]:
+            ps, pi = be.topk(xn, nx_local, cur, counts[owner], min(k, counts[owner]), offs[owner])
+            if ps.shape[1] < k:  # a shard smaller than k: pad its list, the merge drops the padding
+                ps = torch.cat([ps, ps.new_full((nx_local, k - ps.shape[1]), float("-inf"))], dim=1)
+                pi = torch.cat([pi, pi.new_full((nx_local, k - pi.shape[1]), -1)], dim=1)
+            part_s.append(ps)
+            part_i.append(pi)
+        for r in reqs:
+            r.wait()
+        cur, nxt = nxt, cur
+    if not nx_local or not ny:
+        return (torch.zeros((0, k), dtype=torch.float32, device=dev), torch.zeros((0, k), dtype=torch.int32, device=dev))
+    if len(part_s) == 1:
+        return part_s[0], part_i[0]
+    return be.merge_topk(torch.stack(part_s), torch.stack(part_i))
+
+
+def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, backend=None, ring: bool = False):
     """Rows of X and Y are sharded over ranks (rank order = row order).  Returns, for the
-    local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k])."""
+    local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k]).  `ring`: rotate the Y shards around the
+    ranks under the mining (see _ring_xsim_topk) instead of all-gathering Y first."""
     be = backend or EngineXsimBackend()
     rank, ws = world()
     nx_local, d = x_local.shape
     xn = be.normalize(x_local) if nx_local else None
     empty = (torch.zeros((0, k), dtype=torch.float32, device=x_local.device),
              torch.zeros((0, k), dtype=torch.int32, device=x_local.device))
+    if ring and _collectives(ws):
+        return _ring_xsim_topk(be, xn, nx_local, y_local, k)
     if not _collectives(ws):
         if not nx_local or not y_local.shape[0]:
             return empty

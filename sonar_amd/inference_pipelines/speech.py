@@ -32,7 +32,7 @@ from .. import _lib
 from ..speech_encoder import (SonarSpeechEncoderModel, fbank_batch_flat, load_sonar_speech_encoder,
                               waveform_to_fbank, waveforms_to_fbank_batch)  # noqa: F401
 from ..text_encoder import PaddingMask, SequenceBatch
-from .utils import add_progress_bar
+from .utils import add_progress_bar, extract_sequence_batch
 
 CPU = torch.device("cpu")
 
@@ -68,13 +68,37 @@ def read_wav(path: Union[str, Path]) -> torch.Tensor:
 
 @dataclass
 class SpeechInferenceParams:
-    """sonar/inference_pipelines/speech.py:42-73 (fields that apply to waveform inputs)."""
+    """sonar/inference_pipelines/speech.py:42-73 -- the configuration of the TSV-driven pipelines below (same fields,
+    same order, same defaults; `device` must be the HIP device of the engine)."""
 
-    batch_size: int = 3
+    data_file: Path
+    """The pathname of the test TSV data file."""
+
+    audio_root_dir: Path
+    """The pathname of the directory under which audio files are stored."""
+
+    audio_path_index: int
+    """Column index of audio path in given TSV data file."""
+
+    batch_size: int
+    """The batch size for model input."""
+
     fbank_dtype: torch.dtype = torch.float32
-    n_parallel: int = 1
+
+    target_lang: Optional[str] = None
+    """The target translation language."""
+
     pad_idx: int = 0
-    n_prefetched_batches: int = 2
+    """Padding idx to use after applying fbank"""
+
+    device: torch.device = CPU
+    """The device on which to run inference."""
+
+    n_parallel: int = 4
+    """Number of parallel calls when running the pipeline."""
+
+    n_prefetched_batches: int = 4
+    """Number of prefetched batches"""
 
 
 @dataclass
@@ -276,3 +300,203 @@ class SpeechToTextModelPipeline(SpeechModelPipelineInterface):
             out.extend(self.vec2t.predict(emb, target_lang=target_lang, batch_size=emb.shape[0],
                                           source_len=src_len, **generator_kwargs))
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# TSV-driven pipelines (sonar/inference_pipelines/speech.py:76-274): the reference's own golden test drives the speech
+# encoder through these (tests/integration_tests/test_sonar_speech_encoder.py:27-78).  fairseq2's DataPipelineBuilder
+# is replaced by a small lazy builder with the operators these pipelines use (map with a selector, and_return); the
+# stages themselves -- file read + decode on `n_parallel` host threads, bucketing, ONE filterbank launch per bucket that
+# writes the Collater(pad_value, pad_to_multiple=2) layout, prefetch -- are the model pipelines' host / device halves.
+class DataPipeline:
+    """Re-iterable result of `DataPipelineBuilder.and_return()` (fairseq2.data.DataPipeline)."""
+
+    def __init__(self, source, stages) -> None:
+        self._source, self._stages = source, list(stages)
+
+    def __iter__(self):
+        for item in self._source():
+            for fn, selector in self._stages:
+                item = _apply_selected(item, fn, selector)
+            yield item
+
+    def reset(self) -> None:  # fairseq2 API; every __iter__ starts from the beginning here
+        pass
+
+
+def _apply_selected(item, fn, selector: Optional[str]):
+    """fairseq2's `map(fn, selector="a.b.c")`: replace the element at that path of nested dicts by fn(element)."""
+    if not selector:
+        return fn(item)
+    keys = selector.split(".")
+    node = item
+    for k in keys[:-1]:
+        node = node[k]
+    node[keys[-1]] = fn(node[keys[-1]])
+    return item
+
+
+class DataPipelineBuilder:
+    """The subset of fairseq2.data.DataPipelineBuilder the speech pipelines compose with."""
+
+    def __init__(self, source) -> None:
+        self._source, self._stages = source, []
+
+    def map(self, fn, selector: Optional[str] = None, num_parallel_calls: int = 1) -> "DataPipelineBuilder":
+        fns = list(fn) if isinstance(fn, (list, tuple)) else [fn]
+        for f in fns:
+            self._stages.append((f, selector))
+        return self
+
+    def and_return(self) -> DataPipeline:
+        return DataPipeline(self._source, self._stages)
+
+
+class SpeechInferencePipeline:
+    """speech.py:77-92."""
+
+    def prebuild_pipeline(self, context: SpeechInferenceParams) -> DataPipelineBuilder:
+        raise NotImplementedError
+
+    def build_pipeline(self, context: SpeechInferenceParams) -> DataPipeline:
+        return self.prebuild_pipeline(context).and_return()
+
+
+def read_tsv_column(data_file: Union[str, Path], index: int) -> List[str]:
+    """`read_text(data_file, rtrim=True).skip(1).map(StrSplitter(indices=[index]))` (speech.py:99-108): the `index`-th
+    tab-separated field of every line after the header."""
+    out: List[str] = []
+    with open(str(data_file), "r", encoding="utf-8") as fh:
+        for ln, line in enumerate(fh):
+            if ln == 0:
+                continue
+            line = line.rstrip()
+            if not line:
+                continue
+            fields = line.split("\t")
+            if index >= len(fields):
+                raise ValueError(f"{data_file}:{ln + 1}: no column {index} in a line of {len(fields)} fields")
+            out.append(fields[index])
+    return out
+
+
+class AudioToFbankDataPipelineBuilder(SpeechInferencePipeline):
+    """speech.py:95-151: TSV -> audio files under `audio_root_dir` -> decode -> fbank (80 bins, scale 2**15,
+    standardised) -> buckets of `batch_size` -> Collater(pad_idx, pad_to_multiple=2) -> prefetch.  Elements are what
+    the reference's pipeline yields after the collate step:
+    {"audio": {"path": [...], "data": {"fbank": {"seqs" [n, T, 80], "seq_lens" [n], "is_ragged"},
+                                       "sample_rate": [...]}}}."""
+
+    def _batches(self, context: SpeechInferenceParams, paths: Sequence[Path]) -> Iterator[Tuple[SequenceBatch, List[int]]]:
+        """Decode + filterbank + collate for every bucket of `batch_size` files: the model pipelines' host half
+        (threads, pinned staging, side-stream H2D, prefetch) and ONE filterbank launch per bucket."""
+        dev = torch.device(context.device)
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X SONAR engine needs device='cuda[:i]' (no CPU path)")
+        host = SpeechModelPipelineInterface()
+        host.device = dev
+        for hb in host._prefetched(list(paths), context.batch_size, context.n_parallel, context.n_prefetched_batches):
+            yield host._fbank_batch(hb, context.pad_idx)
+
+    def prebuild_pipeline(self, context: SpeechInferenceParams) -> DataPipelineBuilder:
+        if context.batch_size <= 0:
+            raise ValueError("`batch_size` should be strictly positive")
+        names = read_tsv_column(context.data_file, context.audio_path_index)
+        root = Path(context.audio_root_dir)
+        paths = [root / n for n in names]
+
+        def source():
+            bs = context.batch_size
+            buckets = (paths[i:i + bs] for i in range(0, len(paths), bs))
+            for (batch, lens), bucket in zip(self._batches(context, paths), buckets):
+                fb = batch.seqs
+                if context.fbank_dtype != torch.float32:
+                    fb = fb.to(context.fbank_dtype)
+                t = fb.shape[1]
+                yield {"audio": {"path": [str(p) for p in bucket],
+                                 "data": {"fbank": {"seqs": fb, "seq_lens": torch.tensor(lens, dtype=torch.int64),
+                                                    "is_ragged": any(l != t for l in lens)},
+                                          "sample_rate": [16000.0] * len(bucket)}}}
+
+        return DataPipelineBuilder(source)
+
+
+class SpeechToEmbeddingPipeline(SpeechInferencePipeline):
+    """speech.py:154-203.  `build_pipeline(ctx)` yields, per bucket, {"audio": {"path", "data": SonarEncoderOutput}}."""
+
+    audio_to_fbank_dp_builder: AudioToFbankDataPipelineBuilder = AudioToFbankDataPipelineBuilder()
+    model: SonarSpeechEncoderModel
+
+    def __init__(self, model: SonarSpeechEncoderModel) -> None:
+        self.model = model.eval()
+
+    @classmethod
+    def load_model_from_name(cls, encoder_name: str, device: Union[str, torch.device] = "cuda:0",
+                             dtype: torch.dtype = torch.float32) -> "SpeechToEmbeddingPipeline":
+        """A card name is resolved under $SONAR_CHECKPOINT_DIR (sonar_amd/cards.py); the reference loads on the CPU and
+        moves the model in prebuild_pipeline -- the engine is created on its HIP device straight away."""
+        return cls(model=load_sonar_speech_encoder(encoder_name, device=torch.device(device), dtype=dtype))
+
+    def prebuild_pipeline(self, context: SpeechInferenceParams) -> DataPipelineBuilder:
+        _same_device(self.model, context.device)
+        return (self.audio_to_fbank_dp_builder.prebuild_pipeline(context)
+                .map(lambda fbank: extract_sequence_batch(fbank, context.device), selector="audio.data.fbank")
+                .map(self.run_inference, selector="audio.data"))
+
+    @torch.inference_mode()
+    def run_inference(self, data: dict):
+        return self.model(data["fbank"])
+
+
+class SpeechToTextPipeline(SpeechInferencePipeline):
+    """speech.py:206-274: speech -> text translation; `build_pipeline(ctx)` yields {"audio": {"path", "data": [texts]}}."""
+
+    audio_to_fbank_dp_builder: AudioToFbankDataPipelineBuilder = AudioToFbankDataPipelineBuilder()
+
+    def __init__(self, model, tokenizer) -> None:
+        self.model = model.eval()
+        self.tokenizer = tokenizer
+
+    @classmethod
+    def load_model_from_name(cls, encoder_name: str, decoder_name: str, device: Union[str, torch.device] = "cuda:0",
+                             dtype: torch.dtype = torch.float32) -> "SpeechToTextPipeline":
+        from ..cards import resolve_tokenizer
+        from ..text_decoder import SonarEncoderDecoderModel, load_sonar_text_decoder
+        from ..tokenizer import NllbTokenizer
+
+        device = torch.device(device)
+        tokenizer = NllbTokenizer(resolve_tokenizer(decoder_name))
+        encoder = load_sonar_speech_encoder(encoder_name, device=device, dtype=dtype)
+        decoder = load_sonar_text_decoder(decoder_name, device=device, dtype=dtype)
+        return cls(model=SonarEncoderDecoderModel(encoder, decoder).eval(), tokenizer=tokenizer)
+
+    def prebuild_pipeline(self, context: SpeechInferenceParams) -> DataPipelineBuilder:
+        assert context.target_lang is not None
+        _same_device(self.model.decoder, context.device)
+        from .text import EmbeddingToTextModelPipeline
+
+        vec2t = EmbeddingToTextModelPipeline(self.model.decoder, self.tokenizer, device=context.device)
+
+        @torch.inference_mode()
+        def _do_generate(data: dict) -> List[str]:
+            batch: SequenceBatch = data["fbank"]
+            emb = self.model.encoder(batch).sentence_embeddings
+            # fairseq2 caps the output at a * source_len + b with the (padded) fbank frame count as source length
+            return vec2t.predict(emb, target_lang=context.target_lang, batch_size=emb.shape[0],
+                                 source_len=batch.seqs.shape[1])
+
+        return (self.audio_to_fbank_dp_builder.prebuild_pipeline(context)
+                .map(lambda fbank: extract_sequence_batch(fbank, context.device), selector="audio.data.fbank")
+                .map(_do_generate, selector="audio.data"))
+
+
+def _same_device(model, device) -> None:
+    """`self.model.to(context.device)` of the reference: an engine cannot move, so the devices must agree."""
+    have = torch.device(getattr(model, "device", device))
+    want = torch.device(device)
+    if want.type == "cuda" and want.index is None:
+        want = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    if have.type == "cuda" and have.index is None:
+        have = torch.device("cuda", 0)
+    if have != want:
+        raise RuntimeError(f"context.device is {device} but the engine was created on {have}")

@@ -346,6 +346,45 @@ class ConditionalTransformerDecoderModel:
         return self
 
 
+class SonarEncoderDecoderModel:
+    """sonar/models/sonar_translation/model.py:24-78: the (encoder, decoder) pair fairseq2's generators drive through
+    encode / decode / project.  Here generation runs inside the decoder engine, so the object only holds the two
+    engine-backed models the speech / text translation pipelines hand around (`model.encoder(batch)
+    .sentence_embeddings` is what `encode` returns, unsqueezed, in the reference)."""
+
+    def __init__(self, encoder, decoder: ConditionalTransformerDecoderModel) -> None:
+        enc_dim, dec_dim = getattr(encoder, "model_dim", None), getattr(decoder, "model_dim", None)
+        if enc_dim is not None and dec_dim is not None and enc_dim != dec_dim:
+            raise ValueError(f"`model_dim` of `encoder` and `model_dim` of `decoder` must be equal, but are {enc_dim} "
+                             f"and {dec_dim} instead.")
+        self.encoder = encoder
+        self.decoder = decoder
+        self.model_dim = dec_dim
+        self.max_target_seq_len = getattr(decoder, "max_target_seq_len", None)
+
+    @property
+    def dtype(self):
+        return self.encoder.dtype
+
+    @property
+    def device(self):
+        return self.decoder.device
+
+    def eval(self):
+        return self
+
+    def to(self, device=None, dtype=None):
+        """The engines live on the HIP device they were created on; `.to` accepts that device and nothing else."""
+        if device is not None and torch.device(device).type != "cpu" and torch.device(device) != torch.device(self.device):
+            raise RuntimeError(f"the engine-backed model lives on {self.device}")
+        return self
+
+    def encode(self, seqs: torch.Tensor, padding_mask=None):
+        from .text_encoder import SequenceBatch
+
+        return self.encoder(SequenceBatch(seqs, padding_mask)).sentence_embeddings.unsqueeze(1), None
+
+
 def load_sonar_text_decoder(checkpoint: Union[str, Mapping], arch: str = "basic",
                             device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
                             config: Optional[SonarTextDecoderConfig] = None,

@@ -43,6 +43,8 @@ def main():
     s1, i1 = xsim.topk(x, y, 4)
     s2, i2 = D.sharded_xsim_topk(x, y, 4)
     res["topk_ok"] = bool(torch.equal(i1, i2[:n])) and bool(torch.equal(s1, s2[:n]))
+    s3, i3 = D.sharded_xsim_topk(x, y, 4, ring=True)   # ring rotation of the Y shards (one rank: its own shard only)
+    res["ring_ok"] = bool(torch.equal(i1, i3[:n])) and bool(torch.equal(s1, s3[:n]))
     for margin in ("cosine", "ratio", "distance"):
         e1, p1 = xsim.xsim_error(x, y, margin)
         e2, p2 = D.sharded_xsim_error(x, y, margin)

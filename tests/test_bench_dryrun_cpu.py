@@ -21,7 +21,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,form", [(1, "plain"), (2, "torchrun"), (4, "torchrun"), (2, "plain"), (4, "plain")])
+@pytest.mark.parametrize("world,form", [(1, "plain"), (2, "torchrun"), (4, "torchrun"), (2, "plain"), (4, "plain"),
+                                        (8, "torchrun"), (8, "plain-ring"), (2, "torchrun-ring")])
 def test_bench_control_flow_dry_run(world, form):
     """form "torchrun": the driver's documented N > 1 command; form "plain": `python bench.py --gpus N` with no
     WORLD_SIZE in the environment -- bench.py then launches its own ranks (round-2 verdict: the first SCALE
@@ -30,6 +31,10 @@ def test_bench_control_flow_dry_run(world, form):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     args = ["--gpus", str(world), "--steps", "3", "--warmup", "1"]
+    ring = form.endswith("-ring")       # --xsim-ring: Y shards rotated around the ranks under the mining
+    if ring:
+        args.append("--xsim-ring")
+        form = form[:-5]
     if form == "plain":
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
     else:
@@ -47,6 +52,10 @@ def test_bench_control_flow_dry_run(world, form):
     assert abs(out["value"] - 8 * world * 3 / (out["ms_per_step"] * 3 / 1e3)) / out["value"] < 1e-6
     assert out["collective"]["world_size"] == world
     assert out["collective"]["backend"] == ("gloo" if world > 1 else None)
+    if world > 1:   # one fact sheet per rank (the first real SCALE record must show N distinct ranks)
+        assert [f["rank"] for f in out["collective"]["ranks"]] == list(range(world))
+        assert len({f["pid"] for f in out["collective"]["ranks"]}) == world
+        assert out["xsim"]["y_exchange"].startswith("ring" if ring else "all-gather")
     xs = out["xsim"]
     assert xs["nx_total"] == xs["ny_total"] == 512 * world and xs["nx_per_gpu"] == 512 and xs["pairs_per_s"] > 0
     # the timed xsim configuration checks itself: the constructed neighbour of every row, global indices over ranks

@@ -97,8 +97,14 @@ class TorchXsimBackend:
     def merge_topk(self, part_scores, part_idx=None):
         p, n, k = part_scores.shape
         flat = part_scores.permute(1, 0, 2).reshape(n, p * k)
-        o = torch.sort(flat, dim=1, descending=True, stable=True)
-        return o.values[:, :k].contiguous(), None
+        if part_idx is None:
+            o = torch.sort(flat, dim=1, descending=True, stable=True)
+            return o.values[:, :k].contiguous(), None
+        fi = part_idx.permute(1, 0, 2).reshape(n, p * k).long()
+        # total order of the engine's merge: score descending, index ascending
+        o1 = torch.sort(fi, dim=1, stable=True)
+        o2 = torch.sort(flat.gather(1, o1.indices), dim=1, descending=True, stable=True)
+        return o2.values[:, :k].contiguous(), o1.values.gather(1, o2.indices)[:, :k].to(torch.int32).contiguous()
 
     def margin_select(self, fs, fi, bs, margin, x_index_offset, err_count):
         if margin == "cosine":
@@ -140,6 +146,9 @@ def _xsim_worker(rank, world, port, q, force=False):
         s, idx = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be)
         rs, ri = OX.cosine_topk(x, y, 3)
         assert torch.equal(idx.long(), ri[xb:xe]) and torch.allclose(s, rs[xb:xe], atol=1e-6)
+        # the same with the Y shards rotated around the ranks under the mining instead of all-gathered
+        s2, idx2 = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be, ring=True)
+        assert torch.equal(idx2.long(), ri[xb:xe]) and torch.allclose(s2, rs[xb:xe], atol=1e-6)
         for m in ("cosine", "ratio", "distance"):
             err, pred = sharded_xsim_error(x[xb:xe], y[yb:ye], margin=m, k=4, backend=be)
             assert abs(err - fx[m + "_err"] / n) < 1e-12, (m, err, fx[m + "_err"])
@@ -152,6 +161,8 @@ def _xsim_worker(rank, world, port, q, force=False):
             xb, xe, yb, ye = xcut[rank], xcut[rank + 1], ycut[rank], ycut[rank + 1]
             s, idx = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be)
             assert idx.shape == (xe - xb, 3) and torch.equal(idx.long(), ri[xb:xe])
+            s2, idx2 = sharded_xsim_topk(x[xb:xe], y[yb:ye], k=3, backend=be, ring=True)   # shards of 1 and 0 rows
+            assert idx2.shape == (xe - xb, 3) and torch.equal(idx2.long(), ri[xb:xe])
             for m in ("cosine", "ratio", "distance"):
                 err, pred = sharded_xsim_error(x[xb:xe], y[yb:ye], margin=m, k=4, backend=be)
                 assert abs(err - fx[m + "_err"] / n) < 1e-12, (m, err, fx[m + "_err"])

@@ -39,5 +39,8 @@ def test_bench_multi_gpu_branch_over_rccl_with_one_rank():
     print({k: rec[k] for k in ("value", "n_gpus", "collective")}, rec["xsim"]["top1_agreement_with_constructed_neighbours"])
     assert rec["collective"]["backend"] == "nccl" and rec["collective"]["world_size"] == 1
     assert rec["collective"]["rccl_version"]
+    # the per-rank fact sheet and RCCL's own init lines (NCCL_DEBUG=INFO into a file) ride in rank 0's JSON
+    assert rec["collective"]["ranks"][0]["rank"] == 0 and rec["collective"]["ranks"][0]["cus"] > 0
+    print("RCCL init:", rec["collective"].get("rccl_init_lines"))
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["xsim"]["top1_agreement_with_constructed_neighbours"] == 1.0

@@ -184,6 +184,51 @@ def test_speech_to_text_model_pipeline():
     assert s2t.predict(AUDIO, target_lang="fra_Latn", batch_size=4) == fra
 
 
+def _tsv_params(target_lang="fra_Latn"):
+    from sonar_amd.inference_pipelines import SpeechInferenceParams
+
+    # test_sonar_speech_encoder.py:38-48, field for field (the wavs sit next to the TSV here, not in audio_files/)
+    return SpeechInferenceParams(data_file=DATA.joinpath("audio_ref.tsv"), audio_root_dir=DATA, audio_path_index=1,
+                                 target_lang=target_lang, batch_size=4, pad_idx=0, device=DEV,
+                                 fbank_dtype=torch.float32, n_parallel=1)
+
+
+@needs("sonar_speech_encoder_eng")
+def test_tsv_speech_to_embedding_pipeline_golden():
+    """test_sonar_speech_encoder.py:69-78, call for call: SpeechToEmbeddingPipeline(encoder).build_pipeline(params),
+    first element, `["audio"]["data"].sentence_embeddings` against speech_embedding.pt."""
+    from sonar_amd.inference_pipelines import SpeechToEmbeddingPipeline
+    from sonar_amd.speech_encoder import load_sonar_speech_encoder
+
+    encoder = load_sonar_speech_encoder("sonar_speech_encoder_eng", device=DEV, dtype=torch.float32)
+    dp = SpeechToEmbeddingPipeline(encoder).build_pipeline(_tsv_params())
+    actual = next(iter(dp))
+    got = actual["audio"]["data"].sentence_embeddings.float().cpu()
+    want = torch.load(DATA / "speech_embedding.pt").float()
+    cos = torch.nn.functional.cosine_similarity(got, want, dim=-1)
+    print("TSV pipeline 1 - cos", (1 - cos).tolist())
+    assert (1 - cos).max().item() <= 1e-3
+
+
+@needs("sonar_speech_encoder_eng", "text_sonar_basic_decoder")
+def test_tsv_speech_to_text_pipeline_golden():
+    """test_sonar_speech_encoder.py:56-67: SpeechToTextPipeline(SonarEncoderDecoderModel(encoder, decoder), tokenizer)."""
+    from sonar_amd.cards import resolve_tokenizer
+    from sonar_amd.inference_pipelines import SpeechToTextPipeline
+    from sonar_amd.speech_encoder import load_sonar_speech_encoder
+    from sonar_amd.text_decoder import SonarEncoderDecoderModel, load_sonar_text_decoder
+    from sonar_amd.tokenizer import NllbTokenizer
+
+    encoder = load_sonar_speech_encoder("sonar_speech_encoder_eng", device=DEV, dtype=torch.float32)
+    decoder = load_sonar_text_decoder("text_sonar_basic_decoder", device=DEV, dtype=torch.float32)
+    tokenizer = NllbTokenizer(resolve_tokenizer("text_sonar_basic_encoder"))
+    dp = SpeechToTextPipeline(SonarEncoderDecoderModel(encoder, decoder), tokenizer).build_pipeline(_tsv_params())
+    actual = next(iter(dp))
+    assert actual["audio"]["data"] == [
+        "Les rapports de la télévision montrent une fumée blanche provenant de l'usine.",
+        "Ces couples peuvent décider de faire un plan d'adoption pour leur bébé."]
+
+
 # ---------------------------------------------------------------- always on: the reference's real audio
 def test_fbank_of_the_reference_clips_vs_oracle():
     """GPU Kaldi filterbank on the two real FLEURS clips (not noise) against the CPU restatement."""

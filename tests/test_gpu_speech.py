@@ -153,3 +153,39 @@ def test_batched_fbank_equals_per_clip_and_pads_with_zeros():
     raw, _ = waveforms_to_fbank_batch([c.cuda() for c in clips], standardize=False)
     assert torch.equal(raw[3, :1], waveform_to_fbank(clips[3].cuda(), standardize=False))   # a single frame
     assert torch.equal(raw[0, :98], waveform_to_fbank(clips[0].cuda(), standardize=False))
+
+
+def test_tsv_driven_pipelines_on_the_reference_clips(tmp_path):
+    """The TSV-driven pipelines (sonar/inference_pipelines/speech.py:42-274; the reference's golden test drives the
+    encoder through them, tests/integration_tests/test_sonar_speech_encoder.py:27-78) on the reference's own TSV and
+    clips with a small random-init encoder: `build_pipeline(params)` must yield, per bucket, the embeddings
+    SpeechToEmbeddingModelPipeline.predict returns for the same files, in the reference's element structure."""
+    from pathlib import Path
+
+    from oracle import speech_encoder as OS
+    from sonar_amd.inference_pipelines import (SpeechInferenceParams, SpeechToEmbeddingModelPipeline,
+                                               SpeechToEmbeddingPipeline)
+    from sonar_amd.speech_encoder import SonarSpeechEncoderModel
+
+    data = Path(__file__).parent / "golden" / "reference_data"
+    ocfg, cfg = _cfgs(layers=1, pool=1)
+    params = OS.make_synthetic_params(ocfg, seed=5, std=0.06)
+    model = SonarSpeechEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    dev = torch.device("cuda:0")
+    ctx = SpeechInferenceParams(data_file=data / "audio_ref.tsv", audio_root_dir=data, audio_path_index=1,
+                                target_lang="fra_Latn", batch_size=4, pad_idx=0, device=dev,
+                                fbank_dtype=torch.float32, n_parallel=1)
+    dp = SpeechToEmbeddingPipeline(model).build_pipeline(ctx)
+    items = list(dp)
+    assert len(items) == 1 and [Path(p).name for p in items[0]["audio"]["path"]] == ["audio_1.wav", "audio_2.wav"]
+    got = items[0]["audio"]["data"].sentence_embeddings
+    want = SpeechToEmbeddingModelPipeline(model, device=dev).predict(
+        [str(data / "audio_1.wav"), str(data / "audio_2.wav")], batch_size=4)
+    assert got.shape == (2, 256) and _cos_err(got, want) <= 1e-6
+    # batch_size 1: two buckets, same rows; the pipeline object can be iterated again
+    ctx1 = SpeechInferenceParams(data_file=data / "audio_ref.tsv", audio_root_dir=data, audio_path_index=1,
+                                 batch_size=1, device=dev, n_parallel=2, n_prefetched_batches=1)
+    dp1 = SpeechToEmbeddingPipeline(model).build_pipeline(ctx1)
+    for _ in range(2):
+        rows = torch.cat([it["audio"]["data"].sentence_embeddings for it in dp1])
+        assert _cos_err(rows, want) <= 1e-5

@@ -251,3 +251,79 @@ def test_host_abi_functions():
     assert bounds[:nb.value + 1].tolist() == [0, 2, 5, 6] and nopen.value == 0
     assert lib.smi_host_dynamic_bucket(bl.ctypes.data, 6, 2**31, 4, 1, bounds.ctypes.data, C.byref(nb), C.byref(nopen)) == 0
     assert bounds[:nb.value + 1].tolist() == [0, 4] and nopen.value == 2
+
+
+def test_tsv_speech_pipeline_plumbing(tmp_path):
+    """The host plumbing of the TSV-driven speech pipelines (sonar/inference_pipelines/speech.py:42-274) without a
+    GPU: parameter object, TSV column selection (header skipped, right-trimmed), bucketing, the nested element
+    structure with its `selector` maps, re-iteration, argument errors.  The device stages are stubbed."""
+    import dataclasses
+
+    from sonar_amd.inference_pipelines import (AudioToFbankDataPipelineBuilder, SpeechInferenceParams,
+                                               SpeechToEmbeddingPipeline)
+    from sonar_amd.inference_pipelines.speech import DataPipelineBuilder, read_tsv_column
+    from sonar_amd.text_encoder import PaddingMask, SequenceBatch
+
+    # the reference's dataclass: same fields, order and defaults (speech.py:42-73)
+    fields = [(f.name, f.default) for f in dataclasses.fields(SpeechInferenceParams)]
+    assert [n for n, _ in fields] == ["data_file", "audio_root_dir", "audio_path_index", "batch_size", "fbank_dtype",
+                                      "target_lang", "pad_idx", "device", "n_parallel", "n_prefetched_batches"]
+    assert dict(fields[4:]) == {"fbank_dtype": torch.float32, "target_lang": None, "pad_idx": 0,
+                                "device": torch.device("cpu"), "n_parallel": 4, "n_prefetched_batches": 4}
+    tsv = tmp_path / "ref.tsv"
+    tsv.write_text("id\taudio\tnote\n1\ta.wav\tx  \n2\tb.wav\ty\n\n3\tc.wav\tz\n", encoding="utf-8")
+    assert read_tsv_column(tsv, 1) == ["a.wav", "b.wav", "c.wav"]
+    assert read_tsv_column(tsv, 2) == ["x", "y", "z"]
+    with pytest.raises(ValueError, match="no column 5"):
+        read_tsv_column(tsv, 5)
+
+    seen = []
+
+    class StubFbank(AudioToFbankDataPipelineBuilder):
+        def _batches(self, context, paths):
+            for i in range(0, len(paths), context.batch_size):
+                chunk = paths[i:i + context.batch_size]
+                seen.append([p.name for p in chunk])
+                lens = [4 + 2 * j for j in range(len(chunk))]
+                fb = torch.zeros(len(chunk), max(lens), 80)
+                for j, l in enumerate(lens):
+                    fb[j, :l] = float(i + j + 1)
+                yield SequenceBatch(fb, PaddingMask(torch.tensor(lens), max(lens))), lens
+
+    class StubModel:
+        device = torch.device("cpu")
+
+        def eval(self):
+            return self
+
+        def __call__(self, batch):
+            from sonar_amd.text_encoder import SonarEncoderOutput
+
+            lens = batch.padding_mask.seq_lens if batch.padding_mask is not None else None
+            pooled = batch.seqs.sum(dim=1)[:, :2] / (lens.unsqueeze(1) if lens is not None else batch.seqs.shape[1])
+            return SonarEncoderOutput(None, pooled, batch.padding_mask)
+
+    ctx = SpeechInferenceParams(data_file=tsv, audio_root_dir=tmp_path / "clips", audio_path_index=1, batch_size=2)
+    pipe = SpeechToEmbeddingPipeline(StubModel())
+    pipe.audio_to_fbank_dp_builder = StubFbank()
+    dp = pipe.build_pipeline(ctx)
+    for _ in range(2):                                  # a DataPipeline can be iterated again
+        seen.clear()
+        items = list(dp)
+        assert seen == [["a.wav", "b.wav"], ["c.wav"]]
+        assert [it["audio"]["path"] for it in items] == [[str(tmp_path / "clips" / "a.wav"), str(tmp_path / "clips" / "b.wav")],
+                                                        [str(tmp_path / "clips" / "c.wav")]]
+        emb = torch.cat([it["audio"]["data"].sentence_embeddings for it in items])
+        assert torch.allclose(emb[:, 0], torch.tensor([1.0, 2.0, 3.0]) * 80 / 80)
+    # the fbank stage alone yields the collated dict of the reference (seqs / seq_lens / is_ragged)
+    first = next(iter(StubFbank().build_pipeline(ctx)))
+    fbd = first["audio"]["data"]["fbank"]
+    assert fbd["seqs"].shape == (2, 6, 80) and fbd["seq_lens"].tolist() == [4, 6] and fbd["is_ragged"] is True
+    assert first["audio"]["data"]["sample_rate"] == [16000.0, 16000.0]
+    # selector maps compose on the builder, as the reference's pipelines do
+    b = DataPipelineBuilder(lambda: iter([{"a": {"b": 1}}, {"a": {"b": 2}}])).map(lambda v: v + 10, selector="a.b")
+    assert [x["a"]["b"] for x in b.and_return()] == [11, 12]
+    with pytest.raises(ValueError, match="batch_size"):
+        StubFbank().build_pipeline(SpeechInferenceParams(tsv, tmp_path, 1, 0))
+    with pytest.raises(RuntimeError, match="no CPU path"):   # the real device stage refuses a CPU device
+        next(iter(AudioToFbankDataPipelineBuilder().build_pipeline(ctx)))
