@@ -308,12 +308,13 @@ class SonarSpeechEncoderModel:
                  device: Union[str, torch.device] = "cuda:0", dtype: torch.dtype = torch.float16,
                  fp16_residual: Optional[bool] = None):
         """dtype: dtype of the returned embeddings and (as in the reference) of the residual stream, unless
-        `fp16_residual` says otherwise."""
+        `fp16_residual` says otherwise.  A bf16 model keeps the fp32 residual stream: its activations have fp32 range,
+        an fp16 stream does not (round 4, as the text encoder)."""
         self.config = cfg
         self.model_dim = cfg.model_dim
         self.dtype = dtype
         self.engine = SpeechEncoderEngine(cfg, state_dict, device,
-                                          dtype in (torch.float16, torch.bfloat16) if fp16_residual is None else fp16_residual)
+                                          dtype == torch.float16 if fp16_residual is None else fp16_residual)
         self.device = self.engine.device
 
     def eval(self):

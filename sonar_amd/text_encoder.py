@@ -419,10 +419,14 @@ class SonarTextTransformerEncoderModel:
         if dtype not in (torch.float16, torch.bfloat16, torch.float32):
             raise ValueError(f"unsupported model dtype {dtype} (float16, bfloat16 or float32)")
         if fp16_residual is None:
-            # a bf16 model runs the fast path too: its weights are exactly representable as fp16 operands as long as
-            # they lie in fp16's exponent range (|w| in [6.1e-5, 65504]; smaller ones lose mantissa bits as fp16
-            # subnormals), its embeddings are rounded to bf16 on the way out (include/sonar_mi355.h, SMI_BF16)
-            fp16_residual = dtype in (torch.float16, torch.bfloat16)
+            # fp16 model -> fp16 residual stream, as the reference's `.half()` model.  A bf16 model's activations have
+            # fp32 RANGE (sonar/inference_pipelines/text.py:36-54 accepts any dtype), which an fp16 stream does not: it
+            # gets the fp32 residual stream (round 4; the GEMM operands -- LayerNorm outputs, q/k/v, the FFN hidden
+            # activation -- are O(1)-scaled quantities and stay fp16 operands of the fp16 MFMA, fp32 accumulation).
+            # bf16 WEIGHTS are exact fp16 operands as long as they lie in fp16's exponent range (|w| in
+            # [6.1e-5, 65504]; smaller ones lose mantissa bits as fp16 subnormals); embeddings are rounded to bf16
+            # once, on the way out (include/sonar_mi355.h, SMI_BF16).
+            fp16_residual = dtype == torch.float16
         self.config = cfg
         self.dtype = dtype
         self.model_dim = cfg.model_dim
