@@ -315,16 +315,21 @@ int grow_kv(smi_text_decoder* D, DecWork& S, int rows_pad, int positions, hipStr
 constexpr int kKvInitialPositions = 160;
 
 // Number of independent chains for a beam-search call (smi_text_decoder_set_chains / SMI_DEC_CHAINS override).
-// Measured on the `basic` decoder, beam 5 (profiles/r04_experiments.txt, experiment 1): 256 sentences = 1280 rows are
-// 160 lone FFN tiles -- one round on 256 CUs -- and two 640-row chains are SLOWER (3.88 -> 4.16-4.25 ms per step: every
-// co-running launch takes 20-30 % longer, the row-bound kernels' gain does not pay for it); 512 sentences = 2560 rows
-// are 320 tiles -- two rounds -- and two 1280-row chains are 19 % FASTER (7.71 -> 6.23 ms per step).  So a call is
-// split when its FFN tiles no longer fit the chip in one round: chains = ceil(rows_pad / 2048), at most kMaxChains.
+// Measured on the `basic` decoder, beam 5, ms per step (profiles/r04_experiments.txt, experiment 1):
+//   sentences (rows)   1 chain   2 chains   3 chains   4 chains
+//   256  (1280)          3.88      4.16-4.25    4.97
+//   512  (2560)          7.71      6.23
+//   768  (3840)         10.03      9.68       9.18
+//   1024 (5120)         13.57     13.22      12.61      13.22
+// 1280 rows are 160 lone FFN tiles -- one round on 256 CUs -- and splitting them only makes every co-running launch 20-30 %
+// slower (kernel trace: 65 % of the time two kernels in flight, each longer than alone); from 2560 rows on the FFN tiles need
+// a second round and chains of ~1280 rows win, up to three of them (a fourth costs more in contention than it hides).
 int decode_chains(const smi_text_decoder* D, int n, int beam) {
   const int env = DecTuning::env_int("SMI_DEC_CHAINS", 0);
   if (D->flex) return 1;
   const int64_t rows_pad = round_up((int64_t)n * beam, 256);
-  int g = D->chains > 0 ? D->chains : (env > 0 ? env : (int)((rows_pad + 2047) / 2048));
+  const int automatic = rows_pad <= 2048 ? 1 : (int)std::min<int64_t>(3, (rows_pad + 1279) / 1280);
+  int g = D->chains > 0 ? D->chains : (env > 0 ? env : automatic);
   g = std::min(g, kMaxChains);
   // every chain keeps at least two 256-row tiles of hypotheses: below that a chain's launches are all fixed cost
   while (g > 1 && (int64_t)((n + g - 1) / g) * beam < 384) --g;

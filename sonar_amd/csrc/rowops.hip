@@ -69,9 +69,16 @@ __global__ __launch_bounds__(256) void embed_pack_kernel(const int64_t* __restri
     f32x4 o0, o1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      // reference: (embed(seqs) * scale) in model dtype, then fp32 add of PE
-      o0[i] = (float)(f16)((float)ev[i] * scale) + p0[i];
-      o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
+      // reference: (embed(seqs) * scale) in model dtype, then fp32 add of PE.  fp16 stream = fp16 model: the product is
+      // rounded to fp16; fp32 stream (fp32 and bf16 models): no fp16 rounding -- a bf16 model's scaled embedding may lie
+      // beyond fp16's range (round 4)
+      if constexpr (sizeof(XT) == 4) {
+        o0[i] = (float)ev[i] * scale + p0[i];
+        o1[i] = (float)ev[i + 4] * scale + p1[i];
+      } else {
+        o0[i] = (float)(f16)((float)ev[i] * scale) + p0[i];
+        o1[i] = (float)(f16)((float)ev[i + 4] * scale) + p1[i];
+      }
     }
     if constexpr (sizeof(XT) == 4) {
       *(f32x4*)(oc) = o0;

@@ -536,7 +536,14 @@ __device__ __forceinline__ half4 ra_tr_read(unsigned lds_addr) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __restrict__ qkv,
+// 3 waves per SIMD (<= 168 registers; 3 workgroups x 48 KiB of LDS per CU): the kernel is a chain of LDS round trips, DMA
+// waits and one barrier per 32-key block, so a third resident workgroup is what hides them (round 4; it took 204 registers =
+// 2 waves before the pad addresses and the first block's second pad half stopped occupying 31 registers across the loop).
+// -DSMI_RELPOS_WAVES=2 restores the two-wave allocation for A/B builds.
+#ifndef SMI_RELPOS_WAVES
+#define SMI_RELPOS_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_WAVES, SMI_RELPOS_WAVES))) void relpos_attention_kernel(const f16* __restrict__ qkv,
                                                                const int32_t* __restrict__ cu,
                                                                const f16* __restrict__ rp, int rp_zero,
                                                                int rp_rows,
@@ -607,27 +614,34 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
       vaddr[db] = (unsigned)(size_t)(lds + BLK + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
     }
   }
-  // pad read offsets (bytes from Gs) for an EVEN key block: rho = l31 - jj + 31, half 0 = this block's
-  // rows, half 1 (+4 KiB) = the previous block's; an odd block swaps the halves: offset ^ 4096
-  int gread[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int rho = l31 - ((r & 3) + 8 * (r >> 2) + 4 * hi) + 31;  // 0..62
-    gread[r] = ((rho < 32 ? 0 : 32 * 32) + (rho & 31) * 32 + l31) * 4;
-  }
+  // pad read addresses: query l31 needs G[rho][l31] for rho = l31 - jj + 31, jj = the key of accumulator register r.  Row rho
+  // of an EVEN key block sits at rho * 128 B (rows 0..31 = this block's half, 32..63 = the previous block's); an odd block
+  // swaps the halves, i.e. adds 4 KiB modulo 8 KiB.  With jj(r) = c_r + 4 hi, c_r = (r & 3) + 8 (r >> 2), every read is
+  // (gbase + parity * 4096 - c_r * 128) mod 8192: ONE base register and compile-time offsets (round 4: the 16 per-register
+  // offsets of round 1-3 cost 15 VGPRs of a kernel that sits one register class above 3 waves per SIMD).
+  const int gbase = (l31 + 31 - 4 * hi) * 128 + l31 * 4;
   stage(0, 0);
   half8 rf[4];  // the position rows of the NEXT block travel through the softmax / PV half of this one
-  // ... and the first key block's SECOND half (rho 32..63), requested here with everything else: loaded inside the
-  // `kb == 0` branch, hipcc issued the four 16-B loads one at a time, each behind its own `s_waitcnt vmcnt(0)`
-  // (one register quad, LDS-DMA in flight): four exposed memory latencies per workgroup, ~15 % of its life
-  half8 rf_hi[4];
   {
+    // The first key block needs BOTH pad halves (rho 32..63 have no previous block to come from): that half is computed
+    // here, in a prologue, so that its four position-row registers are not live inside the loop (they were: `if (kb == 0)`
+    // in the loop body kept 16 more VGPRs alive across every iteration's peak).  All eight 16-B loads are issued
+    // together, ahead of the K / V wait.
+    half8 rf_hi[4];
     const f16* rrow = rp_row(0, 0);
     const f16* rrow1 = rp_row(0, 1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rf[ks] = *(const half8*)(rrow + (ks * 2 + hi) * 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rf_hi[ks] = *(const half8*)(rrow1 + (ks * 2 + hi) * 8);
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf_hi[ks], qv[ks], g, 0, 0, 0);
+    float* Gold0 = Gs + 32 * 32;  // block 0 reads rho 32..63 from half 1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Gold0[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
   }
 
   for (int j0 = 0, kb = 0; j0 < len; j0 += RA_KB, ++kb) {
@@ -647,8 +661,7 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
     // ---- position term: G[rho][i] = rp[rel_lo + rho] . (q_i + v), rho = 0..63 ----
     // rel_lo drops by 32 per key block, so rows 32..63 of this block are rows 0..31 of the previous
     // one: the pad is two 32-row halves used alternately, and only the first key block computes both.
-    float* Gnew = Gs + (kb & 1) * 32 * 32;        // rho 0..31 of this block
-    float* Gold = Gs + ((kb + 1) & 1) * 32 * 32;  // rho 32..63 = the previous block's rho 0..31
+    float* Gnew = Gs + (kb & 1) * 32 * 32;        // rho 0..31 of this block (rho 32..63 = the previous block's rho 0..31)
     {
       f32x16 g;
 #pragma unroll
@@ -657,15 +670,6 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
       for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf[ks], qv[ks], g, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) Gnew[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
-    }
-    if (kb == 0) {
-      f32x16 g;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) g[r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf_hi[ks], qv[ks], g, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Gold[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = g[r];
     }
     // next block: K / V by DMA into the other buffer, its position rows into rf
     if (j0 + RA_KB < len) {
@@ -678,8 +682,11 @@ __global__ __launch_bounds__(256) void relpos_attention_kernel(const f16* __rest
     // the 16 pad reads are issued back to back and waited for once (left to itself hipcc sinks each
     // read into the branch of its `< len` mask: 16 exec-masked blocks, each with its own LDS wait)
     float bd[16];
+    int gb = gbase + ((kb & 1) << 12);
+    asm volatile("" : "+v"(gb));  // one live base: keep hipcc from materialising the 16 (or 32) addresses in registers
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bd[r] = *(const float*)((const char*)Gs + (gread[r] ^ ((kb & 1) << 12)));
+    for (int r = 0; r < 16; ++r)
+      bd[r] = *(const float*)((const char*)Gs + ((gb - ((r & 3) + 8 * (r >> 2)) * 128) & 8191));
 #pragma unroll
     for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bd[r]));
     // x = content + position (unscaled); only the last key block of a clip has keys to mask

@@ -146,7 +146,7 @@ __device__ unsigned long long xs_trace_buf[256 * 2 * 4];
     float rowthr[8];                                                                                                         \
     _Pragma("unroll")                                                                                                        \
     for (int mi = 0; mi < 8; ++mi) {                                                                                         \
-      float my = best[mi].s[K - 1];                                                                                          \
+      float my = best[mi].s[KR - 1];                                                                                          \
       my = fmaxf(my, __shfl_xor(my, 16, 64));                                                                                \
       my = fmaxf(my, __shfl_xor(my, 32, 64));                                                                                \
       if (kg == 0) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = my;                                                            \
@@ -175,10 +175,93 @@ __device__ unsigned long long xs_trace_buf[256 * 2 * 4];
     }                                                                                                                        \
   } while (0)
 
+// ---- running top-k lists in LDS (round 4) ----------------------------------------------------------------------------
+// One list per X ROW of the tile, shared by the 16 lanes (4 lane groups x 4 column waves) that see scores of that row:
+// K 64-bit keys, descending, key = order-preserving(score) << 32 | (0xffffffff - y index) -- the total order of `better`
+// (score desc, index asc) as ONE unsigned compare.  A candidate is inserted with a cascade of LDS `max` atomics
+// (slot j keeps the larger of {slot, carried key}, the smaller travels on): slot 0 sees every inserted key, so it ends
+// as their maximum; slot 1 sees every key but that one; ... -- the final list is the top K whatever the interleaving
+// of the 16 lanes, and identical from run to run.  What this buys over per-lane lists in registers (8 lists x K x 2
+// words per lane: 16 VGPRs at top-1, 64 at top-4, where hipcc spilled and the deferred fold could not be used):
+//  * no list registers at all: every K runs the schedule of top-1 (group 0 defers its fold into group 1's interval);
+//  * the threshold of a row is the row's TRUE K-th best (one ds_read_b32 of the last key's score word), not the
+//    maximum of four waves' private K-th bests: no shuffles, no publish step, fewer false passes;
+//  * the walk ends with the lists final: no cross-lane / cross-wave merge.
+// Insertions are rare after the first tiles (~K ln(n / K) per row over a chunk of n rows); they take the slow path.
+constexpr unsigned long long XS_EMPTY = (0x007fffffull << 32) | 0x80000000ull;  // (-inf, index 0x7fffffff)
+__device__ __forceinline__ uint32_t xs_ord(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float xs_unord(uint32_t o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+template <int K>
+__device__ __forceinline__ void xs_insert(unsigned long long* list, float v, int n) {
+  unsigned long long key = ((unsigned long long)xs_ord(v) << 32) | (uint32_t)(0xffffffffu - (uint32_t)n);
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const unsigned long long old = __hip_atomic_fetch_max(list + j, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    key = old < key ? old : key;
+    if (key == XS_EMPTY) break;
+  }
+}
+// the 8 row thresholds of a lane (rows wr * 128 + mi * 16 + l15): score word of the last key of each list.  Inline asm, issue
+// and wait in ONE statement: as C++ loads every one of them would get `s_waitcnt vmcnt(0)` from hipcc's LDS-DMA alias tracking
+// (the operand slices of the next tile are in flight) -- gemm.hip, round-3 findings.  A stale value is a valid lower bound.
+template <int K>
+__device__ __forceinline__ void xs_thresholds(unsigned lds_addr, float (&t)[8]) {
+  uint32_t o[8];
+  asm volatile(
+      "ds_read_b32 %0, %8 offset:%9\n\tds_read_b32 %1, %8 offset:%10\n\tds_read_b32 %2, %8 offset:%11\n\t"
+      "ds_read_b32 %3, %8 offset:%12\n\tds_read_b32 %4, %8 offset:%13\n\tds_read_b32 %5, %8 offset:%14\n\t"
+      "ds_read_b32 %6, %8 offset:%15\n\tds_read_b32 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(lds_addr), "n"(0 * 128 * K), "n"(1 * 128 * K), "n"(2 * 128 * K), "n"(3 * 128 * K), "n"(4 * 128 * K),
+        "n"(5 * 128 * K), "n"(6 * 128 * K), "n"(7 * 128 * K)
+      : "memory");
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) t[mi] = xs_unord(o[mi]);
+}
+
+#define XS_FOLD_LL(n0f)                                                                                                      \
+  do {                                                                                                                       \
+    float rowthr[8], vmx[8];                                                                                                 \
+    xs_thresholds<K>(thr_addr, rowthr);                                                                                      \
+    bool hit = false;                                                                                                        \
+    _Pragma("unroll")                                                                                                        \
+    for (int mi = 0; mi < 8; ++mi) {                                                                                         \
+      float vmax = -INFINITY;                                                                                                \
+      _Pragma("unroll")                                                                                                      \
+      for (int ni = 0; ni < 4; ++ni)                                                                                         \
+        _Pragma("unroll")                                                                                                    \
+        for (int r = 0; r < 4; ++r) vmax = fmaxf(vmax, acc.v[ni][mi][r]);                                                    \
+      vmx[mi] = vmax;                                                                                                        \
+      hit |= vmax >= rowthr[mi];                                                                                             \
+    }                                                                                                                        \
+    if (__any(hit)) {                                                                                                        \
+      _Pragma("unroll")                                                                                                      \
+      for (int mi = 0; mi < 8; ++mi) {                                                                                       \
+        if (vmx[mi] >= rowthr[mi]) {                                                                                         \
+          unsigned long long* lst = lists + (wr * 128 + mi * 16 + l15) * K;                                                  \
+          _Pragma("unroll")                                                                                                  \
+          for (int ni = 0; ni < 4; ++ni)                                                                                     \
+            _Pragma("unroll")                                                                                                \
+            for (int r = 0; r < 4; ++r) {                                                                                    \
+              const int n = n0f + wc * 64 + ni * 16 + 4 * kg + r;                                                            \
+              const float v = acc.v[ni][mi][r];                                                                              \
+              if (v >= rowthr[mi] && n < ny) xs_insert<K>(lst, v, n);                                                        \
+            }                                                                                                                \
+        }                                                                                                                    \
+      }                                                                                                                      \
+    }                                                                                                                        \
+  } while (0)
+
 // TM: Xn / Yn are TILE-MAJOR copies (common.hpp; packed into the workspace by xsim_run): a K slice of an operand is one
 // contiguous 16 KiB block and the Y stream of a chunk one linear walk, instead of 256 pieces of 64 B a row apart -- the
 // layout that bought the GEMMs +7 % end to end and +26 % on the bare operand stream.
-template <int K, bool TM>
+// LL: the running top-k lists live in LDS (above), one per row; !LL: per-lane lists in registers (rounds 1-3, K <= 4)
+template <int K, bool TM, bool LL>
 __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __restrict__ Xn,
                                                                   const f16* __restrict__ Yn, int d,
                                                                   int ntx, int nty, int nchunks,
@@ -200,18 +283,30 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
   const int nt = d / G2_BK;
   const int S = max(ntiles, 0) * nt;
 
-  TopK<K> best[8];  // one running list per accumulator row block
+  constexpr int KR = LL ? 1 : K;  // register lists exist only without LL
+  TopK<KR> best[8];               // one running list per accumulator row block
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) best[mi].init();
+  unsigned long long* lists = (unsigned long long*)(smem + G2_LDS_BYTES);  // LL: [256 rows][K] keys
+  const unsigned thr_addr = (unsigned)(size_t)(smem + G2_LDS_BYTES) + ((wr * 128 + l15) * K + (K - 1)) * 8 + 4;
+  if constexpr (LL) {
+    if (tid < 256) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) lists[tid * K + j] = XS_EMPTY;
+    }
+    __syncthreads();  // (before any LDS-DMA is in flight)
+  }
   // Row thresholds shared by the 4 column waves (above the ring): thr[row][wc] = the K-th best score wave wc holds for
   // that row, a lower bound of the row's K-th best.  Published and read WITHOUT a barrier: the values only grow, so a
   // stale one is still a valid bound.  A lane's own K-th best is a much weaker test -- with it some lane of nearly
   // every 16-row block passes and the whole wave walks the insertion path every tile (top-4: 610 ms against 480 for
   // top-1 at 262 144 x 1 M, r02 experiment 24).
   float* thr = (float*)(smem + G2_LDS_BYTES);
-  if (kg == 0) {
+  if constexpr (!LL) {
+    if (kg == 0) {
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = -INFINITY;
+      for (int mi = 0; mi < 8; ++mi) thr[(wr * 128 + mi * 16 + l15) * 4 + wc] = -INFINITY;
+    }
   }
 
   if (S > 0) {
@@ -283,7 +378,8 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
 #ifdef SMI_XSIM_TRACE
       const unsigned long long tr_f0 = wall_clock64();
 #endif
-      XS_FOLD(n0f);
+      if constexpr (LL) XS_FOLD_LL(n0f);
+      else XS_FOLD(n0f);
 #ifdef SMI_XSIM_TRACE
       const unsigned long long dt = wall_clock64() - tr_f0;
       tr_fold += dt;
@@ -301,8 +397,8 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     // for that (it spills) and reads them AFTER the fold, in the same interval; top-4 (64 list registers) spills either way and
     // ran 60 % slower deferred: it keeps the two-interval schedule.  Same box, 262 144 x 1 M: top-1 443.5 / 445.6 -> 434.9 /
     // 434.2 ms, top-2 493.2 / 492.6 -> 474.0 / 473.1 ms (r03 experiment 14).
-    constexpr bool DEFER = K <= 2;
-    constexpr bool LATE_READ = K == 2;
+    constexpr bool DEFER = LL || K <= 2;    // LL: no list registers, every K runs top-1's schedule
+    constexpr bool LATE_READ = !LL && K == 2;
     bool pending = false;
     int n0_pending = 0;
     for (int s = 0; s < S; ++s) {
@@ -384,7 +480,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
 #ifdef SMI_XSIM_TRACE
           fold(n0);
 #else
-          XS_FOLD(n0);
+          XS_FOLD(n0);  // (!LL, K = 4: the macro, not the lambda -- 76 bytes of spills otherwise)
 #endif
         }
         n0 += G2_BN;
@@ -403,21 +499,34 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     if (wr == 0) SMI_BARRIER();
   }
 
+  if constexpr (LL) {  // the lists are final: one thread per row writes its chunk-partial list
+    __syncthreads();
+    if (tid < 256) {
+      const size_t o = ((size_t)chunk * nx_pad + m0 + tid) * K;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const unsigned long long key = lists[tid * K + j];
+        ps[o + j] = xs_unord((uint32_t)(key >> 32));
+        pi[o + j] = (int)(0xffffffffu - (uint32_t)key);
+      }
+    }
+    return;
+  }
   // a row's candidates sit in the 4 lane groups (kg) of 4 column waves: join the lane groups with
   // xor-shuffles (both partners end with the merged list), then the 4 waves through LDS
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
     for (int step = 16; step <= 32; step <<= 1) {
-      float os[K];
-      int oi[K];
+      float os[KR];
+      int oi[KR];
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
+      for (int j = 0; j < KR; ++j) {
         os[j] = __shfl_xor(best[mi].s[j], step, 64);
         oi[j] = __shfl_xor(best[mi].i[j], step, 64);
       }
 #pragma unroll
-      for (int j = 0; j < K; ++j) best[mi].push(os[j], oi[j]);
+      for (int j = 0; j < KR; ++j) best[mi].push(os[j], oi[j]);
     }
   }
   __syncthreads();
@@ -428,7 +537,7 @@ __global__ __launch_bounds__(G2_THREADS) void xsim_tile256_kernel(const f16* __r
     for (int mi = 0; mi < 8; ++mi) {
       const int row = wr * 128 + mi * 16 + l15;
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
+      for (int j = 0; j < KR; ++j) {
         ls[(row * 4 + wc) * K + j] = best[mi].s[j];
         li[(row * 4 + wc) * K + j] = best[mi].i[j];
       }
@@ -656,14 +765,28 @@ static bool xsim_tm() {
   }();
   return v;
 }
+// SMI_XSIM_LL=0: per-lane top-k lists in registers (rounds 1-3; k = 8 then runs on the 128x128 engine) instead of the
+// per-row lists in LDS -- A/B switch, read once (the workspace formula depends on it)
+static bool xsim_ll() {
+  static const bool v = [] {
+    const char* e = getenv("SMI_XSIM_LL");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
+// top-1 keeps its list in registers (16 VGPRs, no pressure there: 436.7 vs 439.6 ms with LDS lists at 262 144 x 1 M); k >= 2
+// run on LDS lists: 475.1 -> 450.0 ms (k = 2), 545.7 -> 454.3 (k = 4), 657.9 -> 484.2 (k = 8, which the register version could
+// only run on the 128x128 engine) -- same box, identical indices and scores (profiles/r04_experiments.txt, experiment 2)
+static bool xsim_use_ll(int K) { return K >= 2 && xsim_ll(); }
+static bool xsim_on_256(int K) { return K <= 4 || xsim_ll(); }
 // per-chunk partial lists: [chunks][nx_pad][K] scores + indices
 static size_t xsim_lists_bytes(int64_t nx_pad, int64_t ny_pad, int K) {
   return (size_t)xsim_chunks(ny_pad / GT_BN) * nx_pad * K * 8;
 }
-// ... followed (256x256 engine, k <= 4) by the tile-major copies of Xn and Yn
+// ... followed (256x256 engine) by the tile-major copies of Xn and Yn
 size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k, int d) {
   const int K = round_k(k);
-  const size_t tm = K <= 4 ? (size_t)(nx_pad + ny_pad) * d * sizeof(f16) : 0;
+  const size_t tm = xsim_on_256(K) ? (size_t)(nx_pad + ny_pad) * d * sizeof(f16) : 0;
   return xsim_lists_bytes(nx_pad, ny_pad, K) + tm;
 }
 
@@ -681,23 +804,32 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
   float* ps = (float*)ws;
   hipError_t e;
   int nchunks;
-  if constexpr (K <= 4) {
+  if (xsim_on_256(K)) {
     // 256x256 tiles, continuous slice stream
+    const bool ll = xsim_use_ll(K);
+    constexpr int lds_ll = G2_LDS_BYTES + 256 * K * 8, lds_reg = G2_LDS_BYTES + 4096;
     static DeviceOnce attr256_done;
     if (!attr256_done.done()) {
-      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + 4096);
+      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ll);
       if (e != hipSuccess) return e;
-      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES + 4096);
+      e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ll);
       if (e != hipSuccess) return e;
+      if constexpr (K <= 4) {
+        e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_reg);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)xsim_tile256_kernel<K, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_reg);
+        if (e != hipSuccess) return e;
+      }
       attr256_done.set();
     }
     const int ntx = (int)(nx_pad / G2_BM), nty = (int)(ny_pad / G2_BN);
     nchunks = xsim_chunks(nty);
     const int tpc = (nty + nchunks - 1) / nchunks;
     int* pi = (int*)((char*)ws + (size_t)nchunks * nx_pad * K * 4);
-    if (xsim_tm()) {
+    const f16* xa = Xn;
+    const f16* ya = Yn;
+    const bool tm = xsim_tm();
+    if (tm) {
       // tile-major copies of both operands behind the partial lists (one pass over each: ~1.5 ms of the 1.8 s at 1 M x 1 M)
       f16* xtm = (f16*)((char*)ws + xsim_lists_bytes(nx_pad, ny_pad, K));
       f16* ytm = xtm + (size_t)nx_pad * d;
@@ -710,12 +842,22 @@ static hipError_t xsim_run(const f16* Xn, int64_t nx, int64_t nx_pad, const f16*
           e = launch_pack_tile_major(src[o] + r0 * d, dst[o] + r0 * d, (int)nr, d, 0, stream);
           if (e != hipSuccess) return e;
         }
-      hipLaunchKernelGGL((xsim_tile256_kernel<K, true>), dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
-                         stream, xtm, ytm, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
-    } else {
-      hipLaunchKernelGGL((xsim_tile256_kernel<K, false>), dim3(ntx * nchunks), dim3(G2_THREADS), G2_LDS_BYTES + 4096,
-                         stream, Xn, Yn, d, ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi);
+      xa = xtm;
+      ya = ytm;
     }
+#define SMI_XSIM_LAUNCH(TMV, LLV, LDS)                                                                              \
+  hipLaunchKernelGGL((xsim_tile256_kernel<K, TMV, LLV>), dim3(ntx * nchunks), dim3(G2_THREADS), LDS, stream, xa, ya, d, \
+                     ntx, nty, nchunks, tpc, (int)ny, (int)nx_pad, ps, pi)
+    if (ll) {
+      if (tm) SMI_XSIM_LAUNCH(true, true, lds_ll);
+      else SMI_XSIM_LAUNCH(false, true, lds_ll);
+    } else {
+      if constexpr (K <= 4) {
+        if (tm) SMI_XSIM_LAUNCH(true, false, lds_reg);
+        else SMI_XSIM_LAUNCH(false, false, lds_reg);
+      }
+    }
+#undef SMI_XSIM_LAUNCH
   } else {
     const int ntx = (int)(nx_pad / GT_BM), nty = (int)(ny_pad / GT_BN);
     nchunks = xsim_chunks(nty);

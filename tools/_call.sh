@@ -1,13 +1,15 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 OUT=$PWD/gpurun_out
-cd /tmp
-for C in 1 2; do
-  rocprofv3 --kernel-trace -d $OUT/r04b_trace_c$C -o t --output-format csv -- python $OLDPWD/tools/bench_decoder_chains.py 256 64 2 -- "chains=$C" > $OUT/r04b_trace_c$C.log 2>&1
-  python $OLDPWD/tools/trace_overlap.py $OUT/r04b_trace_c$C 0.6 0.98 > $OUT/r04b_overlap_c$C.txt 2>&1
+python -m pytest tests/test_gpu_xsim_margin.py tests/test_gpu_decoder.py tests/test_gpu_encoder.py tests/test_gpu_speech.py tests/test_gpu_rccl.py -m gpu -q -x 2>&1 | tail -8 > $OUT/r04c_pytest.log
+python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -k "xsim" 2>&1 | tail -4 >> $OUT/r04c_pytest.log
+python -m pytest tests -m gpu -q -x -k "xsim or topk" 2>&1 | tail -4 >> $OUT/r04c_pytest.log
+: > $OUT/r04c_xsim_ll.log
+for K in 1 2 4 8; do
+  for LL in 0 1; do
+    SMI_XSIM_LL=$LL python tools/probe_xsim.py 262144 1048576 $K >> $OUT/r04c_xsim_ll.log 2>&1
+  done
 done
-cd $OLDPWD
-python tools/bench_decoder_chains.py 512 64 2 -- "chains=1" "chains=2" "chains=2 SMI_DEC_KS_OUT=2 SMI_DEC_LOGITS_GRID=128" > $OUT/r04b_chains_n512.log 2>&1
-python -m pytest tests/test_gpu_decoder.py -m gpu -q -x -k chains 2>&1 | tail -5 > $OUT/r04b_pytest_chains.log
-find $OUT -name "*kernel_trace.csv" -size +30M -delete
-cat $OUT/r04b_trace_c1.log | tail -3; cat $OUT/r04b_overlap_c1.txt; cat $OUT/r04b_trace_c2.log | tail -3; cat $OUT/r04b_overlap_c2.txt; cat $OUT/r04b_chains_n512.log; cat $OUT/r04b_pytest_chains.log
+python tools/bench_decoder_chains.py 1024 64 2 -- "chains=1" "chains=2" "chains=3" "chains=4" "chains=0" > $OUT/r04c_chains_n1024.log 2>&1
+python tools/bench_decoder_chains.py 768 64 2 -- "chains=1" "chains=2" "chains=3" "chains=0" > $OUT/r04c_chains_n768.log 2>&1
+cat $OUT/r04c_pytest.log; grep xsim $OUT/r04c_xsim_ll.log; cat $OUT/r04c_chains_n1024.log $OUT/r04c_chains_n768.log | grep chains

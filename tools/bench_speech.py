@@ -33,7 +33,7 @@ def main():
     de = (time.time() - t1) / reps
     frames = n * 499
     print(f"speech n={n} x 10 s: total {dt*1e3:.1f} ms ({n/dt:.1f} clips/s, {n*10/dt:.0f}x real time); encoder only {de*1e3:.1f} ms; "
-          f"{frames} stacked frames; emb finite={bool(torch.isfinite(emb).all())}")
+          f"{frames} stacked frames; emb finite={bool(torch.isfinite(emb).all())} checksum {float(emb.double().sum()):.6f}")
 
 if __name__ == "__main__":
     main()

@@ -20,5 +20,5 @@ for _ in range(3):
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 t = min(ts)
-print(f"xsim nx={nx} ny={ny} k={k} GM={os.environ.get('SMI_XSIM_GM','8')} CHUNKS={os.environ.get('SMI_XSIM_CHUNKS','8')}: "
-      f"{t*1e3:.1f} ms  {nx*ny/t:.3e} pairs/s  {nx*ny*2048/t/1e12:.0f} TFLOP/s  checksum {int(i.sum())}", flush=True)
+print(f"xsim nx={nx} ny={ny} k={k} LL={os.environ.get('SMI_XSIM_LL','1')} TM={os.environ.get('SMI_XSIM_TM','1')}: "
+      f"{t*1e3:.1f} ms  {nx*ny/t:.3e} pairs/s  {nx*ny*2048/t/1e12:.0f} TFLOP/s  checksum {int(i.sum())} score-sum {float(s.double().sum()):.6f}", flush=True)
