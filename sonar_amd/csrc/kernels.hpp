@@ -227,10 +227,10 @@ hipError_t launch_fbank_batch(const float* waves, const int64_t* off_dev, int n,
                               float* out, hipStream_t stream);
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
-                                   int heads, hipStream_t stream);
+                                   int heads, hipStream_t stream, int ctx_tm = 0);
 hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
                                  const float* shift, f16* y, int n, int max_len, int d, int ktaps,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int y_tm = 0);
 hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu, f16* ctx, int n, int d, int heads,
                                  hipStream_t stream);
 hipError_t launch_broadcast_row(const float* row, float* x, int rows, int d, hipStream_t stream);

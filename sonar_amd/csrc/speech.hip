@@ -549,7 +549,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
                                                                int rp_rows,
                                                                const float* __restrict__ u_bias,
                                                                const float* __restrict__ v_bias,
-                                                               f16* __restrict__ ctx, int d, float sl2e) {
+                                                               f16* __restrict__ ctx, int d, float sl2e,
+                                                               int ctx_tm) {
   constexpr int BLK = RA_KB * 128;  // 4 KiB
   __shared__ __attribute__((aligned(16))) char lds[4 * BLK + 4 * 64 * 32 * 4];
   const int n = blockIdx.x, h = blockIdx.y;
@@ -759,6 +760,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   const float ltot = lsum + __shfl_xor(lsum, 32, 64);
   const float inv = 1.0f / ltot;
   if (qi < len) {
+    // ctx_tm: the context is the X operand of the output projection and is written in the tile-major layout of the
+    // 256x256 engine (common.hpp: any packed row addresses its own 64-B slice of a 16 KiB block, no clip alignment needed)
     f16* op = ctx + (size_t)(start + qi) * d + h * 64;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -767,19 +770,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
         half4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
-        *(half4*)(op + db * 32 + 8 * q + 4 * hi) = v;
+        const int col = db * 32 + 8 * q + 4 * hi;
+        if (ctx_tm) *(half4*)(ctx + tm_offset(start + qi, h * 64 + col, d)) = v;
+        else *(half4*)(op + col) = v;
       }
   }
 }
 
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
-                                   int heads, hipStream_t stream) {
+                                   int heads, hipStream_t stream, int ctx_tm) {
   if (heads <= 0 || d != heads * 64 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;
   dim3 grid(n, heads, (max_len + RA_QB - 1) / RA_QB);
   hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias,
-                     v_bias, ctx, d, sl2e);
+                     v_bias, ctx, d, sl2e, ctx_tm);
   return hipGetLastError();
 }
 
@@ -796,7 +801,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
-                                                             f16* __restrict__ y, int d) {
+                                                             f16* __restrict__ y, int d, int y_tm) {
   constexpr int TT = 32, HALF = (KT - 1) / 2, NIN = TT + KT - 1;
   __shared__ __attribute__((aligned(16))) f16 xin[NIN][256];
   __shared__ __attribute__((aligned(16))) f16 yout[TT][256];
@@ -830,21 +835,24 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
   __syncthreads();
   for (int i = tid; i < TT * 32; i += 256) {
     const int tt = i >> 5, ch = (i & 31) * 8;
-    if (t0 + tt < len) *(half8*)(y + (size_t)(start + t0 + tt) * d + c0 + ch) = *(const half8*)&yout[tt][ch];
+    if (t0 + tt < len) {  // y_tm: tile-major X operand of pointwise_conv2 (a 16-B chunk of a row is a 16-B chunk there too)
+      f16* dst = y_tm ? y + tm_offset(start + t0 + tt, c0 + ch, d) : y + (size_t)(start + t0 + tt) * d + c0 + ch;
+      *(half8*)dst = *(const half8*)&yout[tt][ch];
+    }
   }
 }
 
 hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
                                  const float* shift, f16* y, int n, int max_len, int d, int ktaps,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int y_tm) {
   if (d % 256 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(n, (max_len + 31) / 32, d / 256);
   switch (ktaps) {
     case 31:
-      hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d);
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm);
       break;
     case 7:
-      hipLaunchKernelGGL(dwconv_bn_silu_kernel<7>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d);
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<7>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm);
       break;
     default: return hipErrorInvalidValue;
   }

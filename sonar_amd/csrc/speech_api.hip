@@ -4,6 +4,7 @@
 // Reference op order: sonar/models/sonar_speech/model.py:59-77; conformer block / frontend
 // semantics per SURVEY a27-a29 (fairseq2 ~=0.4).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -122,6 +123,7 @@ struct smi_speech_encoder {
   int kpad = 0;  // stacked feature dim padded to a multiple of 64
   int ffn_tile_major = 0;  // macaron FFN operands (LN output, hidden, weights) in the tile-major layout
   int x16 = 0;             // SMI_ENC_FP16_RESIDUAL: the conformer's residual stream is fp16
+  int mid_tm = 0;          // the attention context and the depthwise-conv output (X of the two N = K = d GEMMs) tile-major
   DevBuf pe_ln_w, pe_ln_b, proj_w, proj_b, ln_w, ln_b, pool_q0, pool_out_w, rel_table;
   std::vector<ConfLayer> layers;
   std::vector<PoolLayer> pooler;
@@ -259,6 +261,14 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
   E->layers.resize(c.num_layers);
   E->ffn_tile_major = f % 256 == 0;  // d % 256 == 0 is checked above
   E->x16 = (c.flags & SMI_ENC_FP16_RESIDUAL) != 0;
+  // Round 4: the per-clip kernels (relative-position attention, depthwise conv) write their outputs tile-major -- any packed
+  // row addresses its own 64-B slice of a block, no clip alignment is needed -- so the attention-output and pointwise_conv2
+  // GEMMs (N = K = d, the least efficient shape of the block) read both operands as linear 16 KiB bursts.  SMI_SPEECH_MID_TM=0
+  // restores the row-major operands (A/B, read at create).
+  {
+    const char* e = getenv("SMI_SPEECH_MID_TM");
+    E->mid_tm = E->ffn_tile_major && !(e && e[0] == '0');
+  }
   for (int l = 0; l < c.num_layers && rc == SMI_OK; ++l) {
     const smi_conformer_layer& s = w->layers[l];
     ConfLayer& L = E->layers[l];
@@ -287,6 +297,10 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     up(s.ffn2_out_b, d, false, L.ffn2_b2, "ffn2.output_proj.bias");
     up(s.layer_norm_w, d, false, L.ln_w, "layer_norm.weight");
     up(s.layer_norm_b, d, false, L.ln_b, "layer_norm.bias");
+    if (rc == SMI_OK && E->mid_tm) {
+      rc = to_tile_major(L.w_o, (int)d, (int)d);
+      if (rc == SMI_OK) rc = to_tile_major(L.w_pw2, (int)d, (int)d);
+    }
     if (rc == SMI_OK && E->ffn_tile_major) {
       rc = to_tile_major(L.ffn1_w1, (int)f, (int)d);
       if (rc == SMI_OK) rc = to_tile_major(L.ffn1_w2, (int)d, (int)f);
@@ -450,6 +464,7 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   // (common.hpp): their LayerNorm input, the SiLU hidden activation and the weights.
   const int tmf = E->ffn_tile_major;
   const int ffn_in = tmf ? GEMM_IN_TM : 0, ffn_io = tmf ? GEMM_IN_TM | GEMM_OUT_TM : 0;
+  const int mid_in = E->mid_tm ? GEMM_IN_TM : 0;
   HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream,
                            tmf, x16));
   for (int l = 0; l < c.num_layers; ++l) {
@@ -463,14 +478,14 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | ffn_in, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, pe_slice, L.w_r.as<f16>(), nullptr, E->rp.p, rp_m, d, d, d, stream));
     HIP_TRY(launch_relpos_attention(qkv, dcu, E->rp.as<f16>(), tm - 1, rp_m, L.u_bias.as<float>(), L.v_bias.as<float>(), ctx,
-                                    n, tm, d, c.num_heads, stream));
-    HIP_TRY(launch_gemm_tn(epi_res, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
+                                    n, tm, d, c.num_heads, stream, E->mid_tm));
+    HIP_TRY(launch_gemm_tn(epi_res | mid_in, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
     // x += Conv(LN(x)): pointwise(d->2d)+GLU, depthwise+BN+SiLU, pointwise(d->d)
     HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
     HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | ffn_in, h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
     HIP_TRY(launch_dwconv_bn_silu(E->glu.as<f16>(), dcu, L.w_dw.as<float>(), L.bn_scale.as<float>(), L.bn_shift.as<float>(),
-                                  E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream));
-    HIP_TRY(launch_gemm_tn(epi_res, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
+                                  E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream, E->mid_tm));
+    HIP_TRY(launch_gemm_tn(epi_res | mid_in, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
     // x += 0.5 * FFN2(LN(x))
     HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
     HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
