@@ -227,8 +227,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   constexpr bool TM = LAYOUT > 0;
   // LayerNorm fold (kernels.hpp: GemmLnFold).  CONSUMER: fp16 tile-major epilogues whose X operand is the residual stream
   // itself; PRODUCER: the tile-major residual epilogue, which leaves the row sums of the stream it writes.
-  constexpr bool FOLD_CONSUMER = LAYOUT == 2 && (EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16);
+  // (round 4: also the SiLU epilogue, and the ROW-MAJOR fp16 outputs of tile-major operands -- LAYOUT 1, bias and GLU: the
+  // conformer's fused QKV and pointwise_conv1 feed per-clip kernels that read rows -- in the centred variant only)
+  constexpr bool FOLD_CONSUMER_ST = LAYOUT == 1 && (EPI == EPI_BIAS_F16 || EPI == EPI_GLU_F16);  // staged epilogues
+  constexpr bool FOLD_CONSUMER = (LAYOUT == 2 && (EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16 || EPI == EPI_SILU_F16)) ||
+                                 FOLD_CONSUMER_ST;
   constexpr bool FOLD_PRODUCER = LAYOUT == 3;
+  // the exact variant (epilogue term "- mean * c1") exists for the text encoder's bias / relu consumers only: the later
+  // consumers are centred-only, which spares them the c1 slice's registers (the SiLU kernel spilled with it)
+  constexpr bool FOLD_EXACT = LAYOUT == 2 && (EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16);
   const bool folded = FOLD_CONSUMER && fold.part_in != nullptr;
   // work unit = (tile, K part kz): split-K (EPI_STORE_F32 only) gives each part its own fp32 output slab
   // at out + kz * part_stride bytes; the bias goes into part 0; the consumer sums the slabs.
@@ -269,7 +276,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   float2* rowsum_lds = (float2*)(bias_lds + 1536);  // fold producer: [4 column waves][256 rows]
   auto fetch_c1 = [&](int n0) {
     float v = 0.f;
-    if (folded && tid < 256) v = fold.c1[n0 + tid];
+    if constexpr (FOLD_EXACT) {
+      if (folded && tid < 256) v = fold.c1[n0 + tid];
+    }
     return v;
   };
   // Raw partial sums only -- NO arithmetic here: anything computed from the loads would put their s_waitcnt in front of
@@ -340,8 +349,15 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     out = (char*)out_ + (size_t)kz * part_stride;
     G2_TRACE(0);
     if (tid < 256) bias_lds[tid] = bias_next;
+    if constexpr (FOLD_CONSUMER_ST) {
+      // the staged epilogue of the previous tile went through this staging buffer: the accumulators' zero start value
+      // has to be written again (the register-direct tile-major epilogues never touch it)
+      if (folded && tid < 256) zero_lds[tid] = 0.f;
+    }
     if (folded) {
-      if (tid < 256) c1_lds[tid] = c1_next;
+      if constexpr (FOLD_EXACT) {
+        if (tid < 256) c1_lds[tid] = c1_next;
+      }
       stat_lds[tid] = float2{stat_next.a.x + stat_next.b.x, stat_next.a.y + stat_next.b.y};
     }
     GemmTile256Acc acc;
@@ -362,7 +378,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         const float2 h0 = stat_lds[row], h1 = stat_lds[256 + row];
         row_sq[u] = float2{h0.x + h1.x, h0.y + h1.y};
       }
-      col_c1 = c1_lds[wc * 64 + lane];
+      if constexpr (FOLD_EXACT) col_c1 = c1_lds[wc * 64 + lane];
       col_c2 = bias_lds[wc * 64 + lane];
     }
     G2_TRACE(1);
@@ -387,6 +403,45 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     // staged epilogues: pass p holds tile rows wr*128 + p*32 + (0..31) of both row groups =
     // accumulator blocks mi = 2p, 2p+1; a lane writes staging row lr_w(mi)
     auto lr_w = [&](int mi) { return wr * 32 + (mi & 1) * 16 + l15; };
+    // Fold consumer with a STAGED epilogue (row-major fp16 output): the centred LayerNorm fold applied to the accumulators in
+    // place, before the activation and the staging passes -- out = rstd(row) * acc + c2(column).  Like the tile-major store
+    // (below) it takes everything from registers through ds_bpermute: lane L holds (sum, sum of squares) of rows wr*128 + L and
+    // + 64 + L and c2 of column wc*64 + L.  128 v_pk_fma_f32 per lane and tile.
+    auto fold_affine_st = [&](GemmTile256Acc& a) {
+      float row_rs[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float mean = row_sq[u].x * fold.inv_k;
+        const float var = fmaxf(row_sq[u].y * fold.inv_k - mean * mean, 0.f);
+        row_rs[u] = __builtin_amdgcn_rsqf(var + fold.eps);
+      }
+      float rsall[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+        rsall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(((mi & 3) * 16 + l15) * 4, __float_as_int(row_rs[mi >> 2])));
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        f32x4 c2v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          c2v[r] = __int_as_float(__builtin_amdgcn_ds_bpermute((ni * 16 + 4 * kg + r) * 4, __float_as_int(col_c2)));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          const f32x2 rs2 = {rsall[mi], rsall[mi]};
+          f32x4 v = a.v[ni][mi];
+#pragma unroll
+          for (int hp2 = 0; hp2 < 2; ++hp2) {
+            const f32x2 c2p = {c2v[2 * hp2], c2v[2 * hp2 + 1]};
+            f32x2 vp = {v[2 * hp2], v[2 * hp2 + 1]};
+            vp = __builtin_elementwise_fma(rs2, vp, c2p);
+            v[2 * hp2] = vp[0];
+            v[2 * hp2 + 1] = vp[1];
+          }
+          a.v[ni][mi] = v;
+        }
+      }
+    };
+    (void)fold_affine_st;
 
     if constexpr (EPI == EPI_STORE_F32) {
       if (stats.tile_max) {
@@ -458,7 +513,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       // A = 2j, B = 2j + 1 and v_permlane16_swap joins lane groups so that every lane owns one whole 16-B chunk --
       // here on the fp32 values (4 swaps per pair instead of 2), because the residual add is one fp32 add rounded
       // once.  The 16 old chunks of a wave are requested before the first add.
-      static_assert(EPI == EPI_RESID_F16, "tile-major residual: EPI_RESID_F16 only");
+      static_assert(EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16, "tile-major residual: fp16 stream epilogues only");
+      constexpr float RSTEP = EPI == EPI_RESID_HALF_F16 ? 0.5f : 1.0f;  // x += 0.5 * (...): the conformer's macaron FFNs
       const int cidx = (kg & 1) * 2 + (kg >> 1);
       const int sw = tm_swz(l15);
       f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
@@ -486,7 +542,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           }
           half8 o;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = (f16)((float)oldv[mi][j][i] + c8[i]);
+          for (int i = 0; i < 8; ++i) o[i] = (f16)__builtin_fmaf(c8[i], RSTEP, (float)oldv[mi][j][i]);
           store_nt((half8*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), o);
           if (emit) {
             // of the ROUNDED values (what the consuming GEMM will read), two per v_dot2_f32_f16: exact fp16 products,
@@ -602,6 +658,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     } else if constexpr (EPI == EPI_GLU_F16) {
       // 128 output channels per tile; a wave's 64 columns are [32 values | 32 gates] (W rows interleaved
       // in 32-channel groups at pack time): channel wc*32 + nl*16 + 4kg + r from blocks ni = nl, nl + 2
+      if constexpr (FOLD_CONSUMER_ST) {
+        if (folded) fold_affine_st(acc);  // acc <- rstd(row) * acc + c2(column), the LayerNorm in front of this GEMM
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         char* st = g2_stage(smem, p);
@@ -732,14 +791,17 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       if constexpr (FOLD_CONSUMER) {
         if (!folded)
           store_tile(std::integral_constant<int, 0>{});
-        else if (fold.centered)
+        else if (fold.centered || !FOLD_EXACT)
           store_tile(std::integral_constant<int, 2>{});
-        else
+        else if constexpr (FOLD_EXACT)
           store_tile(std::integral_constant<int, 1>{});
       } else {
         store_tile(std::integral_constant<int, 0>{});
       }
     } else {
+      if constexpr (FOLD_CONSUMER_ST) {
+        if (folded) fold_affine_st(acc);
+      }
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         char* st = g2_stage(smem, p);
@@ -887,16 +949,28 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // floor for a K = 1024 tile and one workgroup per CU; measured crossover (tools/probe_engines.py):
   // 128 tiles tie, 160 tiles win -> use it from 144 tiles (56 % of the CUs) up
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 144);
-  if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream; consumer = layouts 2 (bias / relu), producer = layout 3
-    if (!can256 || sel == 1 || !in_tm || !out_tm || stats) return hipErrorInvalidValue;
-    if (fold->part_in) {
+  if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream
+    if (!can256 || sel == 1 || !in_tm || stats) return hipErrorInvalidValue;
+    if (fold->part_in) {  // consumer: tile-major outputs (bias / relu / silu) or row-major ones (bias / GLU; centred weights)
       if (!fold->c1 || fold->nparts < 1 || fold->nparts > 4) return hipErrorInvalidValue;
-      if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
-      if (epi == EPI_RELU_F16) return launch_one256<EPI_RELU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+      if (out_tm) {
+        if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+        if (epi == EPI_RELU_F16) return launch_one256<EPI_RELU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+        if (epi == EPI_SILU_F16 && fold->centered)
+          return launch_one256<EPI_SILU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+        return hipErrorInvalidValue;
+      }
+      if (!fold->centered) return hipErrorInvalidValue;
+      if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 1>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+      if (epi == EPI_GLU_F16) return launch_one256<EPI_GLU_F16, 1>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
       return hipErrorInvalidValue;
     }
-    if (epi != EPI_RESID_F16 || !fold->part_out) return hipErrorInvalidValue;
-    return launch_one256<EPI_RESID_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+    // producer: the tile-major residual epilogue (part_out may be null: plain read-modify-write of the stream)
+    if (!out_tm) return hipErrorInvalidValue;
+    if (epi == EPI_RESID_F16) return launch_one256<EPI_RESID_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+    if (epi == EPI_RESID_HALF_F16)
+      return launch_one256<EPI_RESID_HALF_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
+    return hipErrorInvalidValue;
   }
   if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
     if (epi != EPI_STORE_F32 || out_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
@@ -913,6 +987,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       SMI_EPI_CASE(EPI_RELU_F16, 2)
       SMI_EPI_CASE(EPI_SILU_F16, 2)
       SMI_EPI_CASE(EPI_RESID_F16, 3)
+      SMI_EPI_CASE(EPI_RESID_HALF_F16, 3)
     }
     return hipErrorInvalidValue;
   }

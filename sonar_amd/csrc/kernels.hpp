@@ -221,7 +221,7 @@ hipError_t launch_stack_ln(const float* fb, int n, int t, int nb, const int32_t*
                            const float* b, float eps, f16* out, int ldo, hipStream_t stream);
 // x = LN1(x) in place; h = f16(w2 ? LN2(x) : x) (h may be null)
 hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0);
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm = 0, int x_f16 = 0, int x_tm = 0);
 hipError_t launch_fbank_batch(const float* waves, const int64_t* off_dev, int n, int tpad, float scale,
                               int standardize, const float* window, const float* mel_w, const int* mel_range,
                               float* out, hipStream_t stream);

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
                                                   const float* __restrict__ b1,
                                                   const float* __restrict__ w2,
                                                   const float* __restrict__ b2, float eps,
-                                                  f16* __restrict__ h, int rows) {
+                                                  f16* __restrict__ h, int rows, int x_tm) {
   constexpr int D = NV * 256;
   constexpr float inv_d = 1.0f / D;
   const int lane = threadIdx.x & 63;
@@ -327,6 +327,9 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
   if (r >= rows) return;
   XT* xr = x + (size_t)r * D;
   if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
+    // x_tm: the fp16 stream itself is tile-major (common.hpp; round 4, with the LayerNorm fold of the conformer's GEMMs):
+    // a lane's 16-B chunk of row r is a 16-B chunk there too
+    auto xp = [&](int k) { return x_tm ? x + tm_offset(r, k * 512 + lane * 8, D) : xr + k * 512 + lane * 8; };
     // fp16 stream: a lane owns 8 consecutive columns per 512-column block -> every access is 16 B
     // (the stream read and write-back, and one whole 16-B chunk of the tile-major h)
     constexpr int NH = NV / 2;
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
     float s8 = 0.f;
 #pragma unroll
     for (int k = 0; k < NH; ++k) {
-      const half8 raw = *(const half8*)(xr + k * 512 + lane * 8);
+      const half8 raw = *(const half8*)xp(k);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         u[k][i] = (float)raw[i];
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
         u[k][i] = (float)hv[i];  // the second LayerNorm sees what the stream holds
         s8 += u[k][i];
       }
-      *(half8*)(xr + k * 512 + lane * 8) = hv;
+      *(half8*)xp(k) = hv;
     }
     if (!h) return;
     if (w2) {
@@ -474,11 +477,12 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
 }
 
 hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2, const float* b2, float eps,
-                      f16* h, int rows, int d, hipStream_t stream, int out_tm, int x_f16) {
+                      f16* h, int rows, int d, hipStream_t stream, int out_tm, int x_f16, int x_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
+  if (x_tm && (!x_f16 || d % 512)) return hipErrorInvalidValue;  // the tile-major stream is fp16, 16-B chunks per lane
   const int blocks = (rows + 3) / 4;
 #define SMI_LN2_LAUNCH(NV, TMF, XT) \
-  hipLaunchKernelGGL((ln2_kernel<NV, TMF, XT>), dim3(blocks), dim3(256), 0, stream, (XT*)x, w1, b1, w2, b2, eps, h, rows);
+  hipLaunchKernelGGL((ln2_kernel<NV, TMF, XT>), dim3(blocks), dim3(256), 0, stream, (XT*)x, w1, b1, w2, b2, eps, h, rows, x_tm);
 #define SMI_LN2_CASE(NV)                 \
   case NV * 256:                         \
     if (out_tm) {                        \

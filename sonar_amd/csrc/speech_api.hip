@@ -63,6 +63,9 @@ struct ConfLayer {
   DevBuf conv_ln_w, conv_ln_b, w_pw1, w_dw, bn_scale, bn_shift, w_pw2;
   DevBuf ffn2_ln_w, ffn2_ln_b, ffn2_w1, ffn2_b1, ffn2_w2, ffn2_b2;
   DevBuf ln_w, ln_b;
+  // LayerNorm folded into the GEMM that consumes it (kernels.hpp: GemmLnFold; round 4): the weights pre-scaled by the
+  // LayerNorm weight and row-centred, tile-major, and c1 (unused by the centred epilogue) / c2 = W . b + bias
+  DevBuf wf_qkv, c1_qkv, c2_qkv, wf_pw1, c1_pw1, c2_pw1, wf_ffn2, c1_ffn2, c2_ffn2;
 };
 struct PoolLayer {
   DevBuf sv_w, sv_b, so_w, so_b, sln_w, sln_b;
@@ -124,11 +127,12 @@ struct smi_speech_encoder {
   int ffn_tile_major = 0;  // macaron FFN operands (LN output, hidden, weights) in the tile-major layout
   int x16 = 0;             // SMI_ENC_FP16_RESIDUAL: the conformer's residual stream is fp16
   int mid_tm = 0;          // the attention context and the depthwise-conv output (X of the two N = K = d GEMMs) tile-major
+  int x_tm = 0;            // the fp16 residual stream itself tile-major + 3 of a block's 5 LayerNorms folded into their GEMMs
   DevBuf pe_ln_w, pe_ln_b, proj_w, proj_b, ln_w, ln_b, pool_q0, pool_out_w, rel_table;
   std::vector<ConfLayer> layers;
   std::vector<PoolLayer> pooler;
   // workspace
-  DevBuf cu, hf, x, h, big, qkv, ctx, glu, dw, rp, enc_h;
+  DevBuf cu, hf, x, h, big, qkv, ctx, glu, dw, rp, enc_h, lnpart;
   DevBuf xq, hq, pv, pq, pkv, pctx, pffn, pout;
 };
 
@@ -269,6 +273,26 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     const char* e = getenv("SMI_SPEECH_MID_TM");
     E->mid_tm = E->ffn_tile_major && !(e && e[0] == '0');
   }
+  // Round 4: with every GEMM operand of a block tile-major, the fp16 residual stream can be tile-major too (the text
+  // encoder's layout): the four residual GEMMs read-modify-write it straight from their accumulators (LAYOUT 3)
+  // and leave per-row (sum, sum of squares), and the LayerNorms in front of the fused QKV, pointwise_conv1 and the second
+  // FFN's inner projection are applied in those GEMMs' epilogues (centred weights) -- 72 row launches and their h round trips
+  // per forward disappear.  The block-final LayerNorm rewrites the stream and stays a kernel (ln2, with the next block's
+  // first LayerNorm).  SMI_SPEECH_X_TM=0 restores the row-major stream (A/B, read at create).
+  {
+    const char* e = getenv("SMI_SPEECH_X_TM");
+    E->x_tm = E->mid_tm && E->x16 && d % 512 == 0 && !(e && e[0] == '0');
+  }
+  auto fold_prep = [&](const DevBuf& W, const DevBuf& g, const DevBuf& b, const float* bias, int64_t N, int64_t K,
+                       DevBuf& Wf, DevBuf& c1, DevBuf& c2) -> int {
+    HIP_TRY(Wf.alloc((size_t)N * K * 2));
+    HIP_TRY(c1.alloc((size_t)N * 4));
+    HIP_TRY(c2.alloc((size_t)N * 4));
+    HIP_TRY(launch_ln_fold_prep(W.as<f16>(), g.as<float>(), b.as<float>(), bias, Wf.as<f16>(), c1.as<float>(),
+                                c2.as<float>(), (int)N, (int)K, 1, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return to_tile_major(Wf, (int)N, (int)K);
+  };
   for (int l = 0; l < c.num_layers && rc == SMI_OK; ++l) {
     const smi_conformer_layer& s = w->layers[l];
     ConfLayer& L = E->layers[l];
@@ -301,6 +325,8 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
       rc = to_tile_major(L.w_o, (int)d, (int)d);
       if (rc == SMI_OK) rc = to_tile_major(L.w_pw2, (int)d, (int)d);
     }
+    if (rc == SMI_OK && E->x_tm)  // (row-major weights in, before they are packed)
+      rc = fold_prep(L.ffn2_w1, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_b1.as<float>(), f, d, L.wf_ffn2, L.c1_ffn2, L.c2_ffn2);
     if (rc == SMI_OK && E->ffn_tile_major) {
       rc = to_tile_major(L.ffn1_w1, (int)f, (int)d);
       if (rc == SMI_OK) rc = to_tile_major(L.ffn1_w2, (int)d, (int)f);
@@ -310,6 +336,8 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
     if (rc == SMI_OK) {
       const smi_tensor ws[3] = {s.q_w, s.k_w, s.v_w}, bs[3] = {s.q_b, s.k_b, s.v_b};
       rc = pack_fused(ws, bs, 3, d, d, L.w_qkv, L.b_qkv, "self_attn.qkv");
+      if (rc == SMI_OK && E->x_tm)
+        rc = fold_prep(L.w_qkv, L.attn_ln_w, L.attn_ln_b, L.b_qkv.as<float>(), 3 * d, d, L.wf_qkv, L.c1_qkv, L.c2_qkv);
       // the QKV and pointwise_conv1 GEMMs read a LayerNorm output: packed rows, no per-clip alignment in the
       // way, so their INPUTS are tile-major too (their outputs feed per-clip kernels and stay row-major)
       if (rc == SMI_OK && E->ffn_tile_major) rc = to_tile_major(L.w_qkv, (int)(3 * d), (int)d);
@@ -324,6 +352,8 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
           he = hipDeviceSynchronize();
         }
         if (he != hipSuccess) rc = fail(SMI_ERR_HIP, "glu interleave: %s", hipGetErrorString(he));
+        if (rc == SMI_OK && E->x_tm)  // the interleaved rows are scaled / centred row by row: the interleave commutes
+          rc = fold_prep(L.w_pw1, L.conv_ln_w, L.conv_ln_b, nullptr, 2 * d, d, L.wf_pw1, L.c1_pw1, L.c2_pw1);
         if (rc == SMI_OK && E->ffn_tile_major) rc = to_tile_major(L.w_pw1, (int)(2 * d), (int)d);
       }
     }
@@ -454,8 +484,21 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   // frontend: stack 2 frames -> LN(160) -> Linear(160 -> d)
   HIP_TRY(launch_stack_ln(fbank, n, t, c.num_mel_bins, dcu, tm, E->pe_ln_w.as<float>(), E->pe_ln_b.as<float>(), c.ln_eps,
                           E->hf.as<f16>(), E->kpad, stream));
-  HIP_TRY(launch_gemm_tn(x16 ? EPI_BIAS_F16 : EPI_STORE_F32, E->hf.as<f16>(), E->proj_w.as<f16>(), E->proj_b.as<float>(), x, R, d,
-                         E->kpad, d, stream));
+  const int xtm = E->x_tm;
+  if (xtm) {  // row-major out of the projection (into h, free here), then one pass into the tile-major stream
+    HIP_TRY(E->lnpart.reserve((size_t)(d / 256) * R * sizeof(float2)));
+    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, E->hf.as<f16>(), E->proj_w.as<f16>(), E->proj_b.as<float>(), h, R, d, E->kpad, d, stream));
+    HIP_TRY(launch_pack_tile_major(h, (f16*)x, R, d, 0, stream));
+  } else {
+    HIP_TRY(launch_gemm_tn(x16 ? EPI_BIAS_F16 : EPI_STORE_F32, E->hf.as<f16>(), E->proj_w.as<f16>(), E->proj_b.as<float>(), x, R, d,
+                           E->kpad, d, stream));
+  }
+  // fold descriptors: the residual GEMMs leave lnpart[d/256][R] (sum, sum of squares) of the rows they have just written,
+  // the next consuming GEMM reads them (one buffer: produced and consumed in stream order, once per pair)
+  float2* lnpart = E->lnpart.as<float2>();
+  const GemmLnFold produce{lnpart, nullptr, nullptr, 0, 0.f, 0.f, 0};
+  auto consume = [&](const DevBuf& c1) { return GemmLnFold{nullptr, lnpart, c1.as<float>(), d / 256, 1.0f / d, c.ln_eps, 1}; };
+  const int io_tm = GEMM_IN_TM | GEMM_OUT_TM;
   // relative positions rel in [-(tm-1), tm-1] (+ tile padding) from the ascending table
   const int64_t P = c.max_frames + 192;
   const f16* pe_slice = E->rel_table.as<f16>() + (size_t)((P - 1) - (tm - 1)) * d;
@@ -466,37 +509,63 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   const int ffn_in = tmf ? GEMM_IN_TM : 0, ffn_io = tmf ? GEMM_IN_TM | GEMM_OUT_TM : 0;
   const int mid_in = E->mid_tm ? GEMM_IN_TM : 0;
   HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream,
-                           tmf, x16));
+                           tmf, x16, xtm));
   for (int l = 0; l < c.num_layers; ++l) {
     ConfLayer& L = E->layers[l];
     // x += 0.5 * FFN1(LN(x))
     HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn1_w1.as<f16>(), L.ffn1_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
-                           stream));
-    // x += RelPosMHA(LN(x))
-    HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
-    HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | ffn_in, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
+    if (xtm) {
+      HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F16 | io_tm, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d, stream,
+                             nullptr, &produce));
+      // x += RelPosMHA(LN(x)): the LayerNorm rides in the fused QKV GEMM, which multiplies the stream itself
+      const GemmLnFold cq = consume(L.c1_qkv);
+      HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | GEMM_IN_TM, (const f16*)x, L.wf_qkv.as<f16>(), L.c2_qkv.as<float>(), qkv, R, 3 * d, d,
+                             3 * d, stream, nullptr, &cq));
+    } else {
+      HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
+                             stream));
+      // x += RelPosMHA(LN(x))
+      HIP_TRY(launch_layernorm(x, L.attn_ln_w.as<float>(), L.attn_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
+      HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | ffn_in, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream));
+    }
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, pe_slice, L.w_r.as<f16>(), nullptr, E->rp.p, rp_m, d, d, d, stream));
     HIP_TRY(launch_relpos_attention(qkv, dcu, E->rp.as<f16>(), tm - 1, rp_m, L.u_bias.as<float>(), L.v_bias.as<float>(), ctx,
                                     n, tm, d, c.num_heads, stream, E->mid_tm));
-    HIP_TRY(launch_gemm_tn(epi_res | mid_in, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
     // x += Conv(LN(x)): pointwise(d->2d)+GLU, depthwise+BN+SiLU, pointwise(d->d)
-    HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
-    HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | ffn_in, h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
+    if (xtm) {
+      HIP_TRY(launch_gemm_tn(EPI_RESID_F16 | io_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream, nullptr,
+                             &produce));
+      const GemmLnFold cg = consume(L.c1_pw1);
+      HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | GEMM_IN_TM, (const f16*)x, L.wf_pw1.as<f16>(), L.c2_pw1.as<float>(), E->glu.p,
+                             R, 2 * d, d, d, stream, nullptr, &cg));
+    } else {
+      HIP_TRY(launch_gemm_tn(epi_res | mid_in, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
+      HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
+      HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | ffn_in, h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
+    }
     HIP_TRY(launch_dwconv_bn_silu(E->glu.as<f16>(), dcu, L.w_dw.as<float>(), L.bn_scale.as<float>(), L.bn_shift.as<float>(),
                                   E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream, E->mid_tm));
-    HIP_TRY(launch_gemm_tn(epi_res | mid_in, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
     // x += 0.5 * FFN2(LN(x))
-    HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
-    HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d,
-                           stream));
+    if (xtm) {
+      HIP_TRY(launch_gemm_tn(EPI_RESID_F16 | io_tm, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream, nullptr,
+                             &produce));
+      const GemmLnFold cf = consume(L.c1_ffn2);
+      HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | io_tm, (const f16*)x, L.wf_ffn2.as<f16>(), L.c2_ffn2.as<float>(), big, R, f, d, f,
+                             stream, nullptr, &cf));
+      HIP_TRY(launch_gemm_tn(EPI_RESID_HALF_F16 | io_tm, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d, stream));
+    } else {
+      HIP_TRY(launch_gemm_tn(epi_res | mid_in, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream));
+      HIP_TRY(launch_layernorm(x, L.ffn2_ln_w.as<float>(), L.ffn2_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
+      HIP_TRY(launch_gemm_tn(EPI_SILU_F16 | ffn_io, h, L.ffn2_w1.as<f16>(), L.ffn2_b1.as<float>(), big, R, f, d, f, stream));
+      HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn2_w2.as<f16>(), L.ffn2_b2.as<float>(), x, R, d, f, d,
+                             stream));
+    }
     // x = LN_block(x); h = next block's ffn1 LN, or the model-level LayerNorm after the last block
     const bool last = l + 1 == c.num_layers;
     const float* w2 = last ? E->ln_w.as<float>() : E->layers[l + 1].ffn1_ln_w.as<float>();
     const float* b2 = last ? E->ln_b.as<float>() : E->layers[l + 1].ffn1_ln_b.as<float>();
     // (the last block's h is the encoder output the pooler reads row-major)
-    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream, last ? 0 : tmf, x16));
+    HIP_TRY(launch_ln2(x, L.ln_w.as<float>(), L.ln_b.as<float>(), w2, b2, c.ln_eps, h, R, d, stream, last ? 0 : tmf, x16, xtm));
   }
   // ---- attention pooler: h now holds the encoder output (fp16) ----
   float* xq = E->xq.as<float>();

@@ -405,6 +405,41 @@ def test_speech_encoder_english_10s_clip_vs_oracle_full_size():
     assert _cos_err(outb[:1], out) <= 1e-5
 
 
+def test_speech_encoder_streams_agree_at_benchmark_rows(monkeypatch):
+    """The tile-major residual stream with the LayerNorm fold (round 4, the default for fp16 models) against the
+    row-major stream with LayerNorm launches, on a batch whose GEMMs give every persistent workgroup SEVERAL tiles
+    (26 clips x 5 s = 6 474 frames = 26 row tiles: 104-416 tiles per GEMM on 256 CUs) -- per-tile state that only a
+    second tile of a workgroup can clobber (the staged fold epilogue's LDS constants, found the hard way) is invisible
+    to the short-clip oracle tests above.  The two engines differ by fp16 roundings of h only."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sonar_amd.speech_encoder import SpeechEncoderEngine, get_speech_encoder_config, waveforms_to_fbank_batch
+    from tools.synth import speech_encoder_state_dict
+
+    dev = torch.device("cuda:0")
+    sd = speech_encoder_state_dict(dev)
+    cfg = get_speech_encoder_config("english")
+    g = torch.Generator(device=dev).manual_seed(31)
+    wavs = [torch.rand(80000 - 37 * i, device=dev, generator=g) * 2 - 1 for i in range(26)]
+    fb, lens = waveforms_to_fbank_batch(wavs)
+    monkeypatch.setenv("SMI_SPEECH_X_TM", "0")            # read when the engine is created
+    rowmajor = SpeechEncoderEngine(cfg, sd, device=dev, fp16_residual=True)
+    want = rowmajor.forward(fb, lens, torch.float32).cpu()
+    del rowmajor
+    monkeypatch.delenv("SMI_SPEECH_X_TM")
+    eng = SpeechEncoderEngine(cfg, sd, device=dev, fp16_residual=True)
+    got = eng.forward(fb, lens, torch.float32).cpu()
+    again = eng.forward(fb, lens, torch.float32).cpu()
+    assert torch.isfinite(got).all() and torch.equal(got, again)
+    err = _cos_err(got, want)
+    rel = (got - want).abs().max().item() / want.abs().max().item()
+    print(f"english speech encoder, 26 x 5 s: tile-major stream + LN fold vs row-major stream: max (1 - cos) {err:.2e}, "
+          f"max |diff| / max |ref| {rel:.2e}")
+    assert err <= 1e-5 and rel <= 2e-2
+
+
 def test_speech_encoder_english_vs_oracle_full_size():
     """sonar_speech_encoder_eng (24 conformer blocks, d 1024, 3-layer pooler) on 3 clips of 1.0 / 1.6 / 2.0 s,
     waveform -> embedding, against the fp32 oracle (filterbank included), both residual precisions."""
