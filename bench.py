@@ -293,6 +293,8 @@ class _StubXsim:
 
 def _with_rccl_log(collective: dict, path) -> dict:
     """RCCL's own init lines (NCCL_DEBUG=INFO, subsystem INIT, written to a file): the `nranks` of the communicator."""
+    if path and not os.path.exists(path):
+        collective["rccl_init_lines"] = "NCCL_DEBUG_FILE was not written by this RCCL build (the per-rank fact sheet stands alone)"
     if path and os.path.exists(path):
         try:
             with open(path, "r", errors="replace") as fh:

@@ -1,6 +1,6 @@
 """Variant build of the library for same-box A/B runs: recompile the named sources with extra flags, link them with the in-tree
 objects of everything else into gpurun_variants/lib<name>.so (git-ignored; travels to the GPU box).  Load it with SMI_LIB=...
-usage: python tools/build_variant.py <name> <src.hip>[,<src2.hip>] -DFLAG[=v] ..."""
+usage: python tools/build_variant.py <name> <src.hip>[=<other file to compile in its place>][,<src2.hip>] -DFLAG[=v] ..."""
 import os
 import subprocess
 import sys
@@ -11,7 +11,9 @@ from sonar_amd import build as B  # noqa: E402
 
 
 def main():
-    name, srcs, flags = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
+    name, flags = sys.argv[1], sys.argv[3:]
+    alt = dict((x.split("=", 1) + [""])[:2] for x in sys.argv[2].split(","))   # source -> replacement file ("" = itself)
+    srcs = list(alt)
     B.build(verbose=False)
     out = Path(__file__).resolve().parent.parent / "gpurun_variants"
     objd = out / f"obj_{name}"
@@ -23,7 +25,8 @@ def main():
         stem = Path(s).stem
         if s in srcs:
             o = objd / (stem + ".o")
-            subprocess.run([cc, *base, *flags, "-c", str(B.CSRC / s), "-o", str(o)], check=True)
+            src = alt[s] or str(B.CSRC / s)
+            subprocess.run([cc, *base, *flags, f"-I{B.CSRC}", "-c", src, "-o", str(o)], check=True)
         else:
             o = B.OUT_DIR / "obj" / (stem + ".o")
         objs.append(str(o))

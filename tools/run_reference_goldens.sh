@@ -27,6 +27,11 @@ python -m pytest tests/test_gpu_reference_goldens.py -m gpu -v -s -rs 2>&1 | tee
   for f in sonar_text_encoder.pt sonar_text_decoder.pt spenc.eng.pt sentencepiece.source.256000.model; do
     if [ -e "$SONAR_CHECKPOINT_DIR/$f" ]; then echo "#   $f ($(stat -c %s "$SONAR_CHECKPOINT_DIR/$f") bytes)"; else echo "#   $f MISSING"; fi
   done
+  echo "# TOLERANCES: the reference asserts its fp32 CPU run to 1e-4 (cosine matrix, logits, speech embeddings: rtol 1e-4 /"
+  echo "#   atol 1e-5 of torch.testing.assert_close) -- this engine multiplies fp16 operands with fp32 accumulation, so the"
+  echo "#   restated tests hold embeddings to 1e-3 on cosine quantities (BASELINE north_star) and fp16-model logits to 5e-2"
+  echo "#   absolute; a PASSED line below is a pass at THOSE bounds, the measured deltas are printed so the reference's own"
+  echo "#   bounds can be read off directly.  Token ids and translated strings are compared exactly."
   echo "# measured deltas (printed by the tests):"
   grep -E "cosine matrix|max \|diff\||1 - cos|dot products|^\[\[|tokens|translat" "$LOG"
   echo "# outcome per test:"
