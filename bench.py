@@ -167,6 +167,28 @@ def decoder_leg(dev, n=256, steps=64, cpu=True):
            "ms": dt * 1e3, "ms_per_step": dt * 1e3 / (steps + 1), "sentences_per_s": n / dt,
            "tokens_per_s": n * (steps + 1) / dt,
            "frac_of_mfma_peak": flop_step * (steps + 1) / dt / 1e12 / MFMA_PEAK_TFLOPS}
+    out["chains"] = 1   # decode_chains(): one chain up to 2048 hypothesis rows
+    # the same decoder on a bucket twice as large: 2560 rows need a second round of FFN tiles as ONE chain, and run as two
+    # independent chains by default (round 4); both timed, same engine, same embeddings
+    try:
+        emb2 = torch.nn.functional.normalize(torch.randn(2 * n, D, device=dev, generator=g), dim=-1).half() * 0.2
+        res = {}
+        for chains in (1, 0):
+            eng.set_chains(chains)
+            eng.generate(emb2, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.generate(emb2, [3, 256047], beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
+            torch.cuda.synchronize()
+            res[chains] = time.perf_counter() - t0
+        eng.set_chains(0)
+        out["batch_x2"] = {"workload": f"the same decoder, batch {2 * n} ({2 * n * 5} hypothesis rows)",
+                           "one_chain_ms_per_step": res[1] * 1e3 / (steps + 1),
+                           "default_chains_ms_per_step": res[0] * 1e3 / (steps + 1), "default_chains": 2,
+                           "sentences_per_s": 2 * n / res[0]}
+        del emb2
+    except Exception as e:   # an extra, never the reason the C5 number is lost
+        out["batch_x2"] = {"error": repr(e)}
     if cpu:
         from oracle import text_decoder as OD
 

@@ -366,6 +366,32 @@ def test_basic_decoder_long_prefix_vs_oracle_full_size(basic_decoder):
         assert ties <= 2
 
 
+def test_basic_decoder_chains_bit_identical_full_size(basic_decoder, monkeypatch):
+    """Independent decode chains at full size (24 layers, V 256 206): 520 sentences x beam 5 = 2 600 hypothesis rows (2 816 padded) run as
+    three chains by default.  With the per-launch tile choices pinned the hypotheses, lengths, scores and
+    margins equal the single chain's bit for bit, sentence for sentence (the toy-width twin of this test covers 3 chains and
+    uneven groups, tests/test_gpu_decoder.py)."""
+    OD, ocfg, params, eng = basic_decoder
+    g = torch.Generator(device="cuda").manual_seed(61)
+    n = 520
+    emb = F.normalize(torch.randn(n, 1024, device="cuda", generator=g), dim=-1).half() * 0.2
+    kw = dict(beam_size=5, min_gen_len=5, max_gen_len=(0, 6))
+    monkeypatch.setenv("SMI_DEC_KS_OUT", "2")
+    monkeypatch.setenv("SMI_DEC_FFN1_ENGINE", "2")
+    try:
+        eng.set_chains(1)
+        one = [t.cpu() for t in eng.generate(emb, [3, 256047], **kw)]
+        m_one = eng.last_margins(n).cpu()
+        eng.set_chains(0)                       # the engine's own policy: min(3, ceil(2816 / 1280)) = 3 chains
+        two = [t.cpu() for t in eng.generate(emb, [3, 256047], **kw)]
+        m_two = eng.last_margins(n).cpu()
+    finally:
+        eng.set_chains(0)
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    assert torch.equal(m_one, m_two)
+
+
 def test_speech_encoder_english_10s_clip_vs_oracle_full_size():
     """BASELINE configs[3] at its own shape: ONE 10 s clip (998 filterbank frames -> 499 conformer frames, relative
     positions out to +-498, eight 64-key tiles in the relative-position attention) through the full

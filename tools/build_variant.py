@@ -25,7 +25,11 @@ def main():
         stem = Path(s).stem
         if s in srcs:
             o = objd / (stem + ".o")
-            src = alt[s] or str(B.CSRC / s)
+            src = str(B.CSRC / s)
+            if alt[s]:  # compile a COPY inside the variant's own directory: quote-includes look next to the including file
+                src = str(objd / s)  # first, and a scratch directory such as /tmp may hold stale headers of the same names
+                with open(alt[s], "rb") as fi, open(src, "wb") as fo:
+                    fo.write(fi.read())
             subprocess.run([cc, *base, *flags, f"-I{B.CSRC}", "-c", src, "-o", str(o)], check=True)
         else:
             o = B.OUT_DIR / "obj" / (stem + ".o")
