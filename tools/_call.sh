@@ -1,21 +1,16 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 OUT=$PWD/gpurun_out
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_encoder.py -m gpu -q -x 2>&1 | tail -4 > $OUT/r04n_pytest.log
-python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -k "encoder or speech" 2>&1 | tail -4 >> $OUT/r04n_pytest.log
-: > $OUT/r04n_oldv.log
+python -m pytest tests/test_gpu_speech.py -m gpu -q -x 2>&1 | tail -4 > $OUT/r04o_pytest.log
+python -m pytest tests/test_gpu_fullsize.py -m gpu -q -x -k "speech" 2>&1 | tail -4 >> $OUT/r04o_pytest.log
+: > $OUT/r04o_dw.log
 for i in 1 2; do
-  for V in old new; do
-    if [ $V == old ]; then export SMI_LIB=$PWD/gpurun_variants/libg2old.so; else unset SMI_LIB; fi
-    echo "== $V" >> $OUT/r04n_oldv.log
-    python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-xsim 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-k=d['kernels']
-print('C2 ms/step', round(d['ms_per_step'],2), 'sent/s', round(d['value']), {n:round(v.get('ms_per_step', v.get('ms',0)),3) for n,v in k.items() if isinstance(v,dict)})
-" >> $OUT/r04n_oldv.log 2>&1
-    python tools/bench_speech.py 2>/dev/null | grep "speech n" >> $OUT/r04n_oldv.log
-  done
+  SMI_LIB=$PWD/gpurun_variants/libdw_head.so python tools/bench_speech.py 2>/dev/null | grep "speech n" >> $OUT/r04o_dw.log
+  python tools/bench_speech.py 2>/dev/null | grep "speech n" >> $OUT/r04o_dw.log
 done
-unset SMI_LIB
-cat $OUT/r04n_pytest.log $OUT/r04n_oldv.log
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/r04o_prof -o s --output-format csv -- python $OLDPWD/tools/bench_speech.py > /dev/null 2>&1
+cd $OLDPWD
+python tools/summarize_prof.py $OUT/r04o_prof 2>&1 | grep "dwconv\|relpos" | cut -c1-150 >> $OUT/r04o_dw.log
+find $OUT/r04o_prof -name "*kernel_trace*" -delete 2>/dev/null
+cat $OUT/r04o_pytest.log $OUT/r04o_dw.log
