@@ -6,8 +6,10 @@
 // with the epilogues fused.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
+#include "gemm_lone.hpp"
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -72,12 +74,119 @@ __device__ __forceinline__ half4 epi_act_pack(f32x4 v) {
   return half4{lo[0], lo[1], hi[0], hi[1]};
 }
 
+// Epilogue of the 128x128-family engines (gemm_tile.hpp, gemm_lone.hpp): a wave holds MI x NI blocks of 32x32, block
+// (ni, mi) element r is C[row0 + mi*32][col0 + ni*32 + 8*(r>>2) + (r&3)] with row0 = tile row + wave row + (lane&31),
+// col0 = tile column + wave column + 4*(lane>>5).  b[ni][q]: the bias of the lane's 4-column runs, loaded by the caller
+// (before the K loop where possible: a load issued here would sit between the stores -- vmcnt does not tell loads from
+// stores, so every wait for a bias value also waited for all the stores before it; the read-modify-write epilogues
+// likewise read ALL old values first).
+template <int EPI, int LAYOUT, int MI, int NI>
+__device__ __forceinline__ void gt_epilogue(const f32x16 (&acc)[NI][MI], const f32x4 (&b)[NI][4], void* __restrict__ out,
+                                            int row0, int col0, int glu_col0, int N, int ldo) {
+  if constexpr (EPI == EPI_GLU_F16) {
+    static_assert(NI == 2, "GLU pairs the two column blocks of a wave");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int oc = glu_col0 + 8 * q;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int m = row0 + mi * 32;
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          h[e] = (f16)((acc[0][mi][q * 4 + e] + b[0][q][e]) * sigmoid_f(acc[1][mi][q * 4 + e] + b[1][q][e]));
+        *(half4*)((f16*)out + (size_t)m * ldo + oc) = h;
+      }
+    }
+  } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_HALF_F32) {
+    f32x4 old[NI][4][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          old[ni][q][mi] = *(const f32x4*)((const float*)out + (size_t)(row0 + mi * 32) * ldo + col0 + ni * 32 + 8 * q);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e] + b[ni][q][e];
+          if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
+          *(f32x4*)((float*)out + (size_t)(row0 + mi * 32) * ldo + col0 + ni * 32 + 8 * q) = old[ni][q][mi] + v;
+        }
+  } else if constexpr (EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16) {
+    half4 old[NI][4][MI];
+    auto at = [&](int ni, int q, int mi) {
+      const int m = row0 + mi * 32, n = col0 + ni * 32 + 8 * q;
+      return LAYOUT == 3 ? (f16*)out + tm_offset(m, n, N) : (f16*)out + (size_t)m * ldo + n;
+    };
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) old[ni][q][mi] = *(const half4*)at(ni, q, mi);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          half4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[ni][mi][q * 4 + e] + b[ni][q][e];
+            if constexpr (EPI == EPI_RESID_HALF_F16) v *= 0.5f;
+            h[e] = (f16)((float)old[ni][q][mi][e] + v);
+          }
+          *(half4*)at(ni, q, mi) = h;
+        }
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int m = row0 + mi * 32, n = col0 + ni * 32 + 8 * q;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][q * 4 + e] + b[ni][q][e];
+          if constexpr (EPI == EPI_STORE_F32) {
+            *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
+          } else {
+            const half4 h = epi_act_pack<EPI>(v);
+            if constexpr (LAYOUT == 2)
+              *(half4*)((f16*)out + tm_offset(m, n, N)) = h;
+            else
+              *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
+          }
+        }
+  }
+}
+
+// the lane's bias values: 4-column runs at col0 + ni*32 + 8*q (zeros without a bias)
+template <int NI>
+__device__ __forceinline__ void gt_load_bias(f32x4 (&b)[NI][4], const float* __restrict__ bias, int col0) {
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      b[ni][q] = bias ? *(const f32x4*)(bias + col0 + ni * 32 + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // LAYOUT: 0 = row-major operands and output; 1 = tile-major X and W (common.hpp), row-major
 // output; 2 = tile-major X, W and fp16 output (the output is the next GEMM's X, its K = N);
 // 3 = tile-major X, W and a tile-major fp16 RESIDUAL STREAM that is read-modified-written
 // (EPI_RESID_F16 only: the text encoder's x, so that the residual epilogue needs no LDS staging).
-// RING: 0 = the two-stage loop, 2 workgroups per CU (launches with more tiles than CUs); 3 / 4 = the counted-wait
-// ring of gemm_tile.hpp with that many stages, 1 workgroup per CU (launches whose tiles all fit on the chip at once).
+// RING: 0 = the two-stage loop, 2 workgroups per CU (launches with more tiles than CUs); 4 = the counted-wait
+// ring of gemm_tile.hpp with that many stages, 1 workgroup per CU (round 3's lone-tile path, kept for A/B runs:
+// SMI_LONE=0; the default for launches whose tiles all fit on the chip at once is gemm_lone_kernel below).
 template <int EPI, int LAYOUT = 0, int RING = 0>
 __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -104,67 +213,40 @@ __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const
     out = (char*)out + (size_t)kz * part_stride;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hi = lane >> 5, wn = wave & 1;
+  const int hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int col0 = n0 + wn * 64 + 4 * hi;
+  f32x4 b[2][4];
+  gt_load_bias<2>(b, bias, col0);
+  gt_epilogue<EPI, LAYOUT, 2, 2>(acc.v, b, out, m0 + wm * 64 + (lane & 31), col0, n0 / 2 + wn * 32 + 4 * hi, N, ldo);
+}
 
-  if constexpr (EPI == EPI_GLU_F16) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 ba = {0.f, 0.f, 0.f, 0.f}, bg = ba;
-      if (bias) {
-        ba = *(const f32x4*)(bias + gt_col(n0, 0, q));
-        bg = *(const f32x4*)(bias + gt_col(n0, 1, q));
-      }
-      const int oc = n0 / 2 + wn * 32 + 8 * q + 4 * hi;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const int m = gt_row(m0, mi);
-        half4 h;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          h[e] = (f16)((acc.v[0][mi][q * 4 + e] + ba[e]) * sigmoid_f(acc.v[1][mi][q * 4 + e] + bg[e]));
-        *(half4*)((f16*)out + (size_t)m * ldo + oc) = h;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = gt_col(n0, ni, q);
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) b = *(const f32x4*)(bias + n);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int m = gt_row(m0, mi);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc.v[ni][mi][q * 4 + e] + b[e];
-          if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_RESID_HALF_F32) {
-            float* p = (float*)out + (size_t)m * ldo + n;
-            f32x4 o = *(f32x4*)p;
-            if constexpr (EPI == EPI_RESID_HALF_F32) v = v * 0.5f;
-            *(f32x4*)p = o + v;
-          } else if constexpr (EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16) {
-            f16* p = LAYOUT == 3 ? (f16*)out + tm_offset(m, n, N) : (f16*)out + (size_t)m * ldo + n;
-            const half4 o = *(const half4*)p;
-            if constexpr (EPI == EPI_RESID_HALF_F16) v = v * 0.5f;
-            half4 h;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (f16)((float)o[e] + v[e]);
-            *(half4*)p = h;
-          } else if constexpr (EPI == EPI_STORE_F32) {
-            *(f32x4*)((float*)out + (size_t)m * ldo + n) = v;
-          } else {
-            const half4 h = epi_act_pack<EPI>(v);
-            if constexpr (LAYOUT == 2)
-              *(half4*)((f16*)out + tm_offset(m, n, N)) = h;
-            else
-              *(half4*)((f16*)out + (size_t)m * ldo + n) = h;
-          }
-        }
-      }
-    }
+// The lone-tile engine (gemm_lone.hpp): unit shape BM x BN, one workgroup per CU, fragments of the next K tile read
+// under the MFMAs of the current one.  Same arguments and epilogues as gemm_tn_kernel (EPI_GLU_F16: BN = 128 only).
+template <int EPI, int LAYOUT, int BM, int BN>
+__global__ __launch_bounds__(GT_THREADS, 1) void gemm_lone_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+                                                                  const float* __restrict__ bias, void* __restrict__ out,
+                                                                  int M, int N, int K, int ldo, int ksplit,
+                                                                  size_t part_stride) {
+  using S = LoneShape<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n;
+  lone_tile_coords(M / BM, N / BN, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kz = blockIdx.y;
+  const int klen = K / ksplit;
+  if (kz > 0) {
+    bias = nullptr;
+    out = (char*)out + (size_t)kz * part_stride;
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hi = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int col0 = n0 + wn * (BN / 2) + 4 * hi;
+  f32x4 b[S::NI][4];
+  gt_load_bias<S::NI>(b, bias, col0);  // in flight under the pipeline fill
+  f32x16 acc[S::NI][S::MI];
+  lone_mainloop<(LAYOUT > 0), BM, BN, S::NI, S::MI>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
+  gt_epilogue<EPI, LAYOUT, S::MI, S::NI>(acc, b, out, m0 + wm * (BM / 2) + (lane & 31), col0,
+                                         n0 / 2 + wn * 32 + 4 * hi, N, ldo);
 }
 
 // LDS accesses the compiler must NOT see as LDS accesses: after the next tile's LDS-DMA pipeline fill has been issued,
@@ -896,14 +978,39 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   return hipGetLastError();
 }
 
-// SMI_GT_RING: stages of the lone-tile ring (0 = never use it, 3, 4; default 4) -- A/B switch
+// SMI_GT_RING: stages of round 3's lone-tile ring (0 = never use it, 4; default 4) -- A/B switch, used with SMI_LONE=0
 static int gt_ring_stages() {
   static const int st = [] {
     const char* e = getenv("SMI_GT_RING");
     const int v = e ? atoi(e) : 4;
-    return v == 3 || v == 4 ? v : 0;
+    return v == 4 ? v : 0;
   }();
   return st;
+}
+
+// SMI_LONE: 0 = round 3's ring for lone-tile launches, otherwise the lone-tile engine (gemm_lone.hpp); SMI_LONE_SHAPE =
+// 128x128 | 128x64 | 64x64 pins the unit shape (A/B runs; read per launch: decode-time paths switch it per call)
+static bool lone_enabled() {
+  const char* e = getenv("SMI_LONE");
+  return !(e && e[0] == '0');
+}
+struct LoneUnit {
+  int bm, bn;
+};
+// The smallest unit shape whose units fit the chip in ONE round ({0, 0}: none does -- not a lone-tile launch).  Smaller
+// units = more CUs streaming operands, fewer bytes and MFMAs per unit; past one round the two-stage loop with two
+// workgroups per CU takes over.
+static LoneUnit lone_shape(int M, int N, int ksplit, bool wide_only) {
+  const int64_t cus = num_cus();
+  if ((int64_t)(M / 128) * (N / 128) * ksplit > cus) return {0, 0};
+  if (const char* e = getenv("SMI_LONE_SHAPE")) {
+    if (!wide_only && !strcmp(e, "64x64")) return {64, 64};
+    if (!wide_only && !strcmp(e, "128x64")) return {128, 64};
+    if (!strcmp(e, "128x128")) return {128, 128};
+  }
+  if (!wide_only && (int64_t)(M / 64) * (N / 64) * ksplit <= cus) return {64, 64};
+  if (!wide_only && (int64_t)(M / 128) * (N / 64) * ksplit <= cus) return {128, 64};
+  return {128, 128};
 }
 
 template <int EPI, int LAYOUT, int RING>
@@ -923,13 +1030,38 @@ static hipError_t launch_one_ring(const f16* X, const f16* W, const float* bias,
   return hipGetLastError();
 }
 
+template <int EPI, int LAYOUT, int BM, int BN>
+static hipError_t launch_lone(const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ldo,
+                              hipStream_t stream, int ksplit, size_t part_stride) {
+  constexpr int lds = LoneShape<BM, BN>::LDS_BYTES;
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_lone_kernel<EPI, LAYOUT, BM, BN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done.set();
+  }
+  const int grid = (M / BM) * (N / BN);
+  hipLaunchKernelGGL((gemm_lone_kernel<EPI, LAYOUT, BM, BN>), dim3(grid, ksplit), dim3(GT_THREADS), lds, stream, X, W,
+                     bias, out, M, N, K, ldo, ksplit, part_stride);
+  return hipGetLastError();
+}
+
 template <int EPI, int LAYOUT = 0>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
-  // every workgroup gets a CU of its own: hide the DMA latency with a deeper ring instead of a second workgroup
-  const int st = (M / GT_BM) * (N / GT_BN) * ksplit <= num_cus() ? gt_ring_stages() : 0;
-  if (st == 4) return launch_one_ring<EPI, LAYOUT, 4>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
-  if (st == 3) return launch_one_ring<EPI, LAYOUT, 3>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  // every workgroup gets a CU of its own: a unit shape that spreads the launch over the chip and a loop that hides
+  // the DMA latency behind a deep ring instead of a second workgroup
+  const LoneUnit u = lone_shape(M, N, ksplit, EPI == EPI_GLU_F16);
+  if (u.bm && lone_enabled()) {
+    if constexpr (EPI != EPI_GLU_F16) {
+      if (u.bm == 64) return launch_lone<EPI, LAYOUT, 64, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+      if (u.bn == 64) return launch_lone<EPI, LAYOUT, 128, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+    }
+    return launch_lone<EPI, LAYOUT, 128, 128>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  }
+  if (u.bm && gt_ring_stages() == 4)
+    return launch_one_ring<EPI, LAYOUT, 4>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
   return launch_one_ring<EPI, LAYOUT, 0>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
 }
 
@@ -1047,6 +1179,29 @@ int gemm_splitk_parts(int M, int N, int K, int max_parts) {
     const int tiles = (M / G2_BM) * (N / G2_BN);
     const int ks = std::min(std::min(max_parts, num_cus() / std::max(tiles, 1)), (K / G2_BK) / 16);
     if (ks >= 1 && tiles * ks >= 96) return ks;
+  }
+  if (lone_enabled()) {
+    // lone-tile units: the part count with the cheapest launch by a two-term model -- K tiles per unit x the time of one
+    // K tile of the smallest unit shape that still fits the chip in one round (0.2 / 0.3 / 0.4 us for 64x64 / 128x64 /
+    // 128x128), plus the slab traffic every part adds (written here, read by the consumer: 8 bytes per output element
+    // at ~5 TB/s); a unit keeps at least 4 K tiles.  SMI_LONE_KS overrides (A/B runs).
+    if (const char* e = getenv("SMI_LONE_KS")) {
+      const int v = atoi(e);
+      if (v >= 1 && v <= max_parts && K % (GT_BK * v) == 0 && lone_shape(M, N, v, false).bm) return v;
+    }
+    int best = 1;
+    double best_cost = 1e30;
+    for (int ks = 1; ks <= max_parts; ks *= 2) {
+      if (K % (GT_BK * ks) || (ks > 1 && K / ks < 4 * GT_BK)) break;
+      const LoneUnit u = lone_shape(M, N, ks, false);
+      if (!u.bm) break;
+      const double cost = (double)(K / ks / GT_BK) * (u.bm + u.bn) / 640.0 + ks * ((double)M * N * 8.0 / 5e6);
+      if (cost < best_cost) {
+        best_cost = cost;
+        best = ks;
+      }
+    }
+    return best;
   }
   const int tiles = (M / GT_BM) * (N / GT_BN);
   int ks = 1;

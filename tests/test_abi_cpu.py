@@ -40,9 +40,10 @@ def test_version_and_helpers(lib):
     assert b"gfx950" in lib.smi_version()
     assert lib.smi_xsim_padded_rows(1) == 256 and lib.smi_xsim_padded_rows(256) == 256 and lib.smi_xsim_padded_rows(257) == 512
     assert lib.smi_xsim_workspace_bytes(0, 5, 1, 1024) == 0
-    # 8 chunks of partial lists + (k <= 4) the tile-major copies of both padded matrices
+    # 8 chunks of partial lists + the tile-major copies of both padded matrices (every k runs on the 256x256 engine since
+    # the per-row lists moved to LDS, r04 experiment 2)
     assert lib.smi_xsim_workspace_bytes(1000, 100000, 4, 1024) == 8 * 1024 * 4 * 8 + (1024 + 100096) * 1024 * 2
-    assert lib.smi_xsim_workspace_bytes(1000, 100000, 8, 1024) == 8 * 1024 * 8 * 8
+    assert lib.smi_xsim_workspace_bytes(1000, 100000, 8, 1024) == 8 * 1024 * 8 * 8 + (1024 + 100096) * 1024 * 2
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")

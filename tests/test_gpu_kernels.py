@@ -115,6 +115,67 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
+@pytest.mark.parametrize("shape", ["64x64", "128x64", "128x128"])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (256, 1024, 1024), (512, 2560, 128), (1024, 3072, 192),
+                                   (256, 256, 4096)])
+def test_gemm_lone_unit_shapes(lib, monkeypatch, shape, m, n, k):
+    """The lone-tile engine (gemm_lone.hpp): every unit shape, K loops shorter / equal / longer than the ring (1, 2, 3, 16,
+    64 K tiles), row-major and tile-major operands, the fp16 / fp32 / read-modify-write epilogues -- against fp32 torch and
+    BIT-identical to round 3's ring (same MFMA order over K)."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + n * 3 + k * 7)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    ref = x.float() @ w.float().T + bias
+    resid32 = torch.randn(m, n, device="cuda", generator=g)
+    resid16 = resid32.half()
+    tm_ok = m % 256 == 0 and n % 256 == 0
+    xt, wt = (to_tile_major(x), to_tile_major(w)) if tm_ok else (None, None)
+
+    def run(epi, tm, out_tm):
+        if epi == 2:
+            out = resid32.clone()
+        elif epi == 8:
+            out = to_tile_major(resid16) if out_tm else resid16.clone()
+        elif epi == 3:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float32)
+        elif epi == 6:
+            out = torch.full((m, n // 2), float("nan"), device="cuda", dtype=torch.float16)
+        else:
+            out = torch.full((m, n), float("nan"), device="cuda", dtype=torch.float16)
+        flags = (_lib.SMI_GEMM_IN_TM if tm else 0) | (_lib.SMI_GEMM_OUT_TM if out_tm else 0)
+        a, b = (xt, wt) if tm else (x, w)
+        _lib.check(lib.smi_gemm_tn(epi | (1 << 8) | flags, a.data_ptr(), b.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                   m, n, k, n // 2 if epi == 6 else n, _stream()))
+        torch.cuda.synchronize()
+        return from_tile_major(out.view(-1), m, n) if out_tm else out
+
+    cases = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (3, 0, 0), (6, 0, 0), (8, 0, 0)]
+    if tm_ok:
+        cases += [(0, 1, 1), (1, 1, 1), (3, 1, 0), (8, 1, 1), (6, 1, 0)]
+    for epi, tm, out_tm in cases:
+        monkeypatch.setenv("SMI_LONE", "1")
+        monkeypatch.setenv("SMI_LONE_SHAPE", shape)
+        got = run(epi, tm, out_tm)
+        monkeypatch.setenv("SMI_LONE", "0")
+        old = run(epi, tm, out_tm)
+        assert torch.equal(got, old), (epi, tm, out_tm)
+        if epi == 2:
+            want = resid32 + ref
+        elif epi == 8:
+            want = resid16.float() + ref
+        elif epi == 6:
+            r4 = ref.view(m, n // 64, 2, 32)
+            want = (r4[:, :, 0] * torch.sigmoid(r4[:, :, 1])).reshape(m, n // 2)
+        else:
+            want = torch.relu(ref) if epi == 1 else ref
+        err = (got.float() - want).abs().max().item()
+        scale = max(want.abs().max().item(), 1.0)
+        assert err <= (2e-3 if epi in (0, 1, 6, 8) else 2e-5) * scale, (epi, tm, out_tm, err, scale)
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 256), (384, 1024, 1024), (128, 256, 8192),
                                    (256, 256, 64), (256, 256, 128), (256, 512, 192), (512, 1024, 1024),
                                    (256, 256, 8192), (1024, 768, 256)])
