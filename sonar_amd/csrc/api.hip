@@ -484,13 +484,14 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     ProfScope ps(e, SMI_PROF_LAYERNORM, stream);  // the first LayerNorm's statistics have no producing GEMM
     HIP_TRY(launch_row_stats_tm((const f16*)x, e->rowpart.as<float2>(), M, d, nparts, stream));
   }
+  const bool pf_on = true;  // weight prefetch by the row kernels' surplus workgroups (SMI_PREFETCH=0 disables it: A/B runs)
   for (int l = 0; l < c.num_layers && sb; ++l) {  // small batches: the decoder-shaped layer (see above)
     Layer& L = e->layers[l];
     float* parts = e->parts.as<float>();
     const size_t ps = (size_t)M * d;
     { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += FFN-output slabs of the previous layer; h = LN1(x)
     HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ffn2_ks, ps, nullptr, 1, L.ln1_w.as<float>(), L.ln1_b.as<float>(),
-                                 c.ln_eps, h, M, d, stream, tm, x16)); }
+                                 c.ln_eps, h, M, d, stream, tm, x16, pf_on ? L.w_1.p : nullptr, (size_t)f * d * 2)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d, 3 * d, stream)); }
     { ProfScope ps_(e, SMI_PROF_ATTENTION, stream);
@@ -499,7 +500,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, M, d, d, out_ks, stream, tm)); }
     { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += attention-output slabs; h = LN2(x)
     HIP_TRY(launch_sum_layernorm(x, parts, out_ks, ps, nullptr, 1, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d,
-                                 stream, tm, x16)); }
+                                 stream, tm, x16, pf_on ? L.w_2.p : nullptr, (size_t)f * d * 2)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_FFN1, stream);
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_FFN2, stream);

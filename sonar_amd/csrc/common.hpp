@@ -119,6 +119,35 @@ __device__ __forceinline__ float max_over_groups_of_8(float v) {
 }
 #endif
 
+// WEIGHT PREFETCH by surplus workgroups (round 4).  A small-batch forward is a chain of latency-bound launches that
+// leaves HBM idle most of the time, and then streams a layer's 16.8 MB FFN matrices cold: 18.2 us for the FFN-inner
+// projection at M = 256 against 14.0 us when the matrix was read just before (tools/probe_cold_weights.py).  A row
+// kernel that occupies a quarter of the CUs therefore carries extra workgroups that simply READ the weights a later
+// GEMM of the layer will ask for: the lines land in the Infinity Cache (memory side, shared by all XCDs).  Workgroup
+// `wg` of `nwg` streams 4-KiB pieces wg, wg + nwg, ... with PF_DEPTH x 16-B loads in flight per thread (a 16.8 MB matrix
+// over 192 workgroups is 22 loads per thread: ONE round trip; with 8 in flight it was three and the host kernel grew by
+// 1.4 us); the xor of the data is stored under a condition that is practically never true so that the loads stay.
+__device__ __forceinline__ void prefetch_range(const void* p, size_t bytes, int wg, int nwg, unsigned* sink) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* q = (const u32x4*)p;
+  const size_t n16 = bytes >> 4;
+  const size_t step = (size_t)nwg * blockDim.x;
+  unsigned acc = 0;
+  constexpr int PF_DEPTH = 24;
+  for (size_t i = (size_t)wg * blockDim.x + threadIdx.x; i < n16; i += step * PF_DEPTH) {
+    u32x4 v[PF_DEPTH];
+#pragma unroll
+    for (int j = 0; j < PF_DEPTH; ++j) {
+      const size_t idx = min(i + j * step, n16 - 1);  // clamped, branch-free: every load is issued before the first use
+      v[j] = q[idx];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < PF_DEPTH; ++j) acc ^= v[j][0] ^ v[j][1] ^ v[j][2] ^ v[j][3];
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;
+}
+
 // XCD-aware block id remap (bijective for any grid size): hardware deals
 // block b to XCD b%8; give every XCD one contiguous range of logical ids so
 // neighbouring tiles share that XCD's private L2.

@@ -20,6 +20,8 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include <type_traits>
+
 #include "kernels.hpp"
 
 namespace smi {
@@ -63,48 +65,89 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 // ---------------------- x += sum_z parts[z] (+ c[row / group]); h = LN(x)  (fused)
 // parts: split-K slabs of the preceding projection GEMM (fp32 [nparts][rows_pad][d]); c: the
 // per-sentence cross-attention constant.  Either may be null.
-template <int NV, typename XT>
+__device__ unsigned g_prefetch_sink;  // never written in practice (common.hpp: prefetch_range)
+
+// NP: the number of slabs when it is one of 0 / 1 / 2 / 4 / 8 (straight-line loads), -1: any number (rounds of ZB).
+template <int NV, typename XT, int NP>
 __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const float* __restrict__ parts,
                                                      int nparts, size_t part_stride,
                                                      const float* __restrict__ c, int group,
                                                      const float* __restrict__ w,
                                                      const float* __restrict__ b, float eps,
-                                                     f16* __restrict__ h, int rows, int h_tm) {
+                                                     f16* __restrict__ h, int rows, int h_tm,
+                                                     const void* __restrict__ pf, size_t pf_bytes, int main_blocks) {
   constexpr int D = NV * 256;
+  if ((int)blockIdx.x >= main_blocks) {  // surplus workgroups: weight prefetch for a later GEMM (common.hpp)
+    prefetch_range(pf, pf_bytes, blockIdx.x - main_blocks, gridDim.x - main_blocks, &g_prefetch_sink);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   XT* xr = x + (size_t)r * D;
-  // The kernel is one dependent chain per wave (loads -> two wave reductions -> store) at ~1 wave per
-  // SIMD, so every load is issued before the first add: x, the constant, then the slabs eight at a time.
+  // The kernel is one dependent chain per wave (loads -> two wave reductions -> store) at ~1 wave per SIMD, so EVERY
+  // load -- the row, the constant, the slabs, the LayerNorm weights -- is issued before the first use of any of them
+  // and without a branch in between: one memory round trip instead of three (round 4: the fp16 -> fp32 conversion
+  // of the row used to sit in front of the slab loads, the slab loads were separated by wave-uniform branches and the
+  // weights were fetched after the reductions; r04 experiment 12).  The constant is read through a pointer that
+  // falls back to a valid address and zeroed by a select.
   // The summation order (x, slabs ascending, constant) is fixed.  XT = f16: the residual stream is fp16 (the text
   // encoder's small-batch path): fp32 adds, ONE rounding when the row is written back; LayerNorm sees the rounded row.
-  f32x4 v[NV], cv[NV];
+  typedef typename std::conditional<sizeof(XT) == 2, half4, f32x4>::type XV;
+  XV xv[NV];
+  f32x4 v[NV], cv[NV], wv[NV], bv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) xv[k] = *(const XV*)(xr + k * 256 + lane * 4);
+  const float* cp = c ? c + (size_t)(r / group) * D + lane * 4 : w + lane * 4;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) cv[k] = *(const f32x4*)(cp + k * 256);
+  const float* pr = parts + (size_t)r * D + lane * 4;
+  constexpr int NPC = NP > 0 ? NP : 1;
+  f32x4 p[NPC][NV];
+  if constexpr (NP > 0) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) p[j][k] = *(const f32x4*)(pr + (size_t)j * part_stride + k * 256);
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    wv[k] = *(const f32x4*)(w + k * 256 + lane * 4);
+    bv[k] = *(const f32x4*)(b + k * 256 + lane * 4);
+  }
+  // the machine scheduler would otherwise interleave loads and adds in a rolling window of two or three loads in flight
+  // (it minimises registers: 74 instead of ~200) -- the opposite of what a latency chain wants
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     if constexpr (sizeof(XT) == 2) {
-      const half4 xv = *(const half4*)(xr + k * 256 + lane * 4);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[k][i] = (float)xv[i];
+      for (int i = 0; i < 4; ++i) v[k][i] = (float)xv[k][i];
     } else {
-      v[k] = *(const f32x4*)(xr + k * 256 + lane * 4);
+      v[k] = xv[k];
     }
-    cv[k] = c ? *(const f32x4*)(c + (size_t)(r / group) * D + k * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!c) cv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* pr = parts + (size_t)r * D + lane * 4;
-  constexpr int ZB = NV <= 4 ? 8 : 4;  // slabs per round trip (register budget: ZB * NV f32x4)
-  for (int z0 = 0; z0 < nparts; z0 += ZB) {
-    f32x4 p[ZB][NV];
+  if constexpr (NP > 0) {
 #pragma unroll
-    for (int j = 0; j < ZB; ++j)
-#pragma unroll
-      for (int k = 0; k < NV; ++k)
-        p[j][k] = z0 + j < nparts ? *(const f32x4*)(pr + (size_t)(z0 + j) * part_stride + k * 256)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < ZB; ++j)
+    for (int j = 0; j < NP; ++j)
 #pragma unroll
       for (int k = 0; k < NV; ++k) v[k] += p[j][k];
+  } else if constexpr (NP < 0) {
+    constexpr int ZB = NV <= 4 ? 8 : 4;  // slabs per round trip (register budget: ZB * NV f32x4)
+    for (int z0 = 0; z0 < nparts; z0 += ZB) {
+      f32x4 q[ZB][NV];
+#pragma unroll
+      for (int j = 0; j < ZB; ++j)
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+          q[j][k] = z0 + j < nparts ? *(const f32x4*)(pr + (size_t)(z0 + j) * part_stride + k * 256)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < ZB; ++j)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] += q[j][k];
+    }
   }
   float s = 0.f;
 #pragma unroll
@@ -137,11 +180,9 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
   const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const f32x4 wv = *(const f32x4*)(w + k * 256 + lane * 4);
-    const f32x4 bv = *(const f32x4*)(b + k * 256 + lane * 4);
     half4 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (f16)(v[k][i] * rstd * wv[i] + bv[i]);
+    for (int i = 0; i < 4; ++i) o[i] = (f16)(v[k][i] * rstd * wv[k][i] + bv[k][i]);
     if (h_tm)  // tile-major GEMM operand (common.hpp): the FFN inner projection's X
       *(half4*)(h + tm_offset(r, k * 256 + lane * 4, D)) = o;
     else
@@ -149,19 +190,58 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
   }
 }
 
+template <int NV, typename XT>
+static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const float* parts, int nparts, size_t part_stride,
+                             const float* c, int group, const float* w, const float* b, float eps, f16* h, int rows,
+                             int h_tm, const void* pf, size_t pf_bytes) {
+  // surplus workgroups for the weight prefetch: one per CU the row work leaves idle
+  int cus = 256;
+  {
+    int dev = 0;
+    static int cached[64];
+    (void)hipGetDevice(&dev);
+    if (!cached[dev & 63] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      cached[dev & 63] = cus;
+    if (cached[dev & 63]) cus = cached[dev & 63];
+  }
+  // ... when the row work takes at most a quarter of the chip (<= 256 rows: the surplus then streams a 16.8 MB matrix in
+  // one round trip; at 512 rows the prefetch cost more than it saved)
+  static const bool pf_env = [] { const char* v = getenv("SMI_PREFETCH"); return !(v && v[0] == '0'); }();
+  const int extra = pf_env && pf && pf_bytes && blocks * 4 <= cus ? cus - blocks : 0;
+  const int main_blocks = blocks;
+#define SMI_SL(NP)                                                                                                     \
+  hipLaunchKernelGGL((sum_ln_kernel<NV, XT, NP>), dim3(blocks + extra), dim3(256), 0, stream, x, parts, nparts,        \
+                     part_stride, c, group, w, b, eps, h, rows, h_tm, pf, pf_bytes, main_blocks)
+  switch (nparts) {
+    case 0: SMI_SL(0); break;
+    case 1: SMI_SL(1); break;
+    case 2: SMI_SL(2); break;
+    case 4: SMI_SL(4); break;
+    case 8:
+      if constexpr (NV <= 4) {
+        SMI_SL(8);
+        break;
+      }
+      [[fallthrough]];
+    default: SMI_SL(-1); break;
+  }
+#undef SMI_SL
+}
+
 hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
-                                f16* h, int rows, int d, hipStream_t stream, int h_tm, int x_f16) {
+                                f16* h, int rows, int d, hipStream_t stream, int h_tm, int x_f16, const void* pf,
+                                size_t pf_bytes) {
   const int blocks = (rows + 3) / 4;
   if (!parts) nparts = 0;
-#define SMI_AL_CASE(NV)                                                                                     \
-  case NV * 256:                                                                                            \
-    if (x_f16)                                                                                              \
-      hipLaunchKernelGGL((sum_ln_kernel<NV, f16>), dim3(blocks), dim3(256), 0, stream, (f16*)x, parts, nparts, \
-                         part_stride, c, group, w, b, eps, h, rows, h_tm);                                  \
-    else                                                                                                    \
-      hipLaunchKernelGGL((sum_ln_kernel<NV, float>), dim3(blocks), dim3(256), 0, stream, (float*)x, parts,  \
-                         nparts, part_stride, c, group, w, b, eps, h, rows, h_tm);                          \
+#define SMI_AL_CASE(NV)                                                                                              \
+  case NV * 256:                                                                                                     \
+    if (x_f16)                                                                                                       \
+      launch_sum_ln_np<NV, f16>(blocks, stream, (f16*)x, parts, nparts, part_stride, c, group, w, b, eps, h, rows, h_tm, \
+                                pf, pf_bytes);                                                                       \
+    else                                                                                                             \
+      launch_sum_ln_np<NV, float>(blocks, stream, (float*)x, parts, nparts, part_stride, c, group, w, b, eps, h, rows, \
+                                  h_tm, pf, pf_bytes);                                                               \
     break;
   switch (d) {
     SMI_AL_CASE(1)

@@ -222,8 +222,9 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
     DecLayer& L = D->layers[l];
     f16* kvl = S.kv.as<f16>() + (size_t)l * P * slab;
     // x += FFN-out slabs of the previous layer (split-K), then LN1
+    // (small batches: the CUs the row kernels leave idle read the layer's FFN matrices ahead, common.hpp: prefetch_range)
     HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ks_ffn, part_stride, nullptr, 1, L.ln1_w.as<float>(),
-                                 L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream));
+                                 L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, 0, 0, L.w_1.p, (size_t)f * d * 2));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
                            rows_pad, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
@@ -237,7 +238,7 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
     const int tm = D->ffn_tile_major;
     HIP_TRY(launch_sum_layernorm(x, ks_out == 1 ? nullptr : parts, ks_out, part_stride,
                                  S.cc.as<float>() + (size_t)l * n_pad * d, group, L.ln3_w.as<float>(), L.ln3_b.as<float>(),
-                                 c.ln_eps, h, rows, d, stream, tm));
+                                 c.ln_eps, h, rows, d, stream, tm, 0, L.w_2.p, (size_t)f * d * 2));
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | (tm ? GEMM_IN_TM | GEMM_OUT_TM : 0) | (ffn1_engine << 8), h, L.w_1.as<f16>(),
                            L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
     HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm));

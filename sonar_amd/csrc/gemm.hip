@@ -220,10 +220,10 @@ __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const
   gt_epilogue<EPI, LAYOUT, 2, 2>(acc.v, b, out, m0 + wm * 64 + (lane & 31), col0, n0 / 2 + wn * 32 + 4 * hi, N, ldo);
 }
 
-// The lone-tile engine (gemm_lone.hpp): unit shape BM x BN, one workgroup per CU, fragments of the next K tile read
-// under the MFMAs of the current one.  Same arguments and epilogues as gemm_tn_kernel (EPI_GLU_F16: BN = 128 only).
+// The lone-tile engine (gemm_lone.hpp): unit shape BM x BN (64x64 is the one the launcher uses).  Same arguments and
+// epilogues as gemm_tn_kernel (EPI_GLU_F16: BN = 128 only).
 template <int EPI, int LAYOUT, int BM, int BN>
-__global__ __launch_bounds__(GT_THREADS, 1) void gemm_lone_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+__global__ __launch_bounds__(GT_THREADS, (LoneShape<BM, BN>::WG_PER_CU)) void gemm_lone_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
                                                                   const float* __restrict__ bias, void* __restrict__ out,
                                                                   int M, int N, int K, int ldo, int ksplit,
                                                                   size_t part_stride) {
@@ -988,29 +988,22 @@ static int gt_ring_stages() {
   return st;
 }
 
-// SMI_LONE: 0 = round 3's ring for lone-tile launches, otherwise the lone-tile engine (gemm_lone.hpp); SMI_LONE_SHAPE =
-// 128x128 | 128x64 | 64x64 pins the unit shape (A/B runs; read per launch: decode-time paths switch it per call)
+// SMI_LONE: 0 = round 3's ring for every lone-tile launch (A/B runs; read per launch: decode-time paths switch it per
+// call), otherwise 64x64 units of the lone-tile engine (gemm_lone.hpp) when a launch is small enough for them.
 static bool lone_enabled() {
   const char* e = getenv("SMI_LONE");
   return !(e && e[0] == '0');
 }
-struct LoneUnit {
-  int bm, bn;
-};
-// The smallest unit shape whose units fit the chip in ONE round ({0, 0}: none does -- not a lone-tile launch).  Smaller
-// units = more CUs streaming operands, fewer bytes and MFMAs per unit; past one round the two-stage loop with two
-// workgroups per CU takes over.
-static LoneUnit lone_shape(int M, int N, int ksplit, bool wide_only) {
-  const int64_t cus = num_cus();
-  if ((int64_t)(M / 128) * (N / 128) * ksplit > cus) return {0, 0};
-  if (const char* e = getenv("SMI_LONE_SHAPE")) {
-    if (!wide_only && !strcmp(e, "64x64")) return {64, 64};
-    if (!wide_only && !strcmp(e, "128x64")) return {128, 64};
-    if (!strcmp(e, "128x128")) return {128, 128};
-  }
-  if (!wide_only && (int64_t)(M / 64) * (N / 64) * ksplit <= cus) return {64, 64};
-  if (!wide_only && (int64_t)(M / 128) * (N / 64) * ksplit <= cus) return {128, 64};
-  return {128, 128};
+// 64x64 units, two workgroups per CU (64 KiB of LDS each): used while all units are resident at once.  Measured
+// (profiles/r04_experiments.txt, experiment 11): at M = 256 / 512 every projection of the encoder is 25-35 % faster than on
+// 128x128 tiles (more CUs stream operands, a unit has a quarter of the MFMAs and half the LDS traffic); past ~2 units
+// per CU (M = 1280 x N = 3072: 960 units) the 128x128 ring wins again -- a 64x64 unit moves twice the operand bytes per
+// flop through L2.
+static bool lone_fits(int M, int N, int ksplit) {
+  return (int64_t)(M / 64) * (N / 64) * ksplit <= 2 * (int64_t)num_cus();
+}
+static bool ring_fits(int M, int N, int ksplit) {
+  return (int64_t)(M / GT_BM) * (N / GT_BN) * ksplit <= num_cus();
 }
 
 template <int EPI, int LAYOUT, int RING>
@@ -1050,17 +1043,11 @@ static hipError_t launch_lone(const f16* X, const f16* W, const float* bias, voi
 template <int EPI, int LAYOUT = 0>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
-  // every workgroup gets a CU of its own: a unit shape that spreads the launch over the chip and a loop that hides
-  // the DMA latency behind a deep ring instead of a second workgroup
-  const LoneUnit u = lone_shape(M, N, ksplit, EPI == EPI_GLU_F16);
-  if (u.bm && lone_enabled()) {
-    if constexpr (EPI != EPI_GLU_F16) {
-      if (u.bm == 64) return launch_lone<EPI, LAYOUT, 64, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
-      if (u.bn == 64) return launch_lone<EPI, LAYOUT, 128, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
-    }
-    return launch_lone<EPI, LAYOUT, 128, 128>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
-  }
-  if (u.bm && gt_ring_stages() == 4)
+  if constexpr (EPI != EPI_GLU_F16)  // GLU pairs two 32-column blocks of a wave: 128-column tiles only
+    if (lone_enabled() && lone_fits(M, N, ksplit))
+      return launch_lone<EPI, LAYOUT, 64, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  // every workgroup gets a CU of its own: hide the DMA latency with a deeper ring instead of a second workgroup
+  if (ring_fits(M, N, ksplit) && gt_ring_stages() == 4)
     return launch_one_ring<EPI, LAYOUT, 4>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
   return launch_one_ring<EPI, LAYOUT, 0>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
 }
@@ -1181,21 +1168,27 @@ int gemm_splitk_parts(int M, int N, int K, int max_parts) {
     if (ks >= 1 && tiles * ks >= 96) return ks;
   }
   if (lone_enabled()) {
-    // lone-tile units: the part count with the cheapest launch by a two-term model -- K tiles per unit x the time of one
-    // K tile of the smallest unit shape that still fits the chip in one round (0.2 / 0.3 / 0.4 us for 64x64 / 128x64 /
-    // 128x128), plus the slab traffic every part adds (written here, read by the consumer: 8 bytes per output element
-    // at ~5 TB/s); a unit keeps at least 4 K tiles.  SMI_LONE_KS overrides (A/B runs).
+    // Lone-tile units: the part count with the cheapest launch by a two-term model -- K tiles per unit x the time of one
+    // K tile (measured: 0.15 us for a 64x64 unit with a CU of its own, 0.25 us with two per CU, 0.41 us for a 128x128
+    // ring unit), plus what every part adds around the launch (its slab is written here and read by the consumer:
+    // 8 bytes per output element at ~20 TB/s, it is L2 / Infinity-Cache traffic); a unit keeps at least 4 K tiles.
+    // SMI_LONE_KS overrides (A/B runs).
     if (const char* e = getenv("SMI_LONE_KS")) {
       const int v = atoi(e);
-      if (v >= 1 && v <= max_parts && K % (GT_BK * v) == 0 && lone_shape(M, N, v, false).bm) return v;
+      if (v >= 1 && v <= max_parts && K % (GT_BK * v) == 0 && (lone_fits(M, N, v) || ring_fits(M, N, v))) return v;
     }
     int best = 1;
     double best_cost = 1e30;
     for (int ks = 1; ks <= max_parts; ks *= 2) {
       if (K % (GT_BK * ks) || (ks > 1 && K / ks < 4 * GT_BK)) break;
-      const LoneUnit u = lone_shape(M, N, ks, false);
-      if (!u.bm) break;
-      const double cost = (double)(K / ks / GT_BK) * (u.bm + u.bn) / 640.0 + ks * ((double)M * N * 8.0 / 5e6);
+      double t_tile;
+      if (lone_fits(M, N, ks))
+        t_tile = (int64_t)(M / 64) * (N / 64) * ks <= num_cus() ? 0.15 : 0.25;
+      else if (ring_fits(M, N, ks))
+        t_tile = 0.41;
+      else
+        break;
+      const double cost = (K / ks / GT_BK) * t_tile + ks * ((double)M * N * 8.0 / 20e6);
       if (cost < best_cost) {
         best_cost = cost;
         best = ks;

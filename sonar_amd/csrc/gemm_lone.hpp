@@ -1,19 +1,23 @@
-// LONE-TILE engine (round 4): GEMM units for launches whose units all fit on the chip at once -- the encoder at small
-// batches (the reference's default predict(batch_size=5): 190-222 tokens = ONE 256-row panel), the decoder's
-// M = beam x batch projections, the poolers.  Such a launch is a chain of fixed costs plus ONE unit's K loop, so the
-// unit has to be (a) small enough that the launch spreads over all 256 CUs and (b) a loop in which nothing waits
-// for anything that could have been requested earlier.
+// LONE-TILE engine (round 4): GEMM units for launches whose units are all resident on the chip at once -- the encoder at
+// small batches (the reference's default predict(batch_size=5): 190-222 tokens = ONE 256-row panel), the decoder's
+// narrow projections, the poolers.  Such a launch is a chain of fixed costs (~6 us: launch gap, ramp, the first operand
+// latency, epilogue, drain) plus ONE unit's K loop, and the K loop scales with the operand bytes a unit pulls through
+// its CU (measured 0.15 / 0.34 / 0.41 us per K tile for 64x64 / 128x64 / 128x128 units: fragment reads + DMA writes
+// are 3x the stage bytes of LDS traffic), neither with the ring depth nor with how reads and MFMAs overlap.  What
+// shortens it is a SMALLER unit on MORE CUs:
 //
-//  * unit shapes BM x BN = 128x128, 128x64, 64x64 over K tiles of 64 (the 128x128x64 LDS image and bank swizzle of
-//    gemm_tile.hpp: 128-B rows, 16-B chunk c of row r at slot c ^ ((r>>1)&7), v_mfma_f32_32x32x16_f16, W = MFMA A
-//    operand, X = B operand); 4 waves as 2(m) x 2(n), wave tile BM/2 x BN/2.  The launcher picks the smallest
-//    shape whose units still fit the chip in one round (gemm.hip: lone_shape): at M = 256 the FFN projections become
-//    256 units of 128x64 instead of 128 of 128x128, the fused QKV projection 192 units of 64x64 instead of 48.
-//  * the ring holds ST stages (160 / 144 / 128 KiB: ONE workgroup per CU) and a stage's slot is handed back to the
-//    DMA as soon as its fragments are in REGISTERS: the fragments of stage t+1 are read while the MFMAs of stage t
-//    run (two fragment sets, the loop is unrolled by two), so a wave's LDS reads, its DMA issue and its MFMAs
-//    overlap although there is only one wave per SIMD -- the ring of gemm_tile.hpp ran them back to back
-//    (read 16 fragments, barrier, 16 MFMAs: 0.52 us per K tile measured, half of it LDS time, half MFMA time).
+//  * unit shape BM x BN over K tiles of 64 (the LDS image and bank swizzle of gemm_tile.hpp: 128-B rows, 16-B chunk c
+//    of row r at slot c ^ ((r>>1)&7), v_mfma_f32_32x32x16_f16, W = MFMA A operand, X = B operand); 4 waves as
+//    2(m) x 2(n), wave tile BM/2 x BN/2.  The launcher uses 64x64 (gemm.hip: lone_fits): at M = 256 the fused QKV
+//    projection becomes 192 units instead of 48, the FFN projections 512 instead of 128, each with a quarter of the
+//    MFMAs and half the LDS bytes of a 128x128 unit.
+//  * a ring of 4 stages = 64 KiB for 64x64, so TWO workgroups share a CU when a launch has more units than CUs.  Deeper
+//    rings were measured and lost (8 stages: +0.4 us per launch; every stage of the fill is issued before the first
+//    wait), and so did larger units (r04 experiment 11).
+//  * a stage's slot goes back to the DMA as soon as its fragments are in REGISTERS: the fragments of stage t+1 are read
+//    while the MFMAs of stage t run (two fragment sets, the loop is unrolled by two).  Measured neutral against
+//    retiring the reads first (MFMA issue is asynchronous, so the ring of gemm_tile.hpp overlapped them already); kept
+//    because it frees a slot one step earlier.
 //
 // One interval (step t), all four waves in the same phase:
 //     ds_read fragments of stage t+1 -> set B | DMA of stage t+ST into slot t%ST | MFMAs of stage t from set A |
@@ -35,8 +39,13 @@ struct LoneShape {
   static constexpr int MI = BM / 64, NI = BN / 64;             // 32-row MFMA blocks of a wave along m / n
   static constexpr int STAGE_BYTES = (BM + BN) * GT_BK * 2;    // X rows, then W rows, 128 B each
   static constexpr int CPW = (BM + BN) / 32;                   // 1-KiB DMA pieces per wave and stage
-  static constexpr int STAGES = BM + BN == 256 ? 5 : BM + BN == 192 ? 6 : 8;  // 160 / 144 / 128 KiB
-  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+#ifdef SMI_LONE_ST  // probe builds: another ring depth
+  static constexpr int STAGES = SMI_LONE_ST;
+#else
+  static constexpr int STAGES = 4;
+#endif
+  static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;       // 64 KiB for 64x64
+  static constexpr int WG_PER_CU = 160 * 1024 / LDS_BYTES >= 2 ? 2 : 1;
 };
 
 template <int N>
@@ -175,6 +184,10 @@ __device__ __forceinline__ void lone_mainloop(f32x16 (&acc)[NI][MI], const f16* 
   auto step = [&](int t, const LoneFrag<BM, BN>& cur, LoneFrag<BM, BN>& nxt) {
     if (t + 1 < nt) read_frags(t + 1, nxt);
     if (t + ST < nt) issue(t + ST);
+#ifdef SMI_LONE_SERIAL  // probe build: fragment reads retired BEFORE the MFMAs (no overlap inside a wave)
+    if (t + 2 < nt) lone_wait_stages<CPW>(min(nt - 1, t + ST) - (t + 2));
+    lone_retire(nxt);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -184,8 +197,10 @@ __device__ __forceinline__ void lone_mainloop(f32x16 (&acc)[NI][MI], const f16* 
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.w[ks][ni], cur.x[ks][mi], acc[ni][mi], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef SMI_LONE_SERIAL
     if (t + 2 < nt) lone_wait_stages<CPW>(min(nt - 1, t + ST) - (t + 2));
     lone_retire(nxt);
+#endif
   };
   int t = 0;
   for (; t + 1 < nt; t += 2) {

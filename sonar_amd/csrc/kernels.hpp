@@ -166,9 +166,11 @@ hipError_t launch_margin_select(const float* fwd_scores, const int32_t* fwd_idx,
 hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* pe_row, float scale,
                             float* x, int rows, int d, int64_t vocab, hipStream_t stream);
 // x[r] += sum_z parts[z][r] (+ c[r / group] if c); h[r] = LN(x[r])   (parts/c may be null)
+// pf / pf_bytes: weights of a later GEMM that the CUs the row work leaves idle read ahead (common.hpp: prefetch_range)
 hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
-                                f16* h, int rows, int d, hipStream_t stream, int h_tm = 0, int x_f16 = 0);
+                                f16* h, int rows, int d, hipStream_t stream, int h_tm = 0, int x_f16 = 0,
+                                const void* pf = nullptr, size_t pf_bytes = 0);
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream);
 constexpr int kVocabScanK2Max = 16;

@@ -115,13 +115,13 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
-@pytest.mark.parametrize("shape", ["64x64", "128x64", "128x128"])
-@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (256, 1024, 1024), (512, 2560, 128), (1024, 3072, 192),
-                                   (256, 256, 4096)])
-def test_gemm_lone_unit_shapes(lib, monkeypatch, shape, m, n, k):
-    """The lone-tile engine (gemm_lone.hpp): every unit shape, K loops shorter / equal / longer than the ring (1, 2, 3, 16,
-    64 K tiles), row-major and tile-major operands, the fp16 / fp32 / read-modify-write epilogues -- against fp32 torch and
-    BIT-identical to round 3's ring (same MFMA order over K)."""
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (256, 1024, 1024), (512, 2560, 128), (512, 4096, 256),
+                                   (1024, 3072, 192), (256, 256, 4096)])
+def test_gemm_lone_units(lib, monkeypatch, m, n, k):
+    """The lone-tile engine (gemm_lone.hpp, 64x64 units): K loops shorter / equal / longer than the ring (1, 2, 3, 4, 16,
+    64 K tiles), one and two workgroups per CU (4 ... 512 units; 768 units: back on the 128x128 ring), row-major and
+    tile-major operands, the fp16 / fp32 / read-modify-write epilogues -- against fp32 torch and BIT-identical to
+    round 3's ring (same MFMA order over K)."""
     from sonar_amd import _lib
 
     g = torch.Generator(device="cuda").manual_seed(m + n * 3 + k * 7)
@@ -157,7 +157,6 @@ def test_gemm_lone_unit_shapes(lib, monkeypatch, shape, m, n, k):
         cases += [(0, 1, 1), (1, 1, 1), (3, 1, 0), (8, 1, 1), (6, 1, 0)]
     for epi, tm, out_tm in cases:
         monkeypatch.setenv("SMI_LONE", "1")
-        monkeypatch.setenv("SMI_LONE_SHAPE", shape)
         got = run(epi, tm, out_tm)
         monkeypatch.setenv("SMI_LONE", "0")
         old = run(epi, tm, out_tm)

@@ -1,6 +1,6 @@
 """Lone-tile GEMM probe: the projections of a small encoder batch (M = 256: predict(batch_size=5)) and of a decode step
 (M = 1280) through smi_gemm_tn with the 128x128-family engines -- round 3's ring (SMI_LONE=0) against the lone-tile engine
-(gemm_lone.hpp) with the automatic and each pinned unit shape.  Each timing is a chain of `reps` dependent-stream launches
+(gemm_lone.hpp, 64x64 units while they are all resident).  Each timing is a chain of `reps` dependent-stream launches
 between two HIP events (launch gaps included: that is what a forward pays).
 usage: python tools/bench_lone.py [reps]"""
 import os, sys
@@ -22,10 +22,7 @@ def main():
         ("dec1280 qkv", 1280, 3072, 1024, 0, 0, 0), ("dec1280 out(slab)", 1280, 1024, 1024, 3, 0, 0),
         ("dec256 qkv", 256, 3072, 1024, 0, 0, 0),
     ]
-    variants = [("ring(r3)", {"SMI_LONE": "0"}), ("lone auto", {"SMI_LONE": "1"}),
-                ("lone 128x128", {"SMI_LONE": "1", "SMI_LONE_SHAPE": "128x128"}),
-                ("lone 128x64", {"SMI_LONE": "1", "SMI_LONE_SHAPE": "128x64"}),
-                ("lone 64x64", {"SMI_LONE": "1", "SMI_LONE_SHAPE": "64x64"})]
+    variants = [("ring(r3)", {"SMI_LONE": "0"}), ("lone 64x64 (where it fits)", {"SMI_LONE": "1"})]
     for label, m, n, k, epi, tm, otm in shapes:
         x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
         w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
