@@ -378,6 +378,10 @@ def test_basic_decoder_chains_bit_identical_full_size(basic_decoder, monkeypatch
     kw = dict(beam_size=5, min_gen_len=5, max_gen_len=(0, 6))
     monkeypatch.setenv("SMI_DEC_KS_OUT", "2")
     monkeypatch.setenv("SMI_DEC_FFN1_ENGINE", "2")
+    # the split-K FFN output projection: 2 816 rows are 352 units of the 256x256 engine (more than one round: the 128x128
+    # family takes it), a chain's 1 024 rows are 128 units (the 256x256 engine takes it) -- two MFMA shapes, two fp32
+    # summation orders.  Pin the family for both.
+    monkeypatch.setenv("SMI_G2_SPLITK_MIN", "1000000")
     try:
         eng.set_chains(1)
         one = [t.cpu() for t in eng.generate(emb, [3, 256047], **kw)]
