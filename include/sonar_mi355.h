@@ -285,6 +285,14 @@ int smi_text_decoder_last_margins(smi_text_decoder* dec, float* out_margins, int
  * fp32 summation order of split-K slabs. */
 int smi_text_decoder_set_chains(smi_text_decoder* dec, int32_t chains);
 
+/* Storage type of the logits inside smi_text_decoder_generate (round 4): SMI_F32 (default) or SMI_F16.  The reference's fp16
+ * model produces fp16 logits (the tied final_proj is an fp16 Linear; fairseq2's beam search up-casts them inside
+ * log_softmax, sonar/inference_pipelines/text.py:305-346 -> BeamSearchSeq2SeqGenerator), so SMI_F16 is what an fp16 model's
+ * pipeline selects: the logits GEMM then rounds its fp32 accumulators to fp16 once, takes the softmax statistics of the
+ * ROUNDED values and writes half the bytes (0.66 instead of 1.31 GB per position at 256 sentences x beam 5).
+ * smi_text_decoder_logits and smi_text_decoder_sample keep fp32 logits. */
+int smi_text_decoder_set_beam_logits_dtype(smi_text_decoder* dec, int32_t dtype);
+
 /* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
  * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).
  * Per step: probs = softmax(logits / temperature) in fp32, pad -> 0, EOS -> 0 before min_seq_len,

@@ -261,6 +261,7 @@ SYMBOLS = {
                                             C.POINTER(smi_beam_search_params), _vp, _vp, _vp, _vp]),
     "smi_text_decoder_last_margins": (C.c_int, [_vp, _vp, _i32, _vp]),
     "smi_text_decoder_set_chains": (C.c_int, [_vp, _i32]),
+    "smi_text_decoder_set_beam_logits_dtype": (C.c_int, [_vp, _i32]),
     "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                           C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
     "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp,

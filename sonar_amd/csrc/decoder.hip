@@ -496,7 +496,13 @@ __device__ __forceinline__ void wave_best3(float& bv, int& br, int& bt) {
   }
 }
 
-__global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restrict__ logits, int ldl, int vocab,
+// logits of (row, token): fp32 row-major [rows][ldl], or -- f16_tm -- fp16 in the tile-major layout of common.hpp with K = ldl
+// (what the logits GEMM of an fp16 model stores, round 4)
+__device__ __forceinline__ float logit_at(const float* __restrict__ logits, int ldl, int f16_tm, int row, int tok) {
+  return f16_tm ? (float)((const f16*)logits)[tm_offset(row, tok, ldl)] : logits[(size_t)row * ldl + tok];
+}
+
+__global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restrict__ logits, int ldl, int f16_tm, int vocab,
                                                            const float* __restrict__ tile_max,
                                                            const float* __restrict__ tile_sum, int ntiles,
                                                            int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx, int unk_idx,
@@ -580,14 +586,13 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
   // ---- 2b. thread t owns column t of every selected tile
   unsigned long long ck[VSEL_SLOTS];
   unsigned long long cbest = 0ull;
-  const float* lp = logits + (size_t)row * ldl;
 #pragma unroll
   for (int j = 0; j < VSEL_SLOTS; ++j) {
     ck[j] = 0ull;
     if (j < nsel) {
       const int tok = s_sel[j] * 256 + tid;
       if (tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
-        float v = lp[tok] * inv_temp;
+        float v = logit_at(logits, ldl, f16_tm, row, tok) * inv_temp;
         if (tok == unk_idx) v -= unk_penalty;
         if (v != -INFINITY) ck[j] = cand_key(v, tok);
       }
@@ -620,13 +625,13 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
   }
 }
 
-hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
+hipError_t launch_vocab_select(const float* logits, int ldl, int f16_tm, int rows, int vocab, const float* tile_max,
                                const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream) {
   if (rows <= 0 || stat_rows < rows || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, vocab, tile_max, tile_sum,
+  hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, f16_tm, vocab, tile_max, tile_sum,
                      ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
   return hipGetLastError();
 }
@@ -652,7 +657,7 @@ struct BeamState {
 };
 
 __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const float* __restrict__ logits,
-                                                        int ldl, const float* __restrict__ pmax,
+                                                        int ldl, int f16_tm, const float* __restrict__ pmax,
                                                         const float* __restrict__ psum,
                                                         const float* __restrict__ pval,
                                                         const int* __restrict__ pidx, int nchunks,
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
     // candidate of every live row is one given token
     if (tid < na) {
       const int tk = forced_prompt ? forced_tok : eos_idx;
-      const float lp = logits[(size_t)(base + tid) * ldl + tk] * inv_temp - s_lse[tid];
+      const float lp = logit_at(logits, ldl, f16_tm, base + tid, tk) * inv_temp - s_lse[tid];
       c_val[tid] = st.cum[base + tid] + lp;
       c_tok[tid] = tk;
       c_row[tid] = base + tid;
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamState st, const floa
 hipError_t launch_beam_step(const BeamStepArgs& a, hipStream_t stream) {
   BeamState st{a.tok, a.cum, a.nactive, a.done, a.ndone, a.parent, a.new_tok, a.new_cum,
                a.hist, a.fin_tok, a.fin_len, a.fin_score, a.fin_count, a.margins};
-  hipLaunchKernelGGL(beam_step_kernel, dim3(a.n), dim3(256), 0, stream, st, a.logits, a.ldl, a.pmax,
+  hipLaunchKernelGGL(beam_step_kernel, dim3(a.n), dim3(256), 0, stream, st, a.logits, a.ldl, a.logits_f16_tm, a.pmax,
                      a.psum, a.pval, a.pidx, a.nchunks, a.beam, a.k2, a.pos, a.prompt_len, a.forced_tok,
                      a.max_len, a.inv_temp, a.len_penalty, a.normalize, a.eos_idx, a.hist_stride);
   return hipGetLastError();

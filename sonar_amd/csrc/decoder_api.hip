@@ -74,6 +74,7 @@ struct smi_text_decoder {
   DevBuf margins;       // [n][2] decision margins of the last generate() call
   int margins_n = 0;
   int chains = 0;       // smi_text_decoder_set_chains: 0 = SMI_DEC_CHAINS / the default
+  int beam_logits_f16 = 0;  // smi_text_decoder_set_beam_logits_dtype: the beam search's logits are stored in fp16
   int64_t weight_bytes = 0;
   int ffn_tile_major = 0;  // FFN weights stored tile-major (d, f multiples of 256)
   // Generic-dimension mode (flex.hip): head_dim != 64 or dimensions the MFMA engines do not tile for (the reference's
@@ -183,8 +184,11 @@ int flex_decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, i
 }
 
 // one decoder step at position `pos` for `rows` rows (rows_pad GEMM rows); logits -> S.logits
+// logits_f16 (beam search of an fp16 model, round 4): the logits GEMM stores fp16 in the tile-major layout (the reference's
+// fp16 model produces fp16 logits too: fairseq2 up-casts them inside log_softmax) and takes the tile statistics of the
+// rounded values; needs the tile-major table copy.  Halves the 1.3 GB the 256 x 5-row step wrote per position.
 int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int group, int n_pad, int pos,
-                 const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f) {
+                 const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f, int logits_f16 = 0) {
   if (D->flex) return flex_decoder_step(D, S, rows, rows_pad, group, n_pad, pos, anc, anc_stride, stream, stats_scale);
   const smi_text_decoder_config& c = D->cfg;
   const int d = c.model_dim, f = c.ffn_inner_dim;
@@ -250,9 +254,13 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
   // statistics, so the candidate selection never re-reads the 1 MB logits rows
   GemmTileStats st{S.tile_max.as<float>(), S.tile_sum.as<float>(), stats_scale, (int)c.vocab_size};
   if (S.chained && logits_grid_env > 0) set_gemm_grid_cap(logits_grid_env);
-  const hipError_t le = launch_gemm_tn(EPI_STORE_F32 | (ltm ? GEMM_IN_TM : 0), h, (ltm ? D->embed_tm : D->embed).as<f16>(),
-                                       nullptr, S.logits.p, rows_pad, (int)D->vocab_pad, d, (int)D->vocab_pad, stream,
-                                       stats_scale > 0.f ? &st : nullptr);
+  const hipError_t le =
+      logits_f16 && ltm && stats_scale > 0.f
+          ? launch_gemm_tn(EPI_BIAS_F16 | GEMM_IN_TM | GEMM_OUT_TM, h, D->embed_tm.as<f16>(), nullptr, S.logits.p, rows_pad,
+                           (int)D->vocab_pad, d, (int)D->vocab_pad, stream, &st)
+          : launch_gemm_tn(EPI_STORE_F32 | (ltm ? GEMM_IN_TM : 0), h, (ltm ? D->embed_tm : D->embed).as<f16>(), nullptr,
+                           S.logits.p, rows_pad, (int)D->vocab_pad, d, (int)D->vocab_pad, stream,
+                           stats_scale > 0.f ? &st : nullptr);
   set_gemm_grid_cap(0);
   HIP_TRY(le);
   return SMI_OK;
@@ -381,17 +389,21 @@ int generate_chain(smi_text_decoder* D, DecWork& S, const void* emb, int emb_dty
                            S.hist[0].as<int32_t>(), S.anc[0].as<int32_t>(), margins, rows, n, stride,
                            (int)prompt[0], stream));
   const float inv_temp = 1.0f / bp->temperature;
+  // fp16 logits: the handle's setting (SMI_DEC_LOGITS_F16 = 0 / 1 overrides it: A/B runs), MFMA path with the tile-major table
+  const int lf_env = DecTuning::env_int("SMI_DEC_LOGITS_F16", -1);
+  const int logits_f16 = !D->flex && D->embed_tm.p != nullptr && (lf_env >= 0 ? lf_env != 0 : D->beam_logits_f16 != 0);
 
   // everything one decode step enqueues (position pos; ancestry/history buffer pos & 1)
   auto enqueue_step = [&](int pos, hipStream_t s) -> int {
     const int cur = pos & 1, step_nr = pos + 1;
-    if (int rc = decoder_step(D, S, rows, rows_pad, beam, n_pad, pos, S.anc[cur].as<int32_t>(), stride, s, inv_temp))
+    if (int rc = decoder_step(D, S, rows, rows_pad, beam, n_pad, pos, S.anc[cur].as<int32_t>(), stride, s, inv_temp,
+                              logits_f16))
       return rc;
     const bool forced_prompt = step_nr < prompt_len;
     const bool force_eos = !forced_prompt && step_nr == max_len - 1;
     // forced steps need only the softmax normaliser (the candidate is a given token): k2 = 0
     const bool free_step = !forced_prompt && !force_eos;
-    HIP_TRY(launch_vocab_select(S.logits.as<float>(), (int)D->vocab_pad, rows, (int)c.vocab_size,
+    HIP_TRY(launch_vocab_select(S.logits.as<float>(), (int)D->vocab_pad, logits_f16, rows, (int)c.vocab_size,
                                 S.tile_max.as<float>(), S.tile_sum.as<float>(), ntiles, rows_pad, free_step ? k2 : 0, inv_temp,
                                 c.pad_idx, c.eos_idx, c.unk_idx, free_step ? bp->unk_penalty : 0.f,
                                 free_step && step_nr < min_len ? 1 : 0, S.pmax.as<float>(), S.psum.as<float>(),
@@ -403,7 +415,7 @@ int generate_chain(smi_text_decoder* D, DecWork& S, const void* emb, int emb_dty
     a.hist = S.hist[cur].as<int32_t>(); a.fin_tok = S.fin_tok.as<int32_t>(); a.fin_len = S.fin_len.as<int32_t>();
     a.fin_score = S.fin_score.as<float>(); a.fin_count = S.fin_count.as<int32_t>();
     a.margins = margins;
-    a.logits = S.logits.as<float>(); a.ldl = (int)D->vocab_pad;
+    a.logits = S.logits.as<float>(); a.ldl = (int)D->vocab_pad; a.logits_f16_tm = logits_f16;
     a.pmax = S.pmax.as<float>(); a.psum = S.psum.as<float>(); a.pval = S.pval.as<float>(); a.pidx = S.pidx.as<int>();
     a.nchunks = 1; a.n = n; a.beam = beam; a.k2 = k2; a.pos = pos; a.prompt_len = prompt_len;
     a.forced_tok = forced_prompt ? (int)prompt[step_nr] : -1; a.max_len = max_len;
@@ -660,6 +672,13 @@ int smi_text_decoder_set_chains(smi_text_decoder* D, int32_t chains) {
   if (!D) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (chains < 0 || chains > kMaxChains) return fail(SMI_ERR_INVALID_ARG, "chains %d outside [0, %d]", chains, kMaxChains);
   D->chains = chains;
+  return SMI_OK;
+}
+
+int smi_text_decoder_set_beam_logits_dtype(smi_text_decoder* D, int32_t dtype) {
+  if (!D) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (dtype != SMI_F16 && dtype != SMI_F32) return fail(SMI_ERR_INVALID_ARG, "dtype %d: SMI_F16 or SMI_F32", dtype);
+  D->beam_logits_f16 = dtype == SMI_F16;
   return SMI_OK;
 }
 

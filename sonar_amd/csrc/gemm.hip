@@ -525,7 +525,10 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     };
     (void)fold_affine_st;
 
-    if constexpr (EPI == EPI_STORE_F32) {
+    // (round 4: also with the tile-major fp16 store -- an fp16 model's logits are fp16 in the reference, the statistics are
+    // then taken of the ROUNDED values, i.e. of exactly what the selection kernels will read)
+    constexpr bool STATS_F16 = EPI == EPI_BIAS_F16 && LAYOUT == 2;
+    if constexpr (EPI == EPI_STORE_F32 || STATS_F16) {
       if (stats.tile_max) {
         // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's logits
         // GEMM, no bias): branch-free and lane-local over the lane's 16 values of a row in the log2
@@ -542,7 +545,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float v = acc.v[ni][mi][r] * sc2;
+              float v = acc.v[ni][mi][r];
+              if constexpr (STATS_F16) v = (float)(f16)v;
+              v *= sc2;
               if (!full) v = (n0 + wc * 64 + ni * 16 + 4 * kg + r) < stats.valid_n ? v : -INFINITY;
               t[ni][r] = v;
               mx = fmaxf(mx, v);
@@ -1091,7 +1096,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
       return launch_one256<EPI_RESID_HALF_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
     return hipErrorInvalidValue;
   }
-  if (stats) {  // tile statistics exist only in the 256x256 engine's fp32-store epilogue, without a bias
+  if (stats) {  // tile statistics: the 256x256 engine's fp32-store epilogue or its tile-major fp16 store, without a bias
+    if (epi == EPI_BIAS_F16 && out_tm && in_tm && can256 && sel != 1 && !bias)
+      return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, stats);
     if (epi != EPI_STORE_F32 || out_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
     return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, out, M, N, K, ldo, stream, stats)
                  : launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);

@@ -177,7 +177,8 @@ constexpr int kVocabScanK2Max = 16;
 // Per row: softmax normaliser (pmax, psum) from the GEMM's tile statistics and the top-k2 candidates
 // among the k2 best tiles + tile 0 (pval / pidx [rows][kVocabScanK2Max]), without re-reading the whole
 // logits row.
-hipError_t launch_vocab_select(const float* logits, int ldl, int rows, int vocab, const float* tile_max,
+// f16_tm: the logits are fp16 in the tile-major layout (K = ldl) instead of fp32 [rows][ldl]
+hipError_t launch_vocab_select(const float* logits, int ldl, int f16_tm, int rows, int vocab, const float* tile_max,
                                const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream);
@@ -187,6 +188,7 @@ struct BeamStepArgs {
   const int32_t* hist; int32_t* fin_tok; int32_t* fin_len; float* fin_score; int32_t* fin_count;
   float* margins;  // [n][2] or null
   const float* logits; int ldl;
+  int logits_f16_tm;  // logits are fp16 in the tile-major layout (K = ldl) instead of fp32 [rows][ldl]
   const float* pmax; const float* psum; const float* pval; const int* pidx; int nchunks;
   int n, beam, k2, pos, prompt_len, forced_tok, max_len;
   float inv_temp, len_penalty; int normalize, eos_idx, hist_stride;

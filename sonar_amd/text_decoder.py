@@ -141,7 +141,10 @@ class TextDecoderEngine:
 
     def __init__(self, cfg: SonarTextDecoderConfig, state_dict: Mapping[str, torch.Tensor],
                  device: Union[str, torch.device] = "cuda:0",
-                 tokenizer_special: Tuple[int, int, int, int] = (0, 1, 2, 3)):
+                 tokenizer_special: Tuple[int, int, int, int] = (0, 1, 2, 3), dtype: torch.dtype = torch.float16):
+        """dtype: the model's nominal dtype (the reference's `model.to(device, dtype)`).  The engine multiplies fp16
+        operands into fp32 accumulators whatever it is; what follows the dtype is the storage type of the beam search's
+        logits: a float16 model's logits are float16, as its fp16 final_proj produces them in the reference."""
         if cfg.activation_fn != "ReLU" or cfg.layernorm_embedding or cfg.learned_pos or cfg.no_token_positional_embeddings:
             raise NotImplementedError("decoder variant not covered by the MI355X engine")
         self.cfg = cfg
@@ -196,6 +199,7 @@ class TextDecoderEngine:
             _lib.check(self.lib.smi_text_decoder_create(C.byref(ccfg), C.byref(w), C.byref(handle)))
         self._handle = handle
         del keep
+        self.set_beam_logits_dtype(torch.float16 if dtype == torch.float16 else torch.float32)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -253,6 +257,14 @@ class TextDecoderEngine:
         if max_len <= plen:
             raise ValueError("`max_seq_len` leaves no room for generation after the prompt")
         return max_len, min(plen + min_gen_len, max_len)
+
+    def set_beam_logits_dtype(self, dtype: torch.dtype) -> None:
+        """Storage type of the logits inside generate() (smi_text_decoder_set_beam_logits_dtype): float16 is what the
+        reference's fp16 model produces (its tied final_proj is an fp16 Linear), float32 keeps the accumulators."""
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError("float16 or float32")
+        _lib.check(self.lib.smi_text_decoder_set_beam_logits_dtype(
+            self._handle, _lib.SMI_F16 if dtype == torch.float16 else _lib.SMI_F32))
 
     def set_chains(self, chains: int) -> None:
         """Independent decode chains of generate() (smi_text_decoder_set_chains): 0 = the engine's choice."""
@@ -339,7 +351,7 @@ class ConditionalTransformerDecoderModel:
         self.model_dim = cfg.model_dim
         self.max_target_seq_len = cfg.max_seq_len
         self.dtype = dtype
-        self.engine = TextDecoderEngine(cfg, state_dict, device)
+        self.engine = TextDecoderEngine(cfg, state_dict, device, dtype=dtype)
         self.device = self.engine.device
 
     def eval(self):

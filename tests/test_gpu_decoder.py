@@ -218,6 +218,46 @@ def test_independent_chains_return_the_single_chain_hypotheses(setup, chains, mo
     assert same >= 0.9 * n
 
 
+def test_beam_logits_storage_type(setup):
+    """smi_text_decoder_set_beam_logits_dtype (round 4): the beam search of an fp16 model stores its logits in fp16 (tile-major,
+    statistics of the ROUNDED values), as the reference's fp16 final_proj produces them; fp32 keeps the accumulators.  Both
+    re-score to the oracle's log-probabilities; their scores differ by at most the fp16 rounding of the logits; hypotheses are
+    equal wherever the run's own decision margin exceeds that rounding."""
+    OD, ocfg, params, eng = setup
+    g = torch.Generator().manual_seed(23)
+    n = 24
+    emb = (torch.randn(n, ocfg.model_dim, generator=g) * 0.3).cuda()
+    prompt = [3, 17]
+    kw = dict(beam_size=5, min_gen_len=3, max_gen_len=(0, 14))
+    out = {}
+    try:
+        for dt in (torch.float32, torch.float16):
+            eng.set_beam_logits_dtype(dt)
+            toks, lens, scores = [t.cpu() for t in eng.generate(emb, prompt, **kw)]
+            out[dt] = (toks, lens, scores, eng.last_margins(n).cpu())
+    finally:
+        eng.set_beam_logits_dtype(torch.float16)
+    with pytest.raises(ValueError):
+        eng.set_beam_logits_dtype(torch.bfloat16)
+    t32, l32, s32, m32 = out[torch.float32]
+    t16, l16, s16, m16 = out[torch.float16]
+    logit_scale = OD.decoder_logits(params, ocfg, emb[:1].cpu(), torch.tensor([prompt])).abs().max().item()
+    ulp = logit_scale * 2.0 ** -10          # fp16 rounding of a logit of that size, and of the normaliser's inputs
+    same = 0
+    for i in range(n):
+        for dt, (toks, lens, scores, _) in out.items():
+            L = int(lens[i, 0])
+            total = _rescored(OD, params, ocfg, emb[i].cpu(), prompt, toks[i, 0, :L].tolist())
+            assert abs(total / (len(prompt) + L - 1) - scores[i, 0].item()) <= 5e-3, (dt, i)
+        if torch.equal(t32[i, 0], t16[i, 0]):
+            same += 1
+            assert abs(s32[i, 0].item() - s16[i, 0].item()) <= 4 * ulp
+        else:
+            assert min(m32[i, 0].item(), m16[i, 0].item()) <= 8 * ulp, (i, m32[i].tolist(), m16[i].tolist())
+    assert same >= n - 3, same
+    print(f"fp16 / fp32 beam logits: {same}/{n} best hypotheses identical, logit scale {logit_scale:.2f}")
+
+
 def test_beam_search_forced_eos_and_min_len(setup):
     OD, ocfg, params, eng = setup
     emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3
