@@ -258,6 +258,35 @@ def test_beam_logits_storage_type(setup):
     print(f"fp16 / fp32 beam logits: {same}/{n} best hypotheses identical, logit scale {logit_scale:.2f}")
 
 
+def test_bf16_decoder_model_vs_oracle():
+    """A bf16 decoder (`dtype=torch.bfloat16`, bf16 weights and bf16 sentence vectors; sonar/inference_pipelines/text.py:
+    305-346 moves the model with `.to(device, dtype)`): bf16 weights are exact fp16 operands, the stream is fp32, the beam
+    search keeps fp32 logits (fp16 storage is an fp16 model's, test_beam_logits_storage_type).  Teacher-forced logits and the
+    beam-5 hypotheses against the fp32 oracle run on the SAME (bf16-representable) weights and inputs."""
+    from oracle import text_decoder as OD
+    from sonar_amd.text_decoder import ConditionalTransformerDecoderModel
+
+    ocfg, cfg = _cfgs()
+    params = {k: v.to(torch.bfloat16) for k, v in OD.make_synthetic_params(ocfg, seed=77, std=0.09).items()}
+    fparams = {k: v.float() for k, v in params.items()}
+    model = ConditionalTransformerDecoderModel(cfg, params, device="cuda:0", dtype=torch.bfloat16)
+    eng = model.engine
+    g = torch.Generator().manual_seed(5)
+    emb = (torch.randn(6, ocfg.model_dim, generator=g) * 0.3).to(torch.bfloat16)
+    prev = torch.randint(4, ocfg.vocab_size, (6, 9), generator=g)
+    prev[:, 0] = 3
+    ref = OD.decoder_logits(fparams, ocfg, emb.float(), prev)
+    got = eng.logits(emb.cuda(), prev.cuda()).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 1.5e-2 * scale, ((got - ref).abs().max().item(), scale)
+    prompt = [3, 17]
+    toks, lens, scores = [t.cpu() for t in eng.generate(emb.cuda(), prompt, beam_size=5, min_gen_len=3, max_gen_len=(0, 12))]
+    for i in range(6):
+        L = int(lens[i, 0])
+        total = _rescored(OD, fparams, ocfg, emb[i].float(), prompt, toks[i, 0, :L].tolist())
+        assert abs(total / (len(prompt) + L - 1) - scores[i, 0].item()) <= 5e-3, (i, total, scores[i, 0].item())
+
+
 def test_beam_search_forced_eos_and_min_len(setup):
     OD, ocfg, params, eng = setup
     emb = torch.randn(3, ocfg.model_dim, generator=torch.Generator().manual_seed(5)) * 0.3

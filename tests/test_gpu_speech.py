@@ -75,6 +75,33 @@ def test_speech_encoder_vs_oracle(ragged, fp16_residual):
     assert _cos_err(one, emb[i:i + 1]) <= 1e-5
 
 
+def test_bf16_speech_model_vs_oracle():
+    """`dtype=torch.bfloat16` (the reference's pipelines take any dtype, sonar/inference_pipelines/speech.py:402-474 ->
+    `model.to(device, dtype)`): bf16 weights are exact fp16 operands, the residual stream is fp32 (a bf16 model's
+    activations have fp32 range), embeddings come back in bf16 -- within the north_star bound of the fp32 oracle run on the
+    SAME (bf16-representable) weights, and equal to the fp16 model's up to the stream's and the output's roundings."""
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import SonarSpeechEncoderModel
+    from sonar_amd.text_encoder import PaddingMask, SequenceBatch
+
+    ocfg, cfg = _cfgs()
+    params = {k: v.to(torch.bfloat16) for k, v in OS.make_synthetic_params(ocfg, seed=31, std=0.06).items()}
+    g = torch.Generator().manual_seed(9)
+    lens = torch.tensor([300, 97, 158, 299])
+    fb = torch.randn(len(lens), 300, 80, generator=g)
+    for i, L in enumerate(lens.tolist()):
+        fb[i, L:] = 0
+    _, ref = OS.speech_encoder_forward({k: v.float() for k, v in params.items()}, ocfg, fb, lens)
+    batch = SequenceBatch(fb.cuda(), PaddingMask(lens, 300))
+    out = SonarSpeechEncoderModel(cfg, params, device="cuda:0", dtype=torch.bfloat16)(batch).sentence_embeddings
+    assert out.dtype == torch.bfloat16 and out.shape == (4, 256) and torch.isfinite(out.float()).all()
+    err = _cos_err(out, ref)
+    print(f"bf16 speech model: max (1 - cos) vs oracle = {err:.2e}")
+    assert err <= 1e-3, err
+    out16 = SonarSpeechEncoderModel(cfg, params, device="cuda:0", dtype=torch.float16)(batch).sentence_embeddings
+    assert out16.dtype == torch.float16 and _cos_err(out16, out) <= 1e-4
+
+
 def test_speech_encoder_10s_frames_ragged_vs_oracle():
     """The shape BASELINE configs[3] is timed on (998 filterbank frames = 499 conformer frames per clip: eight 64-key
     tiles and relative positions out to +-498 in `relpos_attention_kernel`), as a RAGGED batch at small width."""
