@@ -10,6 +10,7 @@
 #include <type_traits>
 
 #include "gemm_lone.hpp"
+#include "gemm_lone16.hpp"
 #include "gemm_tile.hpp"
 #include "gemm_tile256.hpp"
 #include "kernels.hpp"
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(GT_THREADS, (LoneShape<BM, BN>::WG_PER_CU)) void ge
                                                                   size_t part_stride) {
   using S = LoneShape<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  LONE_TRACE(5);  // kernel entry
   int tile_m, tile_n;
   lone_tile_coords(M / BM, N / BN, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -247,6 +249,57 @@ __global__ __launch_bounds__(GT_THREADS, (LoneShape<BM, BN>::WG_PER_CU)) void ge
   lone_mainloop<(LAYOUT > 0), BM, BN, S::NI, S::MI>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
   gt_epilogue<EPI, LAYOUT, S::MI, S::NI>(acc, b, out, m0 + wm * (BM / 2) + (lane & 31), col0,
                                          n0 / 2 + wn * 32 + 4 * hi, N, ldo);
+  LONE_TRACE(4);  // stores issued
+}
+
+// The k-sliced lone-tile unit (gemm_lone16.hpp): tile-major X and W, 64x64 units, no LDS in the K loop.  EPI_BIAS_F16 /
+// EPI_RELU_F16 (fp16 output, tile-major when OUT_TM, else row-major with ldo) and EPI_STORE_F32 (fp32 row-major: split-K
+// slabs).  blockIdx.y = K part (EPI_STORE_F32), each part K / ksplit = 128 * NKB columns.
+template <int EPI, bool OUT_TM, int NKB>
+__global__ __launch_bounds__(L16_THREADS, 2) void gemm_lone16_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+                                                                     const float* __restrict__ bias, void* __restrict__ out,
+                                                                     int M, int N, int K, int ldo, size_t part_stride) {
+  static_assert(EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16 || EPI == EPI_STORE_F32, "epilogues of the k-sliced unit");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int tile_m, tile_n;
+  lone_tile_coords(M / L16_BM, N / L16_BN, tile_m, tile_n);
+  const int m0 = tile_m * L16_BM, n0 = tile_n * L16_BN;
+  const int kz = blockIdx.y;
+  if (kz > 0) {
+    bias = nullptr;
+    out = (char*)out + (size_t)kz * part_stride;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  // the lane's bias values (its 4-column runs), requested in front of the operand stream through a pointer that falls back to
+  // a valid address: a conditional load is a branch, and hipcc waits for the loads inside it (vmcnt(0)) before it goes on
+  const float* bp = bias ? bias + n0 + 4 * kg : (const float*)W + 4 * kg;
+  f32x4 b[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) b[ni] = *(const f32x4*)(bp + ni * 16);
+  f32x4 acc[4][4];
+  lone16_mainloop<NKB>(acc, X, W, K, m0, n0, kz * 128 * NKB);
+  if (!bias) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) b[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 v[4];
+  lone16_reduce(acc, v, smem);
+  const int row = m0 + wave * 16 + l15;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = n0 + ni * 16 + 4 * kg;
+    const f32x4 o = v[ni] + b[ni];
+    if constexpr (EPI == EPI_STORE_F32) {
+      *(f32x4*)((float*)out + (size_t)row * ldo + n) = o;
+    } else {
+      const half4 h = epi_act_pack<EPI>(o);
+      if constexpr (OUT_TM)
+        *(half4*)((f16*)out + tm_offset(row, n, N)) = h;
+      else
+        *(half4*)((f16*)out + (size_t)row * ldo + n) = h;
+    }
+  }
 }
 
 // LDS accesses the compiler must NOT see as LDS accesses: after the next tile's LDS-DMA pipeline fill has been issued,
@@ -1045,9 +1098,43 @@ static hipError_t launch_lone(const f16* X, const f16* W, const float* bias, voi
   return hipGetLastError();
 }
 
+// the k-sliced unit (gemm_lone16.hpp): tile-major operands, K per unit 256 / 512 / 1024.  SMI_LONE16=0: the LDS-ring unit
+// for every lone launch (A/B runs; its results are bit-identical to the other 128x128-family engines, these are not)
+static bool lone16_enabled() {
+  const char* e = getenv("SMI_LONE16");
+  return !(e && e[0] == '0');
+}
+template <int EPI, bool OUT_TM>
+static hipError_t launch_lone16(const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ldo,
+                                hipStream_t stream, int ksplit, size_t part_stride) {
+  const int grid = (M / L16_BM) * (N / L16_BN);
+  const int nkb = K / ksplit / 128;
+#define SMI_L16(NKB)                                                                                                      \
+  {                                                                                                                       \
+    static DeviceOnce attr_done;                                                                                          \
+    if (!attr_done.done()) {                                                                                              \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_lone16_kernel<EPI, OUT_TM, NKB>,                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, L16_LDS_BYTES);                      \
+      if (e != hipSuccess) return e;                                                                                      \
+      attr_done.set();                                                                                                    \
+    }                                                                                                                     \
+    hipLaunchKernelGGL((gemm_lone16_kernel<EPI, OUT_TM, NKB>), dim3(grid, ksplit), dim3(L16_THREADS), L16_LDS_BYTES,     \
+                       stream, X, W, bias, out, M, N, K, ldo, part_stride);                                               \
+  }
+  if (nkb == 8) SMI_L16(8) else if (nkb == 4) SMI_L16(4) else SMI_L16(2)
+#undef SMI_L16
+  return hipGetLastError();
+}
+
 template <int EPI, int LAYOUT = 0>
 static hipError_t launch_one(const f16* X, const f16* W, const float* bias, void* out, int M, int N,
                              int K, int ldo, hipStream_t stream, int ksplit = 1, size_t part_stride = 0) {
+  if constexpr ((EPI == EPI_BIAS_F16 || EPI == EPI_RELU_F16 || EPI == EPI_STORE_F32) && (LAYOUT == 1 || LAYOUT == 2)) {
+    const int klen = K / ksplit;
+    if (lone_enabled() && lone16_enabled() && lone_fits(M, N, ksplit) && K % ksplit == 0 &&
+        (klen == 256 || klen == 512 || klen == 1024) && (EPI != EPI_STORE_F32 || LAYOUT == 1))
+      return launch_lone16<EPI, LAYOUT == 2>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);
+  }
   if constexpr (EPI != EPI_GLU_F16)  // GLU pairs two 32-column blocks of a wave: 128-column tiles only
     if (lone_enabled() && lone_fits(M, N, ksplit))
       return launch_lone<EPI, LAYOUT, 64, 64>(X, W, bias, out, M, N, K, ldo, stream, ksplit, part_stride);

@@ -33,6 +33,14 @@
 
 namespace smi {
 
+#ifdef SMI_GEMM_TRACE  // development aid: phase timestamps of thread 0 of workgroups 0..15 (gemm.hip: g2_trace_buf)
+extern __device__ unsigned long long g2_trace_buf[16 * 64 * 8];
+#define LONE_TRACE(slot) \
+  if (threadIdx.x == 0 && blockIdx.x < 16 && blockIdx.y == 0) g2_trace_buf[(blockIdx.x * 64) * 8 + (slot)] = wall_clock64()
+#else
+#define LONE_TRACE(slot)
+#endif
+
 template <int BM, int BN>
 struct LoneShape {
   static_assert((BM == 128 || BM == 64) && (BN == 128 || BN == 64), "unit shapes: 128x128, 128x64, 64x64");
@@ -171,19 +179,33 @@ __device__ __forceinline__ void lone_mainloop(f32x16 (&acc)[NI][MI], const f16* 
 
   const int nt = klen / GT_BK;
   const int filled = min(nt, ST);
+  LONE_TRACE(3);  // addresses set up
 #pragma unroll
   for (int s = 0; s < ST; ++s)
     if (s < nt) issue(s);
+  LONE_TRACE(0);                      // fill issued
   lone_wait_stages<CPW>(filled - 1);  // my pieces of stage 0
   asm volatile("s_barrier" ::: "memory");
+  LONE_TRACE(1);                      // stage 0 landed
   LoneFrag<BM, BN> fa, fb;
   read_frags(0, fa);
   if (nt > 1) lone_wait_stages<CPW>(filled - 2);  // my pieces of stage 1
   lone_retire(fa);
 
+#ifdef SMI_GEMM_TRACE
+  unsigned long long ph_read = 0, ph_dma = 0, ph_mfma = 0, ph_wait = 0;
+#define LONE_PH(acc_, t0_) { const unsigned long long now_ = __builtin_readcyclecounter(); acc_ += now_ - t0_; t0_ = now_; }
+#else
+#define LONE_PH(acc_, t0_)
+#endif
   auto step = [&](int t, const LoneFrag<BM, BN>& cur, LoneFrag<BM, BN>& nxt) {
+#ifdef SMI_GEMM_TRACE
+    unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     if (t + 1 < nt) read_frags(t + 1, nxt);
+    LONE_PH(ph_read, t0)
     if (t + ST < nt) issue(t + ST);
+    LONE_PH(ph_dma, t0)
 #ifdef SMI_LONE_SERIAL  // probe build: fragment reads retired BEFORE the MFMAs (no overlap inside a wave)
     if (t + 2 < nt) lone_wait_stages<CPW>(min(nt - 1, t + ST) - (t + 2));
     lone_retire(nxt);
@@ -197,10 +219,12 @@ __device__ __forceinline__ void lone_mainloop(f32x16 (&acc)[NI][MI], const f16* 
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.w[ks][ni], cur.x[ks][mi], acc[ni][mi], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    LONE_PH(ph_mfma, t0)
 #ifndef SMI_LONE_SERIAL
     if (t + 2 < nt) lone_wait_stages<CPW>(min(nt - 1, t + ST) - (t + 2));
     lone_retire(nxt);
 #endif
+    LONE_PH(ph_wait, t0)
   };
   int t = 0;
   for (; t + 1 < nt; t += 2) {
@@ -208,6 +232,15 @@ __device__ __forceinline__ void lone_mainloop(f32x16 (&acc)[NI][MI], const f16* 
     step(t + 1, fb, fa);
   }
   if (t < nt) step(t, fa, fb);
+  LONE_TRACE(2);  // K loop done
+#ifdef SMI_GEMM_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 16 && blockIdx.y == 0) {  // shader-clock cycles per phase, summed over the steps
+    g2_trace_buf[(blockIdx.x * 64 + 1) * 8 + 0] = ph_read;
+    g2_trace_buf[(blockIdx.x * 64 + 1) * 8 + 1] = ph_dma;
+    g2_trace_buf[(blockIdx.x * 64 + 1) * 8 + 2] = ph_mfma;
+    g2_trace_buf[(blockIdx.x * 64 + 1) * 8 + 3] = ph_wait;
+  }
+#endif
 }
 
 // XCD-aware grouped raster (gt_tile_coords) for any unit shape: consecutive logical ids are the row units of ONE

@@ -116,7 +116,7 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
 
 
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (256, 1024, 1024), (512, 2560, 128), (512, 4096, 256),
-                                   (1024, 3072, 192), (256, 256, 4096)])
+                                   (1024, 3072, 192), (256, 256, 4096), (256, 512, 512), (768, 256, 1024)])
 def test_gemm_lone_units(lib, monkeypatch, m, n, k):
     """The lone-tile engine (gemm_lone.hpp, 64x64 units): K loops shorter / equal / longer than the ring (1, 2, 3, 4, 16,
     64 K tiles), one and two workgroups per CU (4 ... 512 units; 768 units: back on the 128x128 ring), row-major and
@@ -157,10 +157,19 @@ def test_gemm_lone_units(lib, monkeypatch, m, n, k):
         cases += [(0, 1, 1), (1, 1, 1), (3, 1, 0), (8, 1, 1), (6, 1, 0)]
     for epi, tm, out_tm in cases:
         monkeypatch.setenv("SMI_LONE", "1")
+        monkeypatch.setenv("SMI_LONE16", "0")     # the LDS-ring unit: same MFMA order over K as the ring
         got = run(epi, tm, out_tm)
         monkeypatch.setenv("SMI_LONE", "0")
         old = run(epi, tm, out_tm)
         assert torch.equal(got, old), (epi, tm, out_tm)
+        # the k-sliced unit (gemm_lone16.hpp: tile-major operands, K per unit 256 / 512 / 1024; everything else falls through to
+        # the ring unit): its own summation order, equal within fp32 rounding of the accumulation
+        monkeypatch.setenv("SMI_LONE", "1")
+        monkeypatch.setenv("SMI_LONE16", "1")
+        got16 = run(epi, tm, out_tm)
+        d16 = (got16.float() - got.float()).abs().max().item()
+        assert d16 <= (2e-3 if epi != 3 else 2e-5) * max(got.float().abs().max().item(), 1.0), (epi, tm, out_tm, d16)
+        got = got16
         if epi == 2:
             want = resid32 + ref
         elif epi == 8:
