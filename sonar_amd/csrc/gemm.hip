@@ -1158,8 +1158,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   if (sel == 2 && !can256) return hipErrorInvalidValue;
   // the 256x256 ping-pong engine is ~1.5x more efficient per CU than the 128x128 one but has a 21 us
   // floor for a K = 1024 tile and one workgroup per CU; measured crossover (tools/probe_engines.py):
-  // 128 tiles tie, 160 tiles win -> use it from 144 tiles (56 % of the CUs) up
-  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 144);
+  // 128 tiles tie, 160 tiles win; round 4 (tools/probe_engines_mid.py, M = 1024 x N = 8192 = 128 tiles, tile-major operands): 25.8 vs
+  // 28.6 us hot, 31.8 vs 33.8 us on cold weights -> use it from 128 tiles (half the CUs) up
+  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
   if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream
     if (!can256 || sel == 1 || !in_tm || stats) return hipErrorInvalidValue;
     if (fold->part_in) {  // consumer: tile-major outputs (bias / relu / silu) or row-major ones (bias / GLU; centred weights)
