@@ -1160,7 +1160,11 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // floor for a K = 1024 tile and one workgroup per CU; measured crossover (tools/probe_engines.py):
   // 128 tiles tie, 160 tiles win; round 4 (tools/probe_engines_mid.py, M = 1024 x N = 8192 = 128 tiles, tile-major operands): 25.8 vs
   // 28.6 us hot, 31.8 vs 33.8 us on cold weights -> use it from 128 tiles (half the CUs) up
-  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= 128);
+  // (SMI_G2_AUTO_MIN overrides the threshold, read per launch: tests that compare runs of different row counts bit for bit
+  // pin the engine family with it)
+  const char* amin = getenv("SMI_G2_AUTO_MIN");
+  const int64_t auto_min = amin && *amin ? atoll(amin) : 128;
+  const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= auto_min);
   if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream
     if (!can256 || sel == 1 || !in_tm || stats) return hipErrorInvalidValue;
     if (fold->part_in) {  // consumer: tile-major outputs (bias / relu / silu) or row-major ones (bias / GLU; centred weights)

@@ -382,6 +382,9 @@ def test_basic_decoder_chains_bit_identical_full_size(basic_decoder, monkeypatch
     # family takes it), a chain's 1 024 rows are 128 units (the 256x256 engine takes it) -- two MFMA shapes, two fp32
     # summation orders.  Pin the family for both.
     monkeypatch.setenv("SMI_G2_SPLITK_MIN", "1000000")
+    # ... and the fused QKV projection: 2 816 rows x 3 072 columns are 132 tiles of the 256x256 engine (its automatic choice from
+    # 128 tiles up), a chain's 1 024 rows are 48 (the 128x128 family)
+    monkeypatch.setenv("SMI_G2_AUTO_MIN", "1000000")
     try:
         eng.set_chains(1)
         one = [t.cpu() for t in eng.generate(emb, [3, 256047], **kw)]
