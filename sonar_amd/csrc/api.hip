@@ -89,7 +89,7 @@ struct smi_text_encoder {
   // workspace (capacity in packed+padded token rows)
   int64_t cap_rows = 0;
   DevBuf x, h, qkv, ctx, ffn;
-  DevBuf parts;  // fp32 split-K slabs of the FFN output projection (small batches only)
+  DevBuf parts;  // split-K slabs of the attention-output / FFN-output projections (small batches only; fp32, or fp16 on an fp16 stream)
   DevBuf rowpart;  // LayerNorm fold: float2 [d / 256][rows] partial (sum, sum of squares) of the residual rows
   bool lnfold = false;  // the folded weights exist (tile-major fp16 configuration, d = 1024)
   bool lnfold_centered = false;  // ... and their rows are centred (no "- mean * c1" term in the epilogue)
@@ -487,26 +487,31 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   const bool pf_on = true;  // weight prefetch by the row kernels' surplus workgroups (SMI_PREFETCH=0 disables it: A/B runs)
   for (int l = 0; l < c.num_layers && sb; ++l) {  // small batches: the decoder-shaped layer (see above)
     Layer& L = e->layers[l];
-    float* parts = e->parts.as<float>();
+    void* parts = e->parts.p;
     const size_t ps = (size_t)M * d;
+    // fp16 slabs for an fp16 residual stream (the fp16 model: the reference rounds every sublayer output to fp16; here each
+    // split-K partial is rounded once, the sum is formed in fp32 and meets the stream in one rounding as before):
+    // half the slab traffic between a projection and the kernel that folds it.  SMI_ENC_SLAB_F16=0: fp32 slabs (A/B runs)
+    static const bool slab_env = [] { const char* v = getenv("SMI_ENC_SLAB_F16"); return !(v && v[0] == '0'); }();
+    const int sf16 = slab_env && x16;
     { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += FFN-output slabs of the previous layer; h = LN1(x)
     HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ffn2_ks, ps, nullptr, 1, L.ln1_w.as<float>(), L.ln1_b.as<float>(),
-                                 c.ln_eps, h, M, d, stream, tm, x16, pf_on ? L.w_1.p : nullptr, (size_t)f * d * 2)); }
+                                 c.ln_eps, h, M, d, stream, tm, x16, pf_on ? L.w_1.p : nullptr, (size_t)f * d * 2, sf16)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_QKV, stream);
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | io_tm, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), qkv, M, 3 * d, d, 3 * d, stream)); }
     { ProfScope ps_(e, SMI_PROF_ATTENTION, stream);
     HIP_TRY(launch_attention(qkv, d_cu, ctx, n, max_len, d, c.num_heads, stream, tm ? 3 : 0)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_OUT, stream);
-    HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, M, d, d, out_ks, stream, tm)); }
+    HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, M, d, d, out_ks, stream, tm, sf16)); }
     { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += attention-output slabs; h = LN2(x)
     HIP_TRY(launch_sum_layernorm(x, parts, out_ks, ps, nullptr, 1, L.ln2_w.as<float>(), L.ln2_b.as<float>(), c.ln_eps, h, M, d,
-                                 stream, tm, x16, pf_on ? L.w_2.p : nullptr, (size_t)f * d * 2)); }
+                                 stream, tm, x16, pf_on ? L.w_2.p : nullptr, (size_t)f * d * 2, sf16)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_FFN1, stream);
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | io_tm, h, L.w_1.as<f16>(), L.b_1.as<float>(), ffn, M, f, d, f, stream)); }
     { ProfScope ps_(e, SMI_PROF_GEMM_FFN2, stream);
-    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, M, d, f, ffn2_ks, stream, tm));
+    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, M, d, f, ffn2_ks, stream, tm, sf16));
     if (l + 1 == c.num_layers)  // the last layer's slabs meet the stream before the final LayerNorm + pooling
-      HIP_TRY(launch_fold_residual(x, x16, parts, ffn2_ks, ps, ps, stream)); }
+      HIP_TRY(launch_fold_residual(x, x16, parts, ffn2_ks, ps, ps, stream, sf16)); }
   }
   for (int l = 0; l < c.num_layers && !sb; ++l) {
     Layer& L = e->layers[l];

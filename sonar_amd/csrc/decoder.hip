@@ -68,8 +68,9 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
 __device__ unsigned g_prefetch_sink;  // never written in practice (common.hpp: prefetch_range)
 
 // NP: the number of slabs when it is one of 0 / 1 / 2 / 4 / 8 (straight-line loads), -1: any number (rounds of ZB).
-template <int NV, typename XT, int NP>
-__global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const float* __restrict__ parts,
+// PT: slab element type (float, or f16: an fp16 model's split-K projections store fp16 partials; the sum is formed in fp32).
+template <int NV, typename XT, int NP, typename PT>
+__global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const PT* __restrict__ parts,
                                                      int nparts, size_t part_stride,
                                                      const float* __restrict__ c, int group,
                                                      const float* __restrict__ w,
@@ -101,14 +102,21 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
   const float* cp = c ? c + (size_t)(r / group) * D + lane * 4 : w + lane * 4;
 #pragma unroll
   for (int k = 0; k < NV; ++k) cv[k] = *(const f32x4*)(cp + k * 256);
-  const float* pr = parts + (size_t)r * D + lane * 4;
+  const PT* pr = parts + (size_t)r * D + lane * 4;
+  typedef typename std::conditional<sizeof(PT) == 2, half4, f32x4>::type PV;
+  auto widen = [](const PV& v) {
+    if constexpr (sizeof(PT) == 2)
+      return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    else
+      return v;
+  };
   constexpr int NPC = NP > 0 ? NP : 1;
-  f32x4 p[NPC][NV];
+  PV p[NPC][NV];
   if constexpr (NP > 0) {
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
-      for (int k = 0; k < NV; ++k) p[j][k] = *(const f32x4*)(pr + (size_t)j * part_stride + k * 256);
+      for (int k = 0; k < NV; ++k) p[j][k] = *(const PV*)(pr + (size_t)j * part_stride + k * 256);
   }
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
 #pragma unroll
     for (int j = 0; j < NP; ++j)
 #pragma unroll
-      for (int k = 0; k < NV; ++k) v[k] += p[j][k];
+      for (int k = 0; k < NV; ++k) v[k] += widen(p[j][k]);
   } else if constexpr (NP < 0) {
     constexpr int ZB = NV <= 4 ? 8 : 4;  // slabs per round trip (register budget: ZB * NV f32x4)
     for (int z0 = 0; z0 < nparts; z0 += ZB) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
       for (int j = 0; j < ZB; ++j)
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-          q[j][k] = z0 + j < nparts ? *(const f32x4*)(pr + (size_t)(z0 + j) * part_stride + k * 256)
+          q[j][k] = z0 + j < nparts ? widen(*(const PV*)(pr + (size_t)(z0 + j) * part_stride + k * 256))
                                     : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < ZB; ++j)
@@ -190,8 +198,8 @@ __global__ __launch_bounds__(256) void sum_ln_kernel(XT* __restrict__ x, const f
   }
 }
 
-template <int NV, typename XT>
-static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const float* parts, int nparts, size_t part_stride,
+template <int NV, typename XT, typename PT>
+static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const PT* parts, int nparts, size_t part_stride,
                              const float* c, int group, const float* w, const float* b, float eps, f16* h, int rows,
                              int h_tm, const void* pf, size_t pf_bytes) {
   // surplus workgroups for the weight prefetch: one per CU the row work leaves idle
@@ -210,7 +218,7 @@ static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const float*
   const int extra = pf_env && pf && pf_bytes && blocks * 4 <= cus ? cus - blocks : 0;
   const int main_blocks = blocks;
 #define SMI_SL(NP)                                                                                                     \
-  hipLaunchKernelGGL((sum_ln_kernel<NV, XT, NP>), dim3(blocks + extra), dim3(256), 0, stream, x, parts, nparts,        \
+  hipLaunchKernelGGL((sum_ln_kernel<NV, XT, NP, PT>), dim3(blocks + extra), dim3(256), 0, stream, x, parts, nparts,    \
                      part_stride, c, group, w, b, eps, h, rows, h_tm, pf, pf_bytes, main_blocks)
   switch (nparts) {
     case 0: SMI_SL(0); break;
@@ -228,20 +236,24 @@ static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const float*
 #undef SMI_SL
 }
 
-hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t part_stride,
+hipError_t launch_sum_layernorm(void* x, const void* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
                                 f16* h, int rows, int d, hipStream_t stream, int h_tm, int x_f16, const void* pf,
-                                size_t pf_bytes) {
+                                size_t pf_bytes, int parts_f16) {
   const int blocks = (rows + 3) / 4;
   if (!parts) nparts = 0;
-#define SMI_AL_CASE(NV)                                                                                              \
-  case NV * 256:                                                                                                     \
-    if (x_f16)                                                                                                       \
-      launch_sum_ln_np<NV, f16>(blocks, stream, (f16*)x, parts, nparts, part_stride, c, group, w, b, eps, h, rows, h_tm, \
-                                pf, pf_bytes);                                                                       \
-    else                                                                                                             \
-      launch_sum_ln_np<NV, float>(blocks, stream, (float*)x, parts, nparts, part_stride, c, group, w, b, eps, h, rows, \
-                                  h_tm, pf, pf_bytes);                                                               \
+#define SMI_AL_GO(NV, XT, PT)                                                                                           \
+  launch_sum_ln_np<NV, XT, PT>(blocks, stream, (XT*)x, (const PT*)parts, nparts, part_stride, c, group, w, b, eps, h, rows, \
+                               h_tm, pf, pf_bytes)
+#define SMI_AL_CASE(NV)                       \
+  case NV * 256:                              \
+    if (x_f16) {                              \
+      if (parts_f16) SMI_AL_GO(NV, f16, f16); \
+      else SMI_AL_GO(NV, f16, float);         \
+    } else {                                  \
+      if (parts_f16) SMI_AL_GO(NV, float, f16); \
+      else SMI_AL_GO(NV, float, float);       \
+    }                                         \
     break;
   switch (d) {
     SMI_AL_CASE(1)
@@ -252,6 +264,7 @@ hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t 
     default: return hipErrorInvalidValue;
   }
 #undef SMI_AL_CASE
+#undef SMI_AL_GO
   return hipGetLastError();
 }
 

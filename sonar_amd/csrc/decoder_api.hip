@@ -198,8 +198,13 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
   f16* ffn = S.ffn.as<f16>();
   const size_t slab = (size_t)rows_pad * 3 * d;  // elements per (layer, pos)
   const int P = S.kv_positions;
-  float* parts = S.parts.as<float>();
+  void* parts = S.parts.p;
   const size_t part_stride = (size_t)rows_pad * d;  // elements
+  // fp16 split-K slabs in the fp16 model's beam search (logits_f16: the reference rounds every sublayer output to fp16; here
+  // each partial is rounded once, the sum is formed in fp32 and added to the fp32 stream): half the 42 MB the FFN output
+  // projection wrote and the next kernel read per layer at 1280 rows.  SMI_DEC_SLAB_F16 = 0 / 1 overrides (A/B runs).
+  const int sf_env = DecTuning::env_int("SMI_DEC_SLAB_F16", -1);
+  const int sf16 = sf_env >= 0 ? (sf_env != 0) : logits_f16;
   // Split-K parts of the two N = d projections.  FFN output (K = f): 8 parts of 32 K slices = 160 lone units at
   // 1280 rows; 10 / 12 parts (unequal K ranges, 200 / 240 units) were traced and are NOT faster -- a unit's K loop
   // shrinks 20.0 -> 15.3 us but its 256 KiB slab store grows 4.3 -> 6.4 us (the slab writes run at the chip's
@@ -228,7 +233,7 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
     // x += FFN-out slabs of the previous layer (split-K), then LN1
     // (small batches: the CUs the row kernels leave idle read the layer's FFN matrices ahead, common.hpp: prefetch_range)
     HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ks_ffn, part_stride, nullptr, 1, L.ln1_w.as<float>(),
-                                 L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, 0, 0, L.w_1.p, (size_t)f * d * 2));
+                                 L.ln1_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, 0, 0, L.w_1.p, (size_t)f * d * 2, sf16));
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, h, L.w_qkv.as<f16>(), L.b_qkv.as<float>(), kvl + (size_t)pos * slab,
                            rows_pad, 3 * d, d, 3 * d, stream));
     HIP_TRY(launch_dec_attention(kvl, anc, anc_stride, ctx, rows, rows_pad, d, c.num_heads, pos, stream));
@@ -237,19 +242,20 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
     if (ks_out == 1)  // no split: the projection adds into the fp32 residual stream itself
       HIP_TRY(launch_gemm_tn(EPI_RESID_F32, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, rows_pad, d, d, d, stream));
     else
-      HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream));
+      HIP_TRY(launch_gemm_tn_splitk(ctx, L.w_o.as<f16>(), L.b_o.as<float>(), parts, rows_pad, d, d, ks_out, stream, 0, sf16));
     // the FFN runs on tile-major operands (common.hpp): LN output, hidden activation and both weights
     const int tm = D->ffn_tile_major;
     HIP_TRY(launch_sum_layernorm(x, ks_out == 1 ? nullptr : parts, ks_out, part_stride,
                                  S.cc.as<float>() + (size_t)l * n_pad * d, group, L.ln3_w.as<float>(), L.ln3_b.as<float>(),
-                                 c.ln_eps, h, rows, d, stream, tm, 0, L.w_2.p, (size_t)f * d * 2));
+                                 c.ln_eps, h, rows, d, stream, tm, 0, L.w_2.p, (size_t)f * d * 2, sf16));
     HIP_TRY(launch_gemm_tn(EPI_RELU_F16 | (tm ? GEMM_IN_TM | GEMM_OUT_TM : 0) | (ffn1_engine << 8), h, L.w_1.as<f16>(),
                            L.b_1.as<float>(), ffn, rows_pad, f, d, f, stream));
-    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm));
+    HIP_TRY(launch_gemm_tn_splitk(ffn, L.w_2.as<f16>(), L.b_2.as<float>(), parts, rows_pad, d, f, ks_ffn, stream, tm, sf16));
   }
   const int ltm = D->embed_tm.p != nullptr;  // the tied projection reads a tile-major copy of the table
   HIP_TRY(launch_sum_layernorm(x, c.num_layers ? parts : nullptr, ks_ffn, part_stride, nullptr, 1,
-                               D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, ltm));
+                               D->lnf_w.as<float>(), D->lnf_b.as<float>(), c.ln_eps, h, rows_pad, d, stream, ltm, 0, nullptr, 0,
+                               sf16));
   // beam search (stats_scale = 1 / temperature > 0): the GEMM also leaves per-tile softmax
   // statistics, so the candidate selection never re-reads the 1 MB logits rows
   GemmTileStats st{S.tile_max.as<float>(), S.tile_sum.as<float>(), stats_scale, (int)c.vocab_size};

@@ -1237,10 +1237,12 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   return hipErrorInvalidValue;
 }
 
-// Split-K GEMM into `ksplit` fp32 slabs: parts[z][m][n] = X[:, Kz] . W[:, Kz]^T (+ bias for z = 0);
-// the consumer (launch_sum_layernorm) adds the slabs to the residual stream.
-hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
-                                 int N, int K, int ksplit, hipStream_t stream, int in_tm) {
+// Split-K GEMM into `ksplit` slabs: parts[z][m][n] = X[:, Kz] . W[:, Kz]^T (+ bias for z = 0); the consumer
+// (launch_sum_layernorm / launch_fold_residual) adds the slabs to the residual stream.  slab_f16: the slabs are fp16 (an fp16
+// model rounds every sublayer output to fp16 in the reference; here each PARTIAL is rounded once and the sum is formed in
+// fp32: half the slab traffic between the two kernels), else fp32.
+hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, void* parts, int M,
+                                 int N, int K, int ksplit, hipStream_t stream, int in_tm, int slab_f16) {
   if (M % GT_BM || N % GT_BN || ksplit < 1 || K % GT_BK || M <= 0) return hipErrorInvalidValue;
   if (in_tm && (M % TM_ROWS || N % TM_ROWS)) return hipErrorInvalidValue;
   // the 256x256 ping-pong engine is far more efficient per CU than the 128x128 one (decoder FFN inner:
@@ -1249,12 +1251,21 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
   const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
   const char* mu = getenv("SMI_G2_SPLITK_MIN");  // A/B switch, read per launch (decode-time path: ~50 launches per step)
   const int min_units = mu && *mu ? atoi(mu) : 96;
-  if (M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= min_units && units256 <= num_cus())
-    return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4)
-                 : launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, (size_t)M * N * 4);
-  if (K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly
-  return in_tm ? launch_one<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4)
-               : launch_one<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, ksplit, (size_t)M * N * 4);
+  const size_t ps = (size_t)M * N * (slab_f16 ? 2 : 4);
+  const bool big = M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= min_units && units256 <= num_cus();
+  if (!big && K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly
+  if (slab_f16) {
+    if (big)
+      return in_tm ? launch_one256<EPI_BIAS_F16, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps)
+                   : launch_one256<EPI_BIAS_F16, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps);
+    return in_tm ? launch_one<EPI_BIAS_F16, 1>(X, W, bias, parts, M, N, K, N, stream, ksplit, ps)
+                 : launch_one<EPI_BIAS_F16, 0>(X, W, bias, parts, M, N, K, N, stream, ksplit, ps);
+  }
+  if (big)
+    return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps)
+                 : launch_one256<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps);
+  return in_tm ? launch_one<EPI_STORE_F32, 1>(X, W, bias, parts, M, N, K, N, stream, ksplit, ps)
+               : launch_one<EPI_STORE_F32, 0>(X, W, bias, parts, M, N, K, N, stream, ksplit, ps);
 }
 
 // How many K parts launch_gemm_tn_splitk should be given for a decode-time projection (M = beam x batch rows,
@@ -1308,6 +1319,6 @@ int gemm_splitk_parts(int M, int N, int K, int max_parts) {
 extern "C" int smi_debug_gemm_splitk(const void* x, const void* w, const float* bias, float* parts, int m, int n, int k,
                                      int ksplit, int in_tm, void* stream) {
   return (int)smi::launch_gemm_tn_splitk((const smi::f16*)x, (const smi::f16*)w, bias, parts, m, n, k, ksplit,
-                                         (hipStream_t)stream, in_tm);
+                                         (hipStream_t)stream, in_tm, 0);
 }
 #endif

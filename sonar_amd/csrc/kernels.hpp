@@ -99,8 +99,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
                           const GemmLnFold* fold = nullptr);
 
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
-hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, float* parts, int M,
-                                 int N, int K, int ksplit, hipStream_t stream, int in_tm = 0);
+// slab_f16: fp16 slabs [ksplit][M][N] instead of fp32 ones (the consumers take the same flag)
+hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, void* parts, int M,
+                                 int N, int K, int ksplit, hipStream_t stream, int in_tm = 0, int slab_f16 = 0);
 // cap the persistent grid of the calling thread's next 256x256-engine launches (0 = no cap)
 void set_gemm_grid_cap(int workgroups);
 // number of K parts for a decode-time split-K projection (gemm.hip): every unit on its own CU, <= max_parts
@@ -144,8 +145,8 @@ hipError_t launch_ln_fold_prep(const f16* W, const float* g, const float* b, con
                                float* c2, int N, int K, int centered, hipStream_t stream);
 // part[0][r] = (sum, sum of squares) of row r of the tile-major fp16 stream x [M][d]; part[1..nparts-1][r] = 0
 hipError_t launch_row_stats_tm(const f16* x_tm, float2* part, int M, int d, int nparts, hipStream_t stream);
-hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int nparts, size_t part_elems, size_t n,
-                                hipStream_t stream);
+hipError_t launch_fold_residual(void* x, int x_f16, const void* parts, int nparts, size_t part_elems, size_t n,
+                                hipStream_t stream, int parts_f16 = 0);
 // dst_f32[i] = float(src_f16[i])
 hipError_t launch_f16_to_f32(const f16* src, float* dst, size_t n, hipStream_t stream);
 
@@ -167,10 +168,11 @@ hipError_t launch_dec_embed(const int32_t* tok, const f16* table, const float* p
                             float* x, int rows, int d, int64_t vocab, hipStream_t stream);
 // x[r] += sum_z parts[z][r] (+ c[r / group] if c); h[r] = LN(x[r])   (parts/c may be null)
 // pf / pf_bytes: weights of a later GEMM that the CUs the row work leaves idle read ahead (common.hpp: prefetch_range)
-hipError_t launch_sum_layernorm(void* x, const float* parts, int nparts, size_t part_stride,
+// parts_f16: the slabs are fp16 (part_stride counts ELEMENTS either way)
+hipError_t launch_sum_layernorm(void* x, const void* parts, int nparts, size_t part_stride,
                                 const float* c, int group, const float* w, const float* b, float eps,
                                 f16* h, int rows, int d, hipStream_t stream, int h_tm = 0, int x_f16 = 0,
-                                const void* pf = nullptr, size_t pf_bytes = 0);
+                                const void* pf = nullptr, size_t pf_bytes = 0, int parts_f16 = 0);
 hipError_t launch_dec_attention(const f16* kv, const int32_t* anc, int anc_stride, f16* ctx, int rows,
                                 int rows_pad, int d, int heads, int pos, hipStream_t stream);
 constexpr int kVocabScanK2Max = 16;

@@ -742,8 +742,8 @@ hipError_t launch_pack_tile_major(const f16* src, f16* dst, int rows, int K, int
 // x[i] += sum_z parts[z][i] (fp32 adds in slab order, one rounding to the stream's type): the consumer of a
 // split-K GEMM that writes fp32 slabs (launch_gemm_tn_splitk; the bias sits in slab 0).  Small batches only
 // (api.hip): a K = 8192 GEMM with a handful of output tiles would otherwise run 256 K slices per tile on a few CUs.
-template <typename XT>
-__global__ __launch_bounds__(256) void fold_residual_kernel(XT* __restrict__ x, const float* __restrict__ parts,
+template <typename XT, typename PT>
+__global__ __launch_bounds__(256) void fold_residual_kernel(XT* __restrict__ x, const PT* __restrict__ parts,
                                                             int nparts, size_t part_elems, size_t n8) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     float acc[8];
@@ -763,12 +763,18 @@ __global__ __launch_bounds__(256) void fold_residual_kernel(XT* __restrict__ x, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum[e] = 0.f;
     for (int z = 0; z < nparts; ++z) {
-      const float* pz = parts + (size_t)z * part_elems + i * 8;
-      const f32x4 a = *(const f32x4*)pz, b = *(const f32x4*)(pz + 4);
+      const PT* pz = parts + (size_t)z * part_elems + i * 8;
+      if constexpr (sizeof(PT) == 2) {
+        const half8 hv = *(const half8*)pz;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sum[e] += a[e];
-        sum[4 + e] += b[e];
+        for (int e = 0; e < 8; ++e) sum[e] += (float)hv[e];
+      } else {
+        const f32x4 a = *(const f32x4*)pz, b = *(const f32x4*)(pz + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sum[e] += a[e];
+          sum[4 + e] += b[e];
+        }
       }
     }
     if constexpr (sizeof(XT) == 2) {
@@ -783,15 +789,20 @@ __global__ __launch_bounds__(256) void fold_residual_kernel(XT* __restrict__ x, 
   }
 }
 
-hipError_t launch_fold_residual(void* x, int x_f16, const float* parts, int nparts, size_t part_elems, size_t n,
-                                hipStream_t stream) {
+hipError_t launch_fold_residual(void* x, int x_f16, const void* parts, int nparts, size_t part_elems, size_t n,
+                                hipStream_t stream, int parts_f16) {
   if (n % 8 || nparts < 1) return hipErrorInvalidValue;
   const size_t n8 = n / 8;
   const int blocks = (int)std::min<size_t>((n8 + 255) / 256, 256 * 16);
-  if (x_f16)
-    hipLaunchKernelGGL(fold_residual_kernel<f16>, dim3(blocks), dim3(256), 0, stream, (f16*)x, parts, nparts, part_elems, n8);
-  else
-    hipLaunchKernelGGL(fold_residual_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)x, parts, nparts, part_elems, n8);
+#define SMI_FR(XT, PT)                                                                                               \
+  hipLaunchKernelGGL((fold_residual_kernel<XT, PT>), dim3(blocks), dim3(256), 0, stream, (XT*)x, (const PT*)parts, nparts, \
+                     part_elems, n8)
+  if (x_f16) {
+    if (parts_f16) SMI_FR(f16, f16); else SMI_FR(f16, float);
+  } else {
+    if (parts_f16) SMI_FR(float, f16); else SMI_FR(float, float);
+  }
+#undef SMI_FR
   return hipGetLastError();
 }
 
