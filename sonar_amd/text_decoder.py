@@ -259,8 +259,9 @@ class TextDecoderEngine:
         return max_len, min(plen + min_gen_len, max_len)
 
     def set_beam_logits_dtype(self, dtype: torch.dtype) -> None:
-        """Storage type of the logits inside generate() (smi_text_decoder_set_beam_logits_dtype): float16 is what the
-        reference's fp16 model produces (its tied final_proj is an fp16 Linear), float32 keeps the accumulators."""
+        """Storage type of the logits (and of the split-K partial sums of the two N = model_dim projections) inside generate()
+        (smi_text_decoder_set_beam_logits_dtype): float16 is what the reference's fp16 model produces (its tied final_proj is
+        an fp16 Linear, every sublayer output is fp16), float32 keeps the accumulators."""
         if dtype not in (torch.float16, torch.float32):
             raise ValueError("float16 or float32")
         _lib.check(self.lib.smi_text_decoder_set_beam_logits_dtype(
