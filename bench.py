@@ -168,6 +168,12 @@ def decoder_leg(dev, n=256, steps=64, cpu=True):
            "tokens_per_s": n * (steps + 1) / dt,
            "frac_of_mfma_peak": flop_step * (steps + 1) / dt / 1e12 / MFMA_PEAK_TFLOPS}
     out["chains"] = 1   # decode_chains(): one chain up to 2048 hypothesis rows
+    # what "fp16" means in this leg since round 4: fp16 operands into fp32 accumulators (as before), an fp32 residual stream,
+    # and -- because the model is an fp16 model -- fp16 STORAGE of the logits and of the split-K partial sums of the two
+    # N = model_dim projections (the reference's fp16 model rounds its logits and every sublayer output to fp16 too;
+    # smi_text_decoder_set_beam_logits_dtype).  SMI_DEC_LOGITS_F16=0 SMI_DEC_SLAB_F16=0 restore fp32 storage.
+    out["storage"] = {"logits": "f16 (tile-major, softmax statistics of the rounded values)", "split_k_partials": "f16",
+                      "residual_stream": "f32", "accumulation": "f32"}
     # the same decoder on a bucket twice as large: 2560 rows need a second round of FFN tiles as ONE chain, and run as two
     # independent chains by default (round 4); both timed, same engine, same embeddings
     try:
@@ -595,7 +601,9 @@ def main():
         c1_t = timed(lambda: model(c1_batch).sentence_embeddings, 20, 3)
         c1_gpu = model(c1_batch).sentence_embeddings.float().cpu()
         extra["c1"] = {"workload": "BASELINE configs[0] on the GPU engine: 32 sentences, lengths randint(8,65) seed 0, fp16",
-                       "tokens": int(c1_lens.sum()), "ms": c1_t / 20 * 1e3, "sentences_per_s": 32 * 20 / c1_t}
+                       "tokens": int(c1_lens.sum()), "ms": c1_t / 20 * 1e3, "sentences_per_s": 32 * 20 / c1_t,
+                       "storage": "fp16 residual stream (the fp16 model's), fp16 split-K partial sums summed in fp32 (round 4; "
+                                  "SMI_ENC_SLAB_F16=0: fp32 partials)"}
 
         # the reference's DEFAULT call: predict(..., batch_size=5) (sonar/inference_pipelines/text.py:178)
         b5_ids, b5_lens = O.synthetic_batch(5, 8, 64, V, seed=1)

@@ -55,6 +55,9 @@ def test_no_device_fails_loudly(lib):
     assert b"no HIP device" in lib.smi_last_error()
     with pytest.raises(_lib.SmiError):
         _lib.check(lib.smi_init(0))
+    # handle setters refuse a null handle instead of dereferencing it
+    assert lib.smi_text_decoder_set_beam_logits_dtype(None, _lib.SMI_F16) != 0
+    assert lib.smi_text_decoder_set_chains(None, 1) != 0
 
 
 def test_engine_refuses_cpu_and_missing_library(monkeypatch, tmp_path):
