@@ -202,20 +202,113 @@ def decoder_leg(dev, n=256, steps=64, cpu=True):
         ocfg = OD.OracleTextDecoderConfig()
         params = {k: v.float().cpu() for k, v in sd.items()}
         del sd
-        n_cpu, steps_cpu = 2, 12
-        e_cpu = emb[:n_cpu].float().cpu()
+        # Parity of the BENCHMARKED shape: one more untimed call on ALL n embeddings -- the same 1 280
+        # hypothesis rows, hence the same engines, split-K part counts and fp16 storage as the timed call -- and sentences
+        # spread over its row tiles (rows 0, 255|256|260, 635, 1 020|1 024, 1 275..1 279) against the oracle's incremental
+        # beam search on exactly those embeddings.  The same oracle run is the CPU baseline's timed sample.
+        steps_cpu = 12
+        picks = sorted({0, n // 5, n // 5 + 1, n // 2 - 1, (4 * n) // 5, n - 1})
+        n_cpu = len(picks)
+        e_cpu = emb[picks].float().cpu()
         kw = dict(beam_size=5, min_gen_len=steps_cpu, max_gen_len=(0, steps_cpu))
         t0 = time.perf_counter()
         ref = OD.beam_search_incremental(params, ocfg, e_cpu, [3, 256047], **kw)
         ct = time.perf_counter() - t0
-        toks, lens, _ = eng.generate(emb[:n_cpu], [3, 256047], **kw)
-        same = sum(toks[i, 0, : int(lens[i, 0])].tolist() == ref[i][0].seq.tolist() for i in range(n_cpu))
+        toks, lens, scores = eng.generate(emb, [3, 256047], **kw)
+        margins = eng.last_margins(n).cpu()
+        toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
+        lg = OD.decoder_logits(params, ocfg, e_cpu[:1], torch.tensor([[3, 256047]]))
+        eps = 1e-3 * float(lg.max() - lg.min())
+        same, mism, dscore = 0, [], 0.0
+        for j, i in enumerate(picks):
+            seq = toks[i, 0, : int(lens[i, 0])].tolist()
+            want = ref[j][0].seq.tolist()
+            if seq == want:
+                same += 1
+                dscore = max(dscore, abs(float(scores[i, 0]) - ref[j][0].score))
+            else:
+                mism.append({"sentence": i, "margins": [float(m) for m in margins[i]],
+                             "first_diff_at": next((t for t, (a, b) in enumerate(zip(seq, want)) if a != b), min(len(seq), len(want)))})
+        out["parity"] = {"call": f"generate() on all {n} embeddings ({n * 5} hypothesis rows: the timed call's engines and storage), "
+                                 f"beam 5, {steps_cpu + 1} decode steps",
+                         "sentences_checked": picks, "best_hypotheses_token_identical_to_oracle": f"{same}/{n_cpu}",
+                         "max_abs_score_diff_of_identical": dscore, "mismatches": mism,
+                         "near_tie_eps": eps,
+                         "all_mismatches_are_near_ties": all(min(m["margins"]) < eps for m in mism)}
         out["cpu_baseline"] = {"value": n_cpu * (steps_cpu + 1) / ct, "unit": "tokens/s", "cores": cores, "kind": "port",
-                               "sample": f"{n_cpu} sentences x beam 5 x {steps_cpu + 1} decode steps, oracle incremental beam search "
-                                         f"(K/V cache, fp32, same weights), one run of {ct:.1f} s",
+                               "sample": f"{n_cpu} sentences of the batch x beam 5 x {steps_cpu + 1} decode steps, oracle incremental beam "
+                                         f"search (K/V cache, fp32, same weights), one run of {ct:.1f} s",
                                "best_hypotheses_token_identical_to_gpu": f"{same}/{n_cpu}"}
         out["speedup_vs_cpu_tokens_per_s"] = out["tokens_per_s"] / out["cpu_baseline"]["value"]
     return out
+
+
+def e2e_leg(model, dev, n=16384, batch_size=1024):
+    """SURVEY 8 row f1 in the driver line: `TextToEmbeddingModelPipeline.predict()` on `n` synthetic strings -- SentencePiece
+    tokenisation, the native host input path (length sort, bucketing, collation, pinned staging), H2D copies and the encoder,
+    i.e. what the reference's predict() does per call (sonar/inference_pipelines/text.py:221-268).  There is no real NLLB
+    SentencePiece model on the box (no network), so a synthetic 32 k-piece unigram model is trained in-process on the same
+    synthetic corpus (tools/bench_e2e.py does the same); `$SONAR_CHECKPOINT_DIR/sentencepiece.source.256000.model` is used when
+    it exists.  Kernel-only headline and this number share the model object."""
+    import random
+    import tempfile
+
+    import sentencepiece as spm
+    import torch
+
+    from sonar_amd.inference_pipelines.text import TextToEmbeddingModelPipeline
+    from sonar_amd.tokenizer import NllbTokenizer
+
+    rnd = random.Random(0)
+    syll = ["ka", "lo", "mi", "ten", "sur", "pa", "ri", "vo", "da", "ne", "shi", "bu", "tra", "el", "on", "qu", "ix", "za"]
+    words = ["".join(rnd.choice(syll) for _ in range(rnd.randint(1, 4))) for _ in range(30000)]
+    cum, acc = [], 0.0
+    for i in range(len(words)):   # Zipf-like word frequencies
+        acc += 1.0 / (i + 1) ** 0.9
+        cum.append(acc)
+    texts = [" ".join(rnd.choices(words, cum_weights=cum, k=rnd.randint(20, 120))) for _ in range(n)]
+    real = os.path.join(os.environ.get("SONAR_CHECKPOINT_DIR", ""), "sentencepiece.source.256000.model")
+    with tempfile.TemporaryDirectory() as tmp:
+        if os.path.exists(real):
+            spm_path, spm_kind = real, "the released NLLB SentencePiece model"
+        else:
+            with open(os.path.join(tmp, "corpus.txt"), "w") as fh:
+                fh.write("\n".join(texts[:12000]))
+            spm.SentencePieceTrainer.train(input=os.path.join(tmp, "corpus.txt"), model_prefix=os.path.join(tmp, "e2e"),
+                                           vocab_size=32000, model_type="unigram", hard_vocab_limit=False, minloglevel=2)
+            spm_path, spm_kind = os.path.join(tmp, "e2e.model"), "synthetic 32k-piece unigram SentencePiece model trained in-process"
+        tok = NllbTokenizer(spm_path)
+        pipe = TextToEmbeddingModelPipeline(model, tok, device=dev)
+        enc = tok.create_encoder(lang="eng_Latn")
+        lens = [min(len(t), SEQ * 4) for t in enc.encode_batch(texts)]       # for the statistics only (untimed)
+        pipe.predict(texts[:2 * batch_size], source_lang="eng_Latn", batch_size=batch_size)   # warm-up
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = pipe.predict(texts, source_lang="eng_Latn", batch_size=batch_size)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        enc.encode_batch(texts)
+        tok_t = time.perf_counter() - t0
+    dt = min(ts)
+    # predict() sorts by CHARACTER length and cuts buckets of `batch_size`; the padded [b, max_len] id matrix is what crosses PCIe
+    # (the engine packs the tokens on the device: padding costs H2D bytes, not MFMA time)
+    order = sorted(range(n), key=lambda i: len(texts[i]))
+    padded = 0
+    for b in range(0, n, batch_size):
+        chunk = [lens[i] for i in order[b:b + batch_size]]
+        padded += max(chunk) * len(chunk)
+    ntok = sum(lens)
+    return {"workload": f"TextToEmbeddingModelPipeline.predict() on {n} synthetic strings (20-120 Zipf words each), batch_size "
+                        f"{batch_size}, eng_Latn: tokenisation + native host input path + H2D + encoder + un-sort, strings in, "
+                        f"[n, 1024] fp16 embeddings on the device out",
+            "tokenizer": spm_kind, "sentences_per_s": n / dt, "tokens_per_s": ntok / dt, "ms": dt * 1e3,
+            "runs_s": [round(t, 3) for t in ts], "tokens_per_sentence": ntok / n,
+            "pad_waste_pct_of_h2d_ids": 100.0 * (1 - ntok / padded),
+            "tokenise_only_sentences_per_s": n / tok_t,
+            "finite": bool(torch.isfinite(out).all()), "out_shape": list(out.shape)}
 
 
 def speech_leg(dev, n=64, cpu=True):
@@ -612,6 +705,12 @@ def main():
         extra["batch5"] = {"workload": "one predict() bucket at the reference's default batch_size=5: 5 sentences, lengths "
                                        "randint(8,65) seed 1, fp16 (text.py:178)",
                            "tokens": int(b5_lens.sum()), "ms": b5_t / 50 * 1e3, "sentences_per_s": 5 * 50 / b5_t}
+
+    if world == 1 and not args.no_extras and not DRYRUN:
+        try:
+            extra["e2e"] = e2e_leg(model, dev)
+        except Exception as e:  # an extra, never the reason the headline is lost
+            extra["e2e"] = {"error": repr(e)}
 
     if hasattr(model, "deferred_check"):
         model.engine.check()  # IndexError if any of the batches above held ids outside the embedding table

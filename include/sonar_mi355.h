@@ -142,9 +142,20 @@ const char* smi_version(void);
 /* ABI revision of this header: bumped whenever a struct grows, an argument list changes or a workspace formula
  * changes (round 2 = 2, round 3 = 3, ...).  A binding compares it with SMI_ABI_VERSION at load time and refuses a
  * library built from another revision (the structs carry no size field). */
-#define SMI_ABI_VERSION 4
+#define SMI_ABI_VERSION 5
 int smi_abi_version(void);
 const char* smi_last_error(void);
+/* Tuning registry (round 5).  Every A/B switch of the library -- engine-family thresholds, split-K part counts, storage
+ * types, layout choices; the list with meanings and defaults is sonar_amd/csrc/tuning.hpp, enumerated here by
+ * smi_tuning_name(0..) until it returns NULL -- is one process-wide integer that is set through these calls and read with
+ * an atomic load.  THE LIBRARY NEVER READS THE ENVIRONMENT: a host that calls none of them runs the shipped defaults, and
+ * results are a deterministic function of (inputs, batch row count, the switches set here) -- see INTEGRATION.md
+ * "Numerics contract".  `name` with or without the "SMI_" prefix.  (The reference has no counterpart: its kernels are
+ * ATen's, selected by torch's own heuristics.) */
+int smi_tuning_set(const char* name, int32_t value);
+int smi_tuning_unset(const char* name);
+int smi_tuning_get(const char* name, int32_t* value, int32_t* is_set);
+const char* smi_tuning_name(int32_t index);
 /* Selects the HIP device for this thread (hipSetDevice). */
 int smi_init(int device_id);
 int smi_device_count(void);
@@ -280,8 +291,8 @@ int smi_text_decoder_last_margins(smi_text_decoder* dec, float* out_margins, int
 /* Independent decode chains of smi_text_decoder_generate (round 4).  Sentences do not interact in
  * EmbeddingToTextModelPipeline.predict (sonar/inference_pipelines/text.py:329-346 decodes buckets of sentences), so a
  * large batch may run as `chains` sentence groups, each with its own workspace, KV cache, beam state, stream and host
- * thread: one group's per-launch fixed costs fall under the other's K loops.  0 = the engine's choice (environment
- * SMI_DEC_CHAINS, else the built-in default), 1 = one chain, up to 4.  Hypotheses equal the single chain's up to the
+ * thread: one group's per-launch fixed costs fall under the other's K loops.  0 = the engine's choice (tuning
+ * switch DEC_CHAINS, else the built-in default), 1 = one chain, up to 4.  Hypotheses equal the single chain's up to the
  * fp32 summation order of split-K slabs. */
 int smi_text_decoder_set_chains(smi_text_decoder* dec, int32_t chains);
 
@@ -289,11 +300,23 @@ int smi_text_decoder_set_chains(smi_text_decoder* dec, int32_t chains);
  * model produces fp16 logits (the tied final_proj is an fp16 Linear; fairseq2's beam search up-casts them inside
  * log_softmax, sonar/inference_pipelines/text.py:305-346 -> BeamSearchSeq2SeqGenerator), so SMI_F16 is what an fp16 model's
  * pipeline selects: the logits GEMM then rounds its fp32 accumulators to fp16 once, takes the softmax statistics of the
- * ROUNDED values and writes half the bytes (0.66 instead of 1.31 GB per position at 256 sentences x beam 5).  With SMI_F16 the
- * split-K partial sums of the attention-output and FFN-output projections are stored in fp16 as well (each partial rounded once,
- * summed in fp32 into the fp32 residual stream: the reference's fp16 model rounds every sublayer output to fp16).
+ * ROUNDED values and writes half the bytes (0.66 instead of 1.31 GB per position at 256 sentences x beam 5; since round 5 the
+ * default beam search does not store the logits at all -- the candidates are selected in the GEMM's epilogue, DESIGN.md 3.4 --
+ * and this setting only decides whether the values it compares are the rounded or the fp32 ones).
  * smi_text_decoder_logits and smi_text_decoder_sample keep fp32 logits and fp32 partial sums. */
 int smi_text_decoder_set_beam_logits_dtype(smi_text_decoder* dec, int32_t dtype);
+
+/* Storage type of the split-K PARTIAL sums of the attention-output and FFN-output projections inside
+ * smi_text_decoder_generate: SMI_F32 (default) or SMI_F16 (round 4; its own setting since round 5, it used to follow the
+ * logits dtype).  With SMI_F16 each partial is rounded to fp16 once -- SATURATING at +-65504 (MODE.FP16_OVFL), so a partial
+ * outside fp16's range cannot turn a representable sum into inf --, the consumer widens, sums in fp32 in slab order and adds to
+ * the fp32 residual stream.  The reference's fp16 model rounds the FULL sublayer output to fp16 once
+ * (sonar/inference_pipelines/text.py:36-54 puts the whole model in fp16); rounding 2-8 partials instead bounds the error by
+ * 2^-11 x the sum of the partials' magnitudes rather than of the result's -- the same order unless the K ranges cancel
+ * (tests/test_gpu_kernels.py::test_splitk_f16_slabs_cancellation_and_saturation).  It halves the 42 MB per layer the FFN
+ * output projection writes and the next kernel reads at 1 280 rows (-3.9 % of a C5 step).  An fp16 model's Python engine
+ * (TextDecoderEngine(dtype=float16)) selects it; a C caller gets fp32 partial sums unless it asks. */
+int smi_text_decoder_set_slab_dtype(smi_text_decoder* dec, int32_t dtype);
 
 /* Sampling generation (sonar/inference_pipelines/text.py:315-320: a `sampler` makes predict() build
  * fairseq2's SamplingSeq2SeqGenerator instead of the beam search; one hypothesis per sentence).
@@ -541,6 +564,11 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);
+/* Split-K form of the same product: parts[z][m][n] (slab_dtype SMI_F32 or SMI_F16, row-major, z < ksplit) = X[:, Kz] . W[:, Kz]^T
+ * (+ bias in part 0); the consumer sums the slabs (the decode step's and the small-batch encoder's N = model_dim
+ * projections).  fp16 slabs saturate at +-65504.  in_tm: x and w tile-major. */
+int smi_gemm_tn_splitk(const void* x_f16, const void* w_f16, const float* bias, void* parts, int32_t m, int32_t n, int32_t k,
+                       int32_t ksplit, int32_t in_tm, int32_t slab_dtype, void* stream);
 /* dst[i] = (dst_dtype) src[i] for n elements of DEVICE memory (dtypes: smi_dtype incl. SMI_BF16; fp32 -> bf16 rounds to
  * nearest even).  The bf16 side of the pipelines' `dtype=` argument: `model.to(device, dtype)` / the embeddings returned by
  * TextToEmbeddingModelPipeline.predict (sonar/inference_pipelines/text.py:161-162, 262-268). */

@@ -6,6 +6,7 @@ the library itself fails with SMI_ERR_NO_DEVICE when no MI355X is visible.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from pathlib import Path
@@ -234,7 +235,7 @@ class smi_mlp_head_layer(C.Structure):
     _fields_ = [("w", smi_tensor), ("b", smi_tensor), ("out_dim", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 4  # SMI_ABI_VERSION of include/sonar_mi355.h
+ABI_VERSION = 5  # SMI_ABI_VERSION of include/sonar_mi355.h
 
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -242,6 +243,10 @@ SYMBOLS = {
     "smi_version": (C.c_char_p, []),
     "smi_abi_version": (C.c_int, []),
     "smi_last_error": (C.c_char_p, []),
+    "smi_tuning_set": (C.c_int, [C.c_char_p, _i32]),
+    "smi_tuning_unset": (C.c_int, [C.c_char_p]),
+    "smi_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(_i32), C.POINTER(_i32)]),
+    "smi_tuning_name": (C.c_char_p, [_i32]),
     "smi_init": (C.c_int, [C.c_int]),
     "smi_device_count": (C.c_int, []),
     "smi_text_encoder_create": (C.c_int, [C.POINTER(smi_text_encoder_config),
@@ -262,6 +267,7 @@ SYMBOLS = {
     "smi_text_decoder_last_margins": (C.c_int, [_vp, _vp, _i32, _vp]),
     "smi_text_decoder_set_chains": (C.c_int, [_vp, _i32]),
     "smi_text_decoder_set_beam_logits_dtype": (C.c_int, [_vp, _i32]),
+    "smi_text_decoder_set_slab_dtype": (C.c_int, [_vp, _i32]),
     "smi_text_decoder_sample": (C.c_int, [_vp, _vp, _i32, _i32, C.POINTER(_i64), _i32,
                                           C.POINTER(smi_sampling_params), _vp, _vp, _vp, _vp]),
     "smi_sample_rows": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _i32, _i32, _f32, _vp,
@@ -280,6 +286,7 @@ SYMBOLS = {
     "smi_xsim_merge_topk": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "smi_xsim_margin_select": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "smi_gemm_tn_splitk": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "smi_mlp_head_create": (C.c_int, [C.POINTER(smi_mlp_head_config), C.POINTER(smi_mlp_head_layer), C.POINTER(_vp)]),
     "smi_mlp_head_destroy": (None, [_vp]),
     "smi_head_featurize": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -321,7 +328,64 @@ def load() -> C.CDLL:
         raise RuntimeError(f"{LIB_PATH} has ABI revision {lib.smi_abi_version()}, this binding speaks {ABI_VERSION}: "
                            "rebuild with `python -m sonar_amd.build --force`")
     _lib = lib
+    _forward_env_switches(lib)
     return lib
+
+
+def tuning_names() -> list:
+    """Names of the library's tuning switches (sonar_amd/csrc/tuning.hpp), without the SMI_ prefix."""
+    lib, out, i = load(), [], 0
+    while True:
+        nm = lib.smi_tuning_name(i)
+        if nm is None:
+            return out
+        out.append(nm.decode())
+        i += 1
+
+
+def _forward_env_switches(lib: C.CDLL) -> None:
+    """The library itself never reads the environment (include/sonar_mi355.h, tuning registry).  For the measurement tooling
+    (`env SMI_LONE=0 python tools/...`) this binding forwards `SMI_<NAME>=<int>` variables ONCE, when the library is loaded;
+    later changes of os.environ have no effect -- use `tuning()` / `set_tuning()`."""
+    i = 0
+    while True:
+        nm = lib.smi_tuning_name(i)
+        if nm is None:
+            break
+        i += 1
+        v = os.environ.get("SMI_" + nm.decode())
+        if v is None or v == "":
+            continue
+        try:
+            iv = int(v)
+        except ValueError:
+            raise RuntimeError(f"SMI_{nm.decode()}={v!r}: tuning switches are integers") from None
+        if lib.smi_tuning_set(nm, iv) != SMI_OK:
+            raise RuntimeError(lib.smi_last_error().decode("utf-8", "replace"))
+
+
+def set_tuning(**switches) -> None:
+    """set_tuning(LONE=0, DEC_KS_OUT=2): process-wide tuning switches (None unsets one)."""
+    lib = load()
+    for name, value in switches.items():
+        rc = lib.smi_tuning_unset(name.encode()) if value is None else lib.smi_tuning_set(name.encode(), int(value))
+        check(rc)
+
+
+@contextlib.contextmanager
+def tuning(**switches):
+    """with _lib.tuning(DEC_KS_OUT=2, G2_AUTO_MIN=1000000): ...  -- sets the switches, restores their previous state on exit."""
+    lib = load()
+    saved = {}
+    for name in switches:
+        v, st = _i32(0), _i32(0)
+        check(lib.smi_tuning_get(name.encode(), C.byref(v), C.byref(st)))
+        saved[name] = v.value if st.value else None
+    set_tuning(**switches)
+    try:
+        yield
+    finally:
+        set_tuning(**saved)
 
 
 def check(status: int) -> None:

@@ -17,6 +17,10 @@
 
 using namespace smi;
 
+namespace smi {
+std::atomic<int64_t> g_tune[TUNE_COUNT];  // tuning.hpp: zero-initialised = every switch unset
+}
+
 namespace smi_host {
 
 std::string& last_error() {
@@ -210,6 +214,29 @@ int check_cfg(const smi_text_encoder_config& c) {
 extern "C" {
 
 const char* smi_version(void) { return "sonar_mi355 0.1.0 (gfx950)"; }
+
+// ---- tuning registry (tuning.hpp): the only way a switch reaches the library ----
+int smi_tuning_set(const char* name, int32_t value) {
+  const int i = tune_index(name);
+  if (i < 0) return fail(SMI_ERR_INVALID_ARG, "unknown tuning switch '%s'", name ? name : "(null)");
+  g_tune[i].store((1ll << 40) | (int64_t)(uint32_t)value, std::memory_order_relaxed);
+  return SMI_OK;
+}
+int smi_tuning_unset(const char* name) {
+  const int i = tune_index(name);
+  if (i < 0) return fail(SMI_ERR_INVALID_ARG, "unknown tuning switch '%s'", name ? name : "(null)");
+  g_tune[i].store(0, std::memory_order_relaxed);
+  return SMI_OK;
+}
+int smi_tuning_get(const char* name, int32_t* value, int32_t* is_set) {
+  const int i = tune_index(name);
+  if (i < 0 || !value || !is_set) return fail(SMI_ERR_INVALID_ARG, "unknown tuning switch '%s'", name ? name : "(null)");
+  const int64_t v = g_tune[i].load(std::memory_order_relaxed);
+  *is_set = v != 0;
+  *value = v ? (int32_t)(uint32_t)(v & 0xffffffffll) : 0;
+  return SMI_OK;
+}
+const char* smi_tuning_name(int32_t index) { return tune_name(index); }
 int smi_abi_version(void) { return SMI_ABI_VERSION; }
 const char* smi_last_error(void) { return smi_host::last_error().c_str(); }
 
@@ -298,7 +325,7 @@ int smi_text_encoder_create(const smi_text_encoder_config* cfg, const smi_text_e
     // them: fp16 tile-major residual stream, d = 1024; SMI_ENC_LNFOLD=0 keeps the LayerNorm launches for A/B runs)
     // SMI_ENC_LNFOLD: 0 = LayerNorm launches, 1 = fold with the exact "- mean * c1" epilogue term, 2 (default) = fold with
     // row-centred weights (kernels.hpp: GemmLnFold.centered)
-    static const int lnfold_env = [] { const char* v = getenv("SMI_ENC_LNFOLD"); return v ? atoi(v) : 2; }();
+    const int lnfold_env = tune(TUNE_ENC_LNFOLD, 2);
     e->lnfold = lnfold_env > 0 && e->tile_major && e->x16 && d == 1024;
     e->lnfold_centered = lnfold_env == 2;
     if (rc == SMI_OK && e->lnfold) {
@@ -425,10 +452,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   // The fp16 residual stream itself is tile-major when everything that touches it has that path (d = 1024, no
   // encoded_seqs output): the residual epilogues of the attention-output and FFN-output GEMMs then read-modify-write
   // it straight from the accumulators instead of staging the tile through LDS in 8 barrier-separated passes.
-  static const bool x_tm_enabled = [] {  // SMI_ENC_X_TM=0: row-major residual stream (A/B measurements)
-    const char* v = getenv("SMI_ENC_X_TM");
-    return !(v && v[0] == '0');
-  }();
+  const bool x_tm_enabled = tune(TUNE_ENC_X_TM, 1) != 0;  // ENC_X_TM=0: row-major residual stream (A/B measurements)
   // Small batches: the FFN output projection (K = ffn_inner_dim) has (M/256)*(d/256) output tiles -- a handful of
   // CUs would each walk 256 K slices (C1, 1312 tokens: 130 us per layer, 3/4 of the forward).  It is then run as a
   // split-K GEMM into fp32 slabs (ks * tiles units, one round on the chip) that a small kernel folds into x.
@@ -442,7 +466,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
   // schedule for A/B runs): the attention output projection is split-K too (every 128x128 unit on a CU of its own, the
   // lone-tile ring engine), and the slabs of both projections are folded into the residual stream by the fused
   // sum + LayerNorm kernel that produces the next GEMM's input -- no separate fold, no separate LayerNorm.
-  static const bool sb_env = [] { const char* v = getenv("SMI_ENC_SB"); return !(v && v[0] == '0'); }();
+  const bool sb_env = tune(TUNE_ENC_SB, 1) != 0;
   const bool sb = sb_env && ffn2_ks > 1 && c.num_layers > 0;
   const int out_ks = sb ? gemm_splitk_parts((int)rows, d, d, 8) : 1;
   const int max_ks = std::max(ffn2_ks, out_ks);
@@ -492,7 +516,7 @@ int smi_text_encoder_forward(smi_text_encoder* e, const int64_t* ids, const int3
     // fp16 slabs for an fp16 residual stream (the fp16 model: the reference rounds every sublayer output to fp16; here each
     // split-K partial is rounded once, the sum is formed in fp32 and meets the stream in one rounding as before):
     // half the slab traffic between a projection and the kernel that folds it.  SMI_ENC_SLAB_F16=0: fp32 slabs (A/B runs)
-    static const bool slab_env = [] { const char* v = getenv("SMI_ENC_SLAB_F16"); return !(v && v[0] == '0'); }();
+    const bool slab_env = tune(TUNE_ENC_SLAB_F16, 1) != 0;
     const int sf16 = slab_env && x16;
     { ProfScope ps_(e, SMI_PROF_LAYERNORM, stream);  // x += FFN-output slabs of the previous layer; h = LN1(x)
     HIP_TRY(launch_sum_layernorm(x, l ? parts : nullptr, ffn2_ks, ps, nullptr, 1, L.ln1_w.as<float>(), L.ln1_b.as<float>(),
@@ -675,6 +699,21 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
     return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));
+  return SMI_OK;
+}
+
+int smi_gemm_tn_splitk(const void* x, const void* w, const float* bias, void* parts, int32_t m, int32_t n, int32_t k,
+                       int32_t ksplit, int32_t in_tm, int32_t slab_dtype, void* stream) {
+  if (!x || !w || !parts) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (slab_dtype != SMI_F16 && slab_dtype != SMI_F32) return fail(SMI_ERR_INVALID_ARG, "slab dtype %d: SMI_F16 or SMI_F32", slab_dtype);
+  if (m <= 0 || m % 128 || n <= 0 || n % 128 || k <= 0 || k % 64 || ksplit < 1 || ksplit > 16 ||
+      (in_tm && (m % 256 || n % 256)))
+    return fail(SMI_ERR_UNSUPPORTED, "split-K gemm shape m=%d n=%d k=%d ksplit=%d", m, n, k, ksplit);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  const hipError_t e = launch_gemm_tn_splitk((const f16*)x, (const f16*)w, bias, parts, m, n, k, ksplit, (hipStream_t)stream,
+                                             in_tm ? 1 : 0, slab_dtype == SMI_F16);
+  if (e == hipErrorInvalidValue) return fail(SMI_ERR_UNSUPPORTED, "split-K gemm: k=%d does not split into %d parts", k, ksplit);
+  HIP_TRY(e);
   return SMI_OK;
 }
 

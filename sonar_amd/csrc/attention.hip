@@ -261,10 +261,7 @@ hipError_t launch_attention(const f16* qkv, const int32_t* cu, f16* ctx, int N, 
   if (heads <= 0 || d != heads * 64 || N <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;  // Dh^-0.5 * log2(e)
   dim3 grid(N, heads, (max_len + AT_QB - 1) / AT_QB);
-  static const int order = [] {  // SMI_ATT_ORDER=0: head-major dispatch (A/B measurements)
-    const char* e = getenv("SMI_ATT_ORDER");
-    return e ? atoi(e) : 1;
-  }();
+  const int order = tune(TUNE_ATT_ORDER, 1);  // ATT_ORDER=0: head-major dispatch (A/B measurements)
   // ctx_tm: bit 0 = ctx written tile-major, bit 1 = qkv read tile-major
   switch (ctx_tm & 3) {
     case 0: hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, qkv, cu, ctx, d, sl2e, order); break;

@@ -38,6 +38,11 @@ __device__ __forceinline__ void store_nt(T* p, const T& v) {
   __builtin_nontemporal_store(v, p);
 }
 
+// MODE.FP16_OVFL (hardware register MODE, bit 23): with it set, a VALU fp16 result that overflows is clamped to +-65504
+// instead of becoming +-inf (true infinities still pass).  The waves that store split-K PARTIAL sums in fp16 set it at entry:
+// a partial above fp16's range must not turn a representable full sum into inf (tests/test_gpu_kernels.py).
+__device__ __forceinline__ void fp16_saturate_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
 // Cross-lane reductions: the whole wave (wave_sum / wave_max, result in every lane), and for the single-query
 // attention kernels (lane = 8 * pg + c) over the 8 lanes c of a position group and over the 8 position groups pg
 // with the lane's c kept.  DPP row operations and the gfx950 lane-swap

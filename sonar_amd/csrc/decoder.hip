@@ -203,18 +203,10 @@ static void launch_sum_ln_np(int blocks, hipStream_t stream, XT* x, const PT* pa
                              const float* c, int group, const float* w, const float* b, float eps, f16* h, int rows,
                              int h_tm, const void* pf, size_t pf_bytes) {
   // surplus workgroups for the weight prefetch: one per CU the row work leaves idle
-  int cus = 256;
-  {
-    int dev = 0;
-    static int cached[64];
-    (void)hipGetDevice(&dev);
-    if (!cached[dev & 63] && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-      cached[dev & 63] = cus;
-    if (cached[dev & 63]) cus = cached[dev & 63];
-  }
+  const int cus = num_cus();  // gemm.hip: per-device, atomically cached (decode chains call this from several host threads)
   // ... when the row work takes at most a quarter of the chip (<= 256 rows: the surplus then streams a 16.8 MB matrix in
   // one round trip; at 512 rows the prefetch cost more than it saved)
-  static const bool pf_env = [] { const char* v = getenv("SMI_PREFETCH"); return !(v && v[0] == '0'); }();
+  const bool pf_env = tune(TUNE_PREFETCH, 1) != 0;
   const int extra = pf_env && pf && pf_bytes && blocks * 4 <= cus ? cus - blocks : 0;
   const int main_blocks = blocks;
 #define SMI_SL(NP)                                                                                                     \

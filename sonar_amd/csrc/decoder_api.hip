@@ -36,15 +36,11 @@ constexpr int kMaxParts = 16;  // split-K slabs the `parts` buffer holds
 // SMI_DEC_LOGITS_GRID (persistent workgroups of a chained call's logits GEMM; 0 = all CUs)
 struct DecTuning {
   int ks_out = 0, ks_ffn = 0, ffn1_engine = -1, logits_grid = 0;
-  static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e && *e ? atoi(e) : dflt;
-  }
   void read() {
-    ks_out = env_int("SMI_DEC_KS_OUT", 0);
-    ks_ffn = env_int("SMI_DEC_KS_FFN", 0);
-    ffn1_engine = env_int("SMI_DEC_FFN1_ENGINE", -1);
-    logits_grid = env_int("SMI_DEC_LOGITS_GRID", 0);
+    ks_out = tune(TUNE_DEC_KS_OUT, 0);
+    ks_ffn = tune(TUNE_DEC_KS_FFN, 0);
+    ffn1_engine = tune(TUNE_DEC_FFN1_ENGINE, -1);
+    logits_grid = tune(TUNE_DEC_LOGITS_GRID, 0);
   }
 };
 
@@ -75,6 +71,7 @@ struct smi_text_decoder {
   int margins_n = 0;
   int chains = 0;       // smi_text_decoder_set_chains: 0 = SMI_DEC_CHAINS / the default
   int beam_logits_f16 = 0;  // smi_text_decoder_set_beam_logits_dtype: the beam search's logits are stored in fp16
+  int beam_slab_f16 = 0;    // smi_text_decoder_set_slab_dtype: the beam search's split-K partial sums are stored in fp16
   int64_t weight_bytes = 0;
   int ffn_tile_major = 0;  // FFN weights stored tile-major (d, f multiples of 256)
   // Generic-dimension mode (flex.hip): head_dim != 64 or dimensions the MFMA engines do not tile for (the reference's
@@ -188,7 +185,8 @@ int flex_decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, i
 // fp16 model produces fp16 logits too: fairseq2 up-casts them inside log_softmax) and takes the tile statistics of the
 // rounded values; needs the tile-major table copy.  Halves the 1.3 GB the 256 x 5-row step wrote per position.
 int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int group, int n_pad, int pos,
-                 const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f, int logits_f16 = 0) {
+                 const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f, int logits_f16 = 0,
+                 int slab_f16 = 0) {
   if (D->flex) return flex_decoder_step(D, S, rows, rows_pad, group, n_pad, pos, anc, anc_stride, stream, stats_scale);
   const smi_text_decoder_config& c = D->cfg;
   const int d = c.model_dim, f = c.ffn_inner_dim;
@@ -200,11 +198,11 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
   const int P = S.kv_positions;
   void* parts = S.parts.p;
   const size_t part_stride = (size_t)rows_pad * d;  // elements
-  // fp16 split-K slabs in the fp16 model's beam search (logits_f16: the reference rounds every sublayer output to fp16; here
-  // each partial is rounded once, the sum is formed in fp32 and added to the fp32 stream): half the 42 MB the FFN output
-  // projection wrote and the next kernel read per layer at 1280 rows.  SMI_DEC_SLAB_F16 = 0 / 1 overrides (A/B runs).
-  const int sf_env = DecTuning::env_int("SMI_DEC_SLAB_F16", -1);
-  const int sf16 = sf_env >= 0 ? (sf_env != 0) : logits_f16;
+  // fp16 split-K slabs in the fp16 model's beam search (smi_text_decoder_set_slab_dtype; its own setting since round 5: the
+  // reference rounds every sublayer output to fp16; here each partial is rounded once -- saturating at +-65504, never inf --,
+  // the sum is formed in fp32 and added to the fp32 stream): half the 42 MB the FFN output projection wrote and the next
+  // kernel read per layer at 1280 rows.  Tuning switch DEC_SLAB_F16 = 0 / 1 overrides (A/B runs).
+  const int sf16 = slab_f16;
   // Split-K parts of the two N = d projections.  FFN output (K = f): 8 parts of 32 K slices = 160 lone units at
   // 1280 rows; 10 / 12 parts (unequal K ranges, 200 / 240 units) were traced and are NOT faster -- a unit's K loop
   // shrinks 20.0 -> 15.3 us but its 256 KiB slab store grows 4.3 -> 6.4 us (the slab writes run at the chip's
@@ -340,7 +338,7 @@ constexpr int kKvInitialPositions = 160;
 // slower (kernel trace: 65 % of the time two kernels in flight, each longer than alone); from 2560 rows on the FFN tiles need
 // a second round and chains of ~1280 rows win, up to three of them (a fourth costs more in contention than it hides).
 int decode_chains(const smi_text_decoder* D, int n, int beam) {
-  const int env = DecTuning::env_int("SMI_DEC_CHAINS", 0);
+  const int env = tune(TUNE_DEC_CHAINS, 0);
   if (D->flex) return 1;
   const int64_t rows_pad = round_up((int64_t)n * beam, 256);
   const int automatic = rows_pad <= 2048 ? 1 : (int)std::min<int64_t>(3, (rows_pad + 1279) / 1280);
@@ -396,14 +394,16 @@ int generate_chain(smi_text_decoder* D, DecWork& S, const void* emb, int emb_dty
                            (int)prompt[0], stream));
   const float inv_temp = 1.0f / bp->temperature;
   // fp16 logits: the handle's setting (SMI_DEC_LOGITS_F16 = 0 / 1 overrides it: A/B runs), MFMA path with the tile-major table
-  const int lf_env = DecTuning::env_int("SMI_DEC_LOGITS_F16", -1);
+  const int lf_env = tune(TUNE_DEC_LOGITS_F16, -1);
   const int logits_f16 = !D->flex && D->embed_tm.p != nullptr && (lf_env >= 0 ? lf_env != 0 : D->beam_logits_f16 != 0);
+  const int sf_env = tune(TUNE_DEC_SLAB_F16, -1);
+  const int slab_f16 = !D->flex && (sf_env >= 0 ? sf_env != 0 : D->beam_slab_f16 != 0);
 
   // everything one decode step enqueues (position pos; ancestry/history buffer pos & 1)
   auto enqueue_step = [&](int pos, hipStream_t s) -> int {
     const int cur = pos & 1, step_nr = pos + 1;
     if (int rc = decoder_step(D, S, rows, rows_pad, beam, n_pad, pos, S.anc[cur].as<int32_t>(), stride, s, inv_temp,
-                              logits_f16))
+                              logits_f16, slab_f16))
       return rc;
     const bool forced_prompt = step_nr < prompt_len;
     const bool force_eos = !forced_prompt && step_nr == max_len - 1;
@@ -685,6 +685,13 @@ int smi_text_decoder_set_beam_logits_dtype(smi_text_decoder* D, int32_t dtype) {
   if (!D) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (dtype != SMI_F16 && dtype != SMI_F32) return fail(SMI_ERR_INVALID_ARG, "dtype %d: SMI_F16 or SMI_F32", dtype);
   D->beam_logits_f16 = dtype == SMI_F16;
+  return SMI_OK;
+}
+
+int smi_text_decoder_set_slab_dtype(smi_text_decoder* D, int32_t dtype) {
+  if (!D) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (dtype != SMI_F16 && dtype != SMI_F32) return fail(SMI_ERR_INVALID_ARG, "dtype %d: SMI_F16 or SMI_F32", dtype);
+  D->beam_slab_f16 = dtype == SMI_F16;
   return SMI_OK;
 }
 

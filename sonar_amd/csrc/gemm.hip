@@ -205,6 +205,9 @@ __global__ __launch_bounds__(GT_THREADS, RING ? 1 : 2) void gemm_tn_kernel(const
   // the consumer sums the slabs (decode-time GEMMs have too few tiles to fill 256 CUs otherwise)
   const int kz = blockIdx.y;
   const int klen = K / ksplit;
+  if constexpr (EPI == EPI_BIAS_F16) {
+    if (ksplit > 1) fp16_saturate_on();  // fp16 split-K partial sums saturate instead of overflowing to inf
+  }
   if constexpr (RING)
     gt_mainloop_ring<(LAYOUT > 0), RING>(acc, X, W, K, m0, n0, smem, kz * klen, klen);
   else
@@ -236,6 +239,9 @@ __global__ __launch_bounds__(GT_THREADS, (LoneShape<BM, BN>::WG_PER_CU)) void ge
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kz = blockIdx.y;
   const int klen = K / ksplit;
+  if constexpr (EPI == EPI_BIAS_F16) {
+    if (ksplit > 1) fp16_saturate_on();  // fp16 split-K partial sums saturate instead of overflowing to inf
+  }
   if (kz > 0) {
     bias = nullptr;
     out = (char*)out + (size_t)kz * part_stride;
@@ -383,6 +389,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   };
   const int ntm = M / G2_BM, ntn = N / G2_BN, ntiles = ntm * ntn * ksplit;
   void* out = out_;
+  if constexpr (EPI == EPI_BIAS_F16 && LAYOUT <= 1) {
+    if (ksplit > 1) fp16_saturate_on();  // fp16 split-K partial sums saturate instead of overflowing to inf
+  }
 #ifdef SMI_GEMM_TRACE
   int trace_i = 0;
   G2_TRACE(5);  // kernel entry
@@ -997,7 +1006,7 @@ extern "C" int smi_debug_gemm_trace(unsigned long long* host_out) {
 static thread_local int g2_grid_cap = 0;
 void set_gemm_grid_cap(int workgroups) { g2_grid_cap = workgroups; }
 
-static int num_cus() {
+int num_cus() {
   static std::atomic<int> cached[64];
   const int dev = DeviceOnce::dev();
   int n = cached[dev].load(std::memory_order_relaxed);
@@ -1021,10 +1030,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   }
   int grid = std::min((M / G2_BM) * (N / G2_BN) * ksplit, num_cus());
   if (g2_grid_cap > 0) grid = std::min(grid, g2_grid_cap);
-  static const int want_raster = [] {  // SMI_G2_RASTER=0 restores the id-order raster everywhere (A/B measurements)
-    const char* e = getenv("SMI_G2_RASTER");
-    return e ? atoi(e) : 2;
-  }();
+  const int want_raster = tune(TUNE_G2_RASTER, 2);  // G2_RASTER=0 restores the id-order raster everywhere (A/B measurements)
   const int ntm = M / G2_BM, ntn = N / G2_BN;
   // XCD-owned m-groups (see the kernel): whole chip, >= 4 n-quads, and a number of m-groups (8 row tiles each) that
   // deals evenly to the 8 XCDs -- otherwise the id-order raster balances better
@@ -1038,19 +1044,13 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
 
 // SMI_GT_RING: stages of round 3's lone-tile ring (0 = never use it, 4; default 4) -- A/B switch, used with SMI_LONE=0
 static int gt_ring_stages() {
-  static const int st = [] {
-    const char* e = getenv("SMI_GT_RING");
-    const int v = e ? atoi(e) : 4;
-    return v == 4 ? v : 0;
-  }();
-  return st;
+  return tune(TUNE_GT_RING, 4) == 4 ? 4 : 0;
 }
 
 // SMI_LONE: 0 = round 3's ring for every lone-tile launch (A/B runs; read per launch: decode-time paths switch it per
 // call), otherwise 64x64 units of the lone-tile engine (gemm_lone.hpp) when a launch is small enough for them.
 static bool lone_enabled() {
-  const char* e = getenv("SMI_LONE");
-  return !(e && e[0] == '0');
+  return tune(TUNE_LONE, 1) != 0;
 }
 // 64x64 units, two workgroups per CU (64 KiB of LDS each): used while all units are resident at once.  Measured
 // (profiles/r04_experiments.txt, experiment 11): at M = 256 / 512 every projection of the encoder is 25-35 % faster than on
@@ -1101,8 +1101,7 @@ static hipError_t launch_lone(const f16* X, const f16* W, const float* bias, voi
 // the k-sliced unit (gemm_lone16.hpp): tile-major operands, K per unit 256 / 512 / 1024.  SMI_LONE16=0: the LDS-ring unit
 // for every lone launch (A/B runs; its results are bit-identical to the other 128x128-family engines, these are not)
 static bool lone16_enabled() {
-  const char* e = getenv("SMI_LONE16");
-  return !(e && e[0] == '0');
+  return tune(TUNE_LONE16, 1) != 0;
 }
 template <int EPI, bool OUT_TM>
 static hipError_t launch_lone16(const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ldo,
@@ -1162,8 +1161,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   // 28.6 us hot, 31.8 vs 33.8 us on cold weights -> use it from 128 tiles (half the CUs) up
   // (SMI_G2_AUTO_MIN overrides the threshold, read per launch: tests that compare runs of different row counts bit for bit
   // pin the engine family with it)
-  const char* amin = getenv("SMI_G2_AUTO_MIN");
-  const int64_t auto_min = amin && *amin ? atoll(amin) : 128;
+  const int64_t auto_min = tune(TUNE_G2_AUTO_MIN, 128);
   const bool use256 = sel == 2 || (sel == 0 && can256 && (int64_t)(M / G2_BM) * (N / G2_BN) >= auto_min);
   if (fold) {  // LayerNorm fold: 256x256 engine, tile-major stream
     if (!can256 || sel == 1 || !in_tm || stats) return hipErrorInvalidValue;
@@ -1249,8 +1247,7 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
   // 160 tiles on 256 CUs still beat 640 small tiles); use it when the units roughly fill the chip once
   // and every unit has a real K loop (its K parts may be unequal)
   const int units256 = (M / G2_BM) * (N / G2_BN) * ksplit;
-  const char* mu = getenv("SMI_G2_SPLITK_MIN");  // A/B switch, read per launch (decode-time path: ~50 launches per step)
-  const int min_units = mu && *mu ? atoi(mu) : 96;
+  const int min_units = tune(TUNE_G2_SPLITK_MIN, 96);  // A/B switch (an atomic load per launch)
   const size_t ps = (size_t)M * N * (slab_f16 ? 2 : 4);
   const bool big = M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= min_units && units256 <= num_cus();
   if (!big && K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly
@@ -1283,8 +1280,7 @@ int gemm_splitk_parts(int M, int N, int K, int max_parts) {
     // ring unit), plus what every part adds around the launch (its slab is written here and read by the consumer:
     // 8 bytes per output element at ~20 TB/s, it is L2 / Infinity-Cache traffic); a unit keeps at least 4 K tiles.
     // SMI_LONE_KS overrides (A/B runs).
-    if (const char* e = getenv("SMI_LONE_KS")) {
-      const int v = atoi(e);
+    if (const int v = tune(TUNE_LONE_KS, 0)) {
       if (v >= 1 && v <= max_parts && K % (GT_BK * v) == 0 && (lone_fits(M, N, v) || ring_fits(M, N, v))) return v;
     }
     int best = 1;

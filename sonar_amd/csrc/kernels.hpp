@@ -6,7 +6,11 @@
 
 #include <atomic>
 
+#include "tuning.hpp"
+
 namespace smi {
+// compute units of the current device (per-device atomic cache; gemm.hip)
+int num_cus();
 // one-time per-DEVICE initialisation flag (function attributes, device-resident constants): a process
 // may drive several GPUs, so a plain `static bool` would skip the set-up on every device but the first
 struct DeviceOnce {

@@ -270,8 +270,7 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
   // GEMMs (N = K = d, the least efficient shape of the block) read both operands as linear 16 KiB bursts.  SMI_SPEECH_MID_TM=0
   // restores the row-major operands (A/B, read at create).
   {
-    const char* e = getenv("SMI_SPEECH_MID_TM");
-    E->mid_tm = E->ffn_tile_major && !(e && e[0] == '0');
+    E->mid_tm = E->ffn_tile_major && tune(TUNE_SPEECH_MID_TM, 1) != 0;
   }
   // Round 4: with every GEMM operand of a block tile-major, the fp16 residual stream can be tile-major too (the text
   // encoder's layout): the four residual GEMMs read-modify-write it straight from their accumulators (LAYOUT 3)
@@ -280,8 +279,7 @@ int smi_speech_encoder_create(const smi_speech_encoder_config* cfg, const smi_sp
   // per forward disappear.  The block-final LayerNorm rewrites the stream and stays a kernel (ln2, with the next block's
   // first LayerNorm).  SMI_SPEECH_X_TM=0 restores the row-major stream (A/B, read at create).
   {
-    const char* e = getenv("SMI_SPEECH_X_TM");
-    E->x_tm = E->mid_tm && E->x16 && d % 512 == 0 && !(e && e[0] == '0');
+    E->x_tm = E->mid_tm && E->x16 && d % 512 == 0 && tune(TUNE_SPEECH_X_TM, 1) != 0;
   }
   auto fold_prep = [&](const DevBuf& W, const DevBuf& g, const DevBuf& b, const float* bias, int64_t N, int64_t K,
                        DevBuf& Wf, DevBuf& c1, DevBuf& c2) -> int {

@@ -759,20 +759,12 @@ static int round_k(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
 
 // SMI_XSIM_TM=0: mine on the row-major normalised matrices (rounds 1-2) instead of tile-major copies -- A/B switch
 static bool xsim_tm() {
-  static const bool v = [] {
-    const char* e = getenv("SMI_XSIM_TM");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
+  return tune(TUNE_XSIM_TM, 1) != 0;
 }
 // SMI_XSIM_LL=0: per-lane top-k lists in registers (rounds 1-3; k = 8 then runs on the 128x128 engine) instead of the
 // per-row lists in LDS -- A/B switch, read once (the workspace formula depends on it)
 static bool xsim_ll() {
-  static const bool v = [] {
-    const char* e = getenv("SMI_XSIM_LL");
-    return e ? atoi(e) != 0 : true;
-  }();
-  return v;
+  return tune(TUNE_XSIM_LL, 1) != 0;
 }
 // top-1 keeps its list in registers (16 VGPRs, no pressure there: 436.7 vs 439.6 ms with LDS lists at 262 144 x 1 M); k >= 2
 // run on LDS lists: 475.1 -> 450.0 ms (k = 2), 545.7 -> 454.3 (k = 4), 657.9 -> 484.2 (k = 8, which the register version could

@@ -152,6 +152,13 @@ def _row_offsets(counts: Sequence[int]) -> List[int]:
     return offs
 
 
+def _no_candidates(nx_local: int, k: int, dev):
+    """The result of mining `nx_local` rows against NO candidates: [nx_local, k] lists of (-inf, -1), the padding a list with
+    fewer than k candidates carries (header of sharded_xsim_topk); [0, k] only for a rank without X rows."""
+    return (torch.full((nx_local, k), float("-inf"), dtype=torch.float32, device=dev),
+            torch.full((nx_local, k), -1, dtype=torch.int32, device=dev))
+
+
 def _ring_xsim_topk(be, xn, nx_local: int, y_local: torch.Tensor, k: int):
     """Forward mining with the Y shards ROTATED around the ranks instead of all-gathered: in step s a rank mines its X
     rows against the shard of rank (rank - s) mod ws while that shard travels on to rank + 1 (one isend + one irecv
@@ -191,7 +198,7 @@ def _ring_xsim_topk(be, xn, nx_local: int, y_local: torch.Tensor, k: int):
             r.wait()
         cur, nxt = nxt, cur
     if not nx_local or not ny:
-        return (torch.zeros((0, k), dtype=torch.float32, device=dev), torch.zeros((0, k), dtype=torch.int32, device=dev))
+        return _no_candidates(nx_local, k, dev)
     if len(part_s) == 1:
         return part_s[0], part_i[0]
     return be.merge_topk(torch.stack(part_s), torch.stack(part_i))
@@ -199,14 +206,13 @@ def _ring_xsim_topk(be, xn, nx_local: int, y_local: torch.Tensor, k: int):
 
 def sharded_xsim_topk(x_local: torch.Tensor, y_local: torch.Tensor, k: int = 1, backend=None, ring: bool = False):
     """Rows of X and Y are sharded over ranks (rank order = row order).  Returns, for the
-    local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k]).  `ring`: rotate the Y shards around the
+    local X rows, (scores [n_local,k], GLOBAL Y indices [n_local,k]; -inf / -1 where Y has fewer than k rows).  `ring`: rotate the Y shards around the
     ranks under the mining (see _ring_xsim_topk) instead of all-gathering Y first."""
     be = backend or EngineXsimBackend()
     rank, ws = world()
     nx_local, d = x_local.shape
     xn = be.normalize(x_local) if nx_local else None
-    empty = (torch.zeros((0, k), dtype=torch.float32, device=x_local.device),
-             torch.zeros((0, k), dtype=torch.int32, device=x_local.device))
+    empty = _no_candidates(nx_local, k, x_local.device)   # [n_local, k] of (-inf, -1): the contract holds for an empty Y too
     if ring and _collectives(ws):
         return _ring_xsim_topk(be, xn, nx_local, y_local, k)
     if not _collectives(ws):

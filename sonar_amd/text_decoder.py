@@ -200,6 +200,7 @@ class TextDecoderEngine:
         self._handle = handle
         del keep
         self.set_beam_logits_dtype(torch.float16 if dtype == torch.float16 else torch.float32)
+        self.set_slab_dtype(torch.float16 if dtype == torch.float16 else torch.float32)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -259,12 +260,20 @@ class TextDecoderEngine:
         return max_len, min(plen + min_gen_len, max_len)
 
     def set_beam_logits_dtype(self, dtype: torch.dtype) -> None:
-        """Storage type of the logits (and of the split-K partial sums of the two N = model_dim projections) inside generate()
-        (smi_text_decoder_set_beam_logits_dtype): float16 is what the reference's fp16 model produces (its tied final_proj is
-        an fp16 Linear, every sublayer output is fp16), float32 keeps the accumulators."""
+        """Type of the logits the beam search of generate() compares (smi_text_decoder_set_beam_logits_dtype): float16 is what
+        the reference's fp16 model produces (its tied final_proj is an fp16 Linear), float32 keeps the accumulators."""
         if dtype not in (torch.float16, torch.float32):
             raise ValueError("float16 or float32")
         _lib.check(self.lib.smi_text_decoder_set_beam_logits_dtype(
+            self._handle, _lib.SMI_F16 if dtype == torch.float16 else _lib.SMI_F32))
+
+    def set_slab_dtype(self, dtype: torch.dtype) -> None:
+        """Storage type of the split-K partial sums of the two N = model_dim projections inside generate()
+        (smi_text_decoder_set_slab_dtype; its own setting since round 5): float16 (an fp16 model's default here: the
+        reference's fp16 model rounds every sublayer output to fp16; partials saturate, they never become inf) or float32."""
+        if dtype not in (torch.float16, torch.float32):
+            raise ValueError("float16 or float32")
+        _lib.check(self.lib.smi_text_decoder_set_slab_dtype(
             self._handle, _lib.SMI_F16 if dtype == torch.float16 else _lib.SMI_F32))
 
     def set_chains(self, chains: int) -> None:
@@ -388,8 +397,14 @@ class SonarEncoderDecoderModel:
 
     def to(self, device=None, dtype=None):
         """The engines live on the HIP device they were created on; `.to` accepts that device and nothing else."""
-        if device is not None and torch.device(device).type != "cpu" and torch.device(device) != torch.device(self.device):
-            raise RuntimeError(f"the engine-backed model lives on {self.device}")
+        if device is not None and torch.device(device).type != "cpu":
+            want, have = torch.device(device), torch.device(self.device)
+            if want.type == "cuda" and want.index is None:      # `.to("cuda")`: the current device, as torch resolves it
+                want = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            if have.type == "cuda" and have.index is None:
+                have = torch.device("cuda", 0)
+            if want != have:
+                raise RuntimeError(f"the engine-backed model lives on {self.device}")
         return self
 
     def encode(self, seqs: torch.Tensor, padding_mask=None):

@@ -451,8 +451,16 @@ class SonarTextTransformerEncoderModel:
         prev, self.deferred_check = self.deferred_check, True
         try:
             yield self
-        finally:
+        except BaseException:
+            # the block failed for a reason of its own: drain and CLEAR the sticky device flag all the same (or the next,
+            # unrelated forward() would report this block's bad id), but let the original exception travel
             self.deferred_check = prev
+            try:
+                self.engine.check()
+            except Exception:
+                pass
+            raise
+        self.deferred_check = prev
         self.engine.check()
 
     def __call__(self, batch: SequenceBatch) -> SonarEncoderOutput:

@@ -2,6 +2,7 @@
 the product path has no CPU fallback and never touches the oracle."""
 import ctypes as C
 import os
+import pathlib
 import re
 import subprocess
 
@@ -83,3 +84,43 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_tuning_registry_and_no_environment_reads(monkeypatch):
+    """Round 5: every A/B switch is an integer of the tuning registry set through the C-ABI; the library
+    itself has no `getenv` (nm: the symbol is not even imported), so a production process cannot be steered -- or raced --
+    through os.environ.  The Python loader forwards SMI_<NAME> variables once, at load."""
+    import ctypes as C
+    import subprocess
+
+    from sonar_amd import _lib
+
+    lib = _lib.load()
+    names = _lib.tuning_names()
+    assert "LONE" in names and "DEC_KS_OUT" in names and "DEC_FUSED_SELECT" in names and len(set(names)) == len(names)
+    und = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    for src in (p for p in (pathlib.Path(ROOT) / "sonar_amd" / "csrc").iterdir() if p.suffix in (".hip", ".hpp", ".cpp")):
+        code = re.sub(r"//.*", "", src.read_text())
+        assert "getenv" not in code, src
+    v, st = C.c_int32(7), C.c_int32(7)
+    assert lib.smi_tuning_get(b"DEC_KS_OUT", C.byref(v), C.byref(st)) == 0 and st.value == 0
+    with _lib.tuning(DEC_KS_OUT=2, SMI_G2_AUTO_MIN=-5):          # with or without the SMI_ prefix; negative values survive
+        assert lib.smi_tuning_get(b"SMI_DEC_KS_OUT", C.byref(v), C.byref(st)) == 0 and (v.value, st.value) == (2, 1)
+        assert lib.smi_tuning_get(b"G2_AUTO_MIN", C.byref(v), C.byref(st)) == 0 and (v.value, st.value) == (-5, 1)
+        with _lib.tuning(DEC_KS_OUT=4):
+            lib.smi_tuning_get(b"DEC_KS_OUT", C.byref(v), C.byref(st))
+            assert v.value == 4
+        lib.smi_tuning_get(b"DEC_KS_OUT", C.byref(v), C.byref(st))
+        assert v.value == 2
+    assert lib.smi_tuning_get(b"DEC_KS_OUT", C.byref(v), C.byref(st)) == 0 and st.value == 0
+    assert lib.smi_tuning_set(b"NO_SUCH_SWITCH", 1) != 0 and b"NO_SUCH_SWITCH" in lib.smi_last_error()
+    # the loader's one-time forwarding
+    monkeypatch.setenv("SMI_LONE_KS", "4")
+    _lib._forward_env_switches(lib)
+    lib.smi_tuning_get(b"LONE_KS", C.byref(v), C.byref(st))
+    assert (v.value, st.value) == (4, 1)
+    _lib.set_tuning(LONE_KS=None)
+    monkeypatch.setenv("SMI_LONE_KS", "four")
+    with pytest.raises(RuntimeError, match="integers"):
+        _lib._forward_env_switches(lib)

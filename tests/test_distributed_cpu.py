@@ -219,5 +219,7 @@ def test_empty_inputs_single_process():
     y = torch.randn(7, 16)
     s, i = sharded_xsim_topk(e0, y, 2, backend=be)
     assert s.shape == (0, 2) and i.shape == (0, 2)
+    # X rows but an empty Y: one list per local row, padded as a list with fewer than k candidates is
     s, i = sharded_xsim_topk(y, e0, 2, backend=be)
-    assert s.shape == (0, 2) and i.shape == (0, 2)
+    assert s.shape == (7, 2) and i.shape == (7, 2)
+    assert torch.isinf(s).all() and (s < 0).all() and (i == -1).all() and i.dtype == torch.int32

@@ -173,7 +173,7 @@ def test_generate_is_repeatable_across_calls(setup):
 
 
 @pytest.mark.parametrize("chains", [2, 3])
-def test_independent_chains_return_the_single_chain_hypotheses(setup, chains, monkeypatch):
+def test_independent_chains_return_the_single_chain_hypotheses(setup, chains):
     """smi_text_decoder_set_chains: a batch decoded as 2 / 3 independent sentence groups (own workspace, KV cache,
     beam state, stream and host thread each) must return what the single chain returns -- hypotheses, lengths,
     scores, decision margins -- sentence for sentence and in input order, an uneven last group included.
@@ -183,8 +183,9 @@ def test_independent_chains_return_the_single_chain_hypotheses(setup, chains, mo
     n, beam = 301, 5          # 1505 rows; 2 chains: 151 + 150 sentences, 3 chains: 101 + 101 + 99
     emb = (torch.randn(n, ocfg.model_dim, generator=torch.Generator().manual_seed(99)) * 0.3).cuda()
     kw = dict(beam_size=beam, max_gen_len=(0, 30))
-    monkeypatch.setenv("SMI_DEC_KS_OUT", "2")        # read by the engine at the start of every generate() call
-    monkeypatch.setenv("SMI_DEC_FFN1_ENGINE", "1")
+    from sonar_amd import _lib
+
+    _lib.set_tuning(DEC_KS_OUT=2, DEC_FFN1_ENGINE=1)   # read by the engine at the start of every generate() call
     try:
         eng.set_chains(1)
         one = [t.cpu() for t in eng.generate(emb, [3, 702], **kw)]
@@ -198,14 +199,14 @@ def test_independent_chains_return_the_single_chain_hypotheses(setup, chains, mo
             eng.set_chains(c)
             dst.extend(t.cpu() for t in eng.generate(emb[:20], [3, 702], **kw))
         # the engine's own choice of tile shapes: only near-ties may differ (summation order of the split-K slabs)
-        monkeypatch.delenv("SMI_DEC_KS_OUT")
-        monkeypatch.delenv("SMI_DEC_FFN1_ENGINE")
+        _lib.set_tuning(DEC_KS_OUT=None, DEC_FFN1_ENGINE=None)
         eng.set_chains(1)
         free_one = eng.generate(emb, [3, 702], **kw)[0].cpu()
         eng.set_chains(chains)
         free_got = eng.generate(emb, [3, 702], **kw)[0].cpu()
     finally:
         eng.set_chains(0)
+        _lib.set_tuning(DEC_KS_OUT=None, DEC_FFN1_ENGINE=None)
     for a, b in zip(got, again):
         assert torch.equal(a, b)
     for a, b in zip(one, got):

@@ -115,9 +115,65 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
+@pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
+                                          (1280, 1024, 1024, 2, 0),      # its attention output projection: lone-tile units
+                                          (256, 1024, 8192, 8, 1),       # small-batch encoder: 64x64 lone units
+                                          (2816, 1024, 8192, 8, 1)])     # more than one round of 256x256 units: the 128x128 family
+def test_splitk_f16_slabs_cancellation_and_saturation(lib, m, n, k, ks, tm):
+    """fp16 split-K partial sums (smi_text_decoder_set_slab_dtype): (1) with K ranges that CANCEL -- partials of
+    magnitude ~2 000 whose sum is O(1) -- the fp16-slab result stays within 2^-11 x sum |partial| of the fp32-slab result (the
+    bound the header states; the reference rounds the full sum once and would keep ~1e-3 relative to the SUM); (2) a partial
+    outside fp16's range saturates at +-65504 instead of becoming inf, so the folded sum stays finite."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + k + ks)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    kp = k // ks
+    # make K parts 0 and 1 cancel: the same large rank-one term with opposite signs in x
+    x[:, :kp] = 0
+    x[:, kp:2 * kp] = 0
+    x[:, 0] = 40.0
+    x[:, kp] = -40.0
+    w[:, 0] = 50.0
+    w[:, kp] = 50.0           # partial 0 = +2000, partial 1 = -2000 everywhere (+ nothing else: the columns are zeroed)
+    bias = torch.randn(n, device="cuda", generator=g)
+    xa, wa = (to_tile_major(x), to_tile_major(w)) if tm else (x, w)
+
+    def run(dt):
+        parts = torch.full((ks, m, n), float("nan"), device="cuda", dtype=torch.float16 if dt == _lib.SMI_F16 else torch.float32)
+        _lib.check(lib.smi_gemm_tn_splitk(xa.data_ptr(), wa.data_ptr(), bias.data_ptr(), parts.data_ptr(), m, n, k, ks, tm,
+                                          dt, _stream()))
+        torch.cuda.synchronize()
+        return parts
+
+    p32, p16 = run(_lib.SMI_F32), run(_lib.SMI_F16)
+    ref = x.float() @ w.float().T + bias
+    s32, s16 = p32.sum(0), p16.float().sum(0)
+    assert torch.isfinite(p16).all()
+    assert (s32 - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1.0)
+    bound = p32.abs().sum(0) * 2.0 ** -11 + 1e-6
+    assert ((s16 - s32).abs() <= bound).all(), ((s16 - s32).abs() / bound).max().item()
+    assert p32[0].abs().min().item() > 1900 and p32[1].abs().min().item() > 1900      # the cancellation is really there
+    print(f"split-K fp16 slabs {m}x{n}x{k}/{ks}: max |sum16 - sum32| {(s16 - s32).abs().max().item():.3f} on sums of "
+          f"{s32.abs().max().item():.2f} with partials of {p32.abs().max().item():.0f}")
+
+    # saturation: partial 0 = +80 000, partial 1 = -80 000 (both outside fp16), the true sum is small
+    x[:, 0] = 200.0
+    x[:, kp] = -200.0
+    w[:, 0] = 400.0
+    w[:, kp] = 400.0
+    xa, wa = (to_tile_major(x), to_tile_major(w)) if tm else (x, w)
+    p16 = run(_lib.SMI_F16)
+    assert torch.isfinite(p16).all(), "an fp16 partial overflowed to inf (MODE.FP16_OVFL not in effect)"
+    assert p16[1].float().min().item() == -65504.0
+    assert p16[0].float().max().item() == 65504.0
+    assert torch.isfinite(p16.float().sum(0)).all()
+
+
 @pytest.mark.parametrize("m,n,k", [(128, 128, 64), (256, 384, 192), (256, 1024, 1024), (512, 2560, 128), (512, 4096, 256),
                                    (1024, 3072, 192), (256, 256, 4096), (256, 512, 512), (768, 256, 1024)])
-def test_gemm_lone_units(lib, monkeypatch, m, n, k):
+def test_gemm_lone_units(lib, m, n, k):
     """The lone-tile engine (gemm_lone.hpp, 64x64 units): K loops shorter / equal / longer than the ring (1, 2, 3, 4, 16,
     64 K tiles), one and two workgroups per CU (4 ... 512 units; 768 units: back on the 128x128 ring), row-major and
     tile-major operands, the fp16 / fp32 / read-modify-write epilogues -- against fp32 torch and BIT-identical to
@@ -156,17 +212,15 @@ def test_gemm_lone_units(lib, monkeypatch, m, n, k):
     if tm_ok:
         cases += [(0, 1, 1), (1, 1, 1), (3, 1, 0), (8, 1, 1), (6, 1, 0)]
     for epi, tm, out_tm in cases:
-        monkeypatch.setenv("SMI_LONE", "1")
-        monkeypatch.setenv("SMI_LONE16", "0")     # the LDS-ring unit: same MFMA order over K as the ring
-        got = run(epi, tm, out_tm)
-        monkeypatch.setenv("SMI_LONE", "0")
-        old = run(epi, tm, out_tm)
+        with _lib.tuning(LONE=1, LONE16=0):       # the LDS-ring unit: same MFMA order over K as the ring
+            got = run(epi, tm, out_tm)
+        with _lib.tuning(LONE=0):
+            old = run(epi, tm, out_tm)
         assert torch.equal(got, old), (epi, tm, out_tm)
         # the k-sliced unit (gemm_lone16.hpp: tile-major operands, K per unit 256 / 512 / 1024; everything else falls through to
         # the ring unit): its own summation order, equal within fp32 rounding of the accumulation
-        monkeypatch.setenv("SMI_LONE", "1")
-        monkeypatch.setenv("SMI_LONE16", "1")
-        got16 = run(epi, tm, out_tm)
+        with _lib.tuning(LONE=1, LONE16=1):
+            got16 = run(epi, tm, out_tm)
         d16 = (got16.float() - got.float()).abs().max().item()
         assert d16 <= (2e-3 if epi != 3 else 2e-5) * max(got.float().abs().max().item(), 1.0), (epi, tm, out_tm, d16)
         got = got16
