@@ -23,6 +23,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// 4 B per lane (LDS destination = wave-uniform base + lane*4): per-tile constants (bias slices, row statistics) that travel with
+// a tile's pipeline fill instead of through registers
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 4, 0, 0);
+}
+
 // glds16 with the non-temporal cache policy (aux = 2, `nt`): for lines that exactly ONE workgroup reads, once.
 __device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(SMI_GLOBAL_PTR(gsrc), SMI_LDS_PTR(lds_wave_base), 16, 0, 2);

@@ -271,6 +271,9 @@ __global__ __launch_bounds__(L16_THREADS, 2) void gemm_lone16_kernel(const f16* 
   lone_tile_coords(M / L16_BM, N / L16_BN, tile_m, tile_n);
   const int m0 = tile_m * L16_BM, n0 = tile_n * L16_BN;
   const int kz = blockIdx.y;
+  if constexpr (EPI == EPI_BIAS_F16) {
+    if (gridDim.y > 1) fp16_saturate_on();  // fp16 split-K partial sums saturate instead of overflowing to inf
+  }
   if (kz > 0) {
     bias = nullptr;
     out = (char*)out + (size_t)kz * part_stride;
@@ -357,6 +360,12 @@ __device__ unsigned long long g2_trace_buf[16 * 64 * 8];
 // id = round * gridDim + xcd_remap(block).  The pipeline fill of tile i+1 is issued before the
 // epilogue of tile i, and the epilogue leaves through two small staging buffers outside ring slots
 // 0..2 (gemm_tile256.hpp), so the ~2 us fill latency of the 32-slice (K = 1024) tiles is hidden.
+// -DSMI_G2_STORE_OVERLAP=0: tile starts drain the previous tile's stores (rounds 1-4) -- A/B builds
+#ifndef SMI_G2_STORE_OVERLAP
+#define SMI_G2_STORE_OVERLAP 1
+#endif
+constexpr bool G2_STORE_OVERLAP = SMI_G2_STORE_OVERLAP != 0;
+
 template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
                                                                 const f16* __restrict__ W,
@@ -409,19 +418,41 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   const int tid = threadIdx.x;
   auto fetch_bias = [&](int n0, int kz) {  // one value per thread (tid < 256): ONE register held across the epilogue
     float v = 0.f;
-    if (bias && kz == 0 && tid < 256) v = bias[n0 + tid];
+    if constexpr (!(G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3))) {
+      if (bias && kz == 0 && tid < 256) v = bias[n0 + tid];
+    }
     return v;
   };
   // fold consumer: the tile's c1 slice, and (mean, rstd) of its 256 rows from the producers' partial sums -- fetched with
   // the pipeline fill like the bias, parked in LDS next to it (floats 256..511; half sums at 1536..), zeros at 1024.. for the
   // accumulators' start value (the bias slot holds c2, which is added AFTER the row scaling)
   float* c1_lds = bias_lds + 256;
-  float* zero_lds = bias_lds + 1024;
+  // Round 5 -- register-direct epilogues (LAYOUT 2 / 3): the per-tile constants travel by LDS-DMA with the tile's pipeline fill
+  // (DMA_CONST) instead of through registers.  A value handed over in a VGPR (`bias_lds[tid] = bias_next` at the tile start)
+  // made hipcc drain the vector-memory queue there (s_waitcnt vmcnt(0): at a loop head its count of younger operations is
+  // pessimistic), and with it the previous tile's 16 output stores -- 2.7 us of a 26.6 us K = 1024 tile (round-2
+  // experiment 26) that can run under the next tile's first K slices instead (gemm_tile256.hpp: pend16).  The constants
+  // are then READ with asm loads (issue + wait in one statement), which hipcc's LDS-DMA alias tracking does not guard.
+  constexpr bool DMA_CONST = G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3);
+  float* zero_lds = bias_lds + (DMA_CONST ? 7936 : 1024);   // DMA_CONST: clear of the statistics / row-sum scratch below
+  float* statraw_lds = bias_lds + 4096;                     // DMA_CONST fold consumer: [4 partials][256 rows] (sum, sum of squares)
   float2* rowsum_lds = (float2*)(bias_lds + 1536);  // fold producer: [4 column waves][256 rows]
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto issue_consts = [&](int m0n, int n0n, int kzn) {
+    if constexpr (DMA_CONST) {
+      if (bias && kzn == 0 && wave_u < 4) glds4(bias + n0n + tid, bias_lds + wave_u * 64);
+      if (folded) {
+        const float* ps = (const float*)fold.part_in + (size_t)m0n * 2 + tid;   // 512 floats per partial, one per thread
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp)
+          if (pp < fold.nparts) glds4(ps + (size_t)pp * M * 2, statraw_lds + pp * 512 + wave_u * 64);
+      }
+    }
+  };
   auto fetch_c1 = [&](int n0) {
     float v = 0.f;
     if constexpr (FOLD_EXACT) {
-      if (folded && tid < 256) v = fold.c1[n0 + tid];
+      if (folded && !fold.centered && tid < 256) v = fold.c1[n0 + tid];
     }
     return v;
   };
@@ -431,7 +462,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   struct RawStat { float2 a, b; };
   auto fetch_rowstat = [&](int m0) {
     RawStat r{{0.f, 0.f}, {0.f, 0.f}};
-    if (folded) {
+    if (!DMA_CONST && folded) {
       const int p = tid >> 8, row = m0 + (tid & 255);
       if (p < fold.nparts) r.a = fold.part_in[(size_t)p * M + row];
       if (p + 2 < fold.nparts) r.b = fold.part_in[(size_t)(p + 2) * M + row];
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     return r;
   };
   float2* stat_lds = (float2*)(bias_lds + 1536);  // [2][256] half sums, joined after the barrier of g2_begin
-  if (FOLD_CONSUMER && tid < 256) zero_lds[tid] = 0.f;  // published by the barrier of the first g2_begin
+  if ((FOLD_CONSUMER || DMA_CONST) && tid < 256) zero_lds[tid] = 0.f;  // published by the barrier of the first g2_begin
 
   // unit id = kz * (ntm * ntn) + output tile: neighbouring ids share operand panels of one K part
   const int nout = ntm * ntn;
@@ -484,15 +515,19 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   float bias_next = fetch_bias(tile_n * G2_BN, kz);
   float c1_next = fetch_c1(tile_n * G2_BN);
   RawStat stat_next = fetch_rowstat(tile_m * G2_BM);
+  issue_consts(tile_m * G2_BM, tile_n * G2_BN, kz);
   g2_prefetch(src, nt, smem);
 
+  bool first_tile = true;  // no stores of a previous tile in the queue
   while (tile < nvirt) {
     const int m0 = tile_m * G2_BM, n0 = tile_n * G2_BN;
     const int tile_n_cur = tile_n;
     (void)tile_n_cur;
     out = (char*)out_ + (size_t)kz * part_stride;
     G2_TRACE(0);
-    if (tid < 256) bias_lds[tid] = bias_next;
+    if constexpr (!DMA_CONST) {
+      if (tid < 256) bias_lds[tid] = bias_next;
+    }
     if constexpr (FOLD_CONSUMER_ST) {
       // the staged epilogue of the previous tile went through this staging buffer: the accumulators' zero start value
       // has to be written again (the register-direct tile-major epilogues never touch it)
@@ -500,12 +535,37 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     }
     if (folded) {
       if constexpr (FOLD_EXACT) {
-        if (tid < 256) c1_lds[tid] = c1_next;
+        if (!fold.centered && tid < 256) c1_lds[tid] = c1_next;
       }
-      stat_lds[tid] = float2{stat_next.a.x + stat_next.b.x, stat_next.a.y + stat_next.b.y};
+      if constexpr (!DMA_CONST) stat_lds[tid] = float2{stat_next.a.x + stat_next.b.x, stat_next.a.y + stat_next.b.y};
     }
     GemmTile256Acc acc;
-    g2_begin(acc, folded ? zero_lds : bias_lds);
+    // register-direct epilogues (tile-major fp16 store, tile-major residual read-modify-write): 16 stores per lane and tile
+    // (plus, on some waves, a row-sum / statistics store), no LDS staging -- they may overlap the next tile's first two K slices
+    // (gemm_tile256.hpp: pend16).  Needs >= 5 K slices per unit (the counted waits of iterations 0, 1 assume that slices 3, 4
+    // are issued there) and a previous tile of this workgroup.
+    const bool pend16 = DMA_CONST && nt >= 5 && !first_tile;
+    if constexpr (DMA_CONST) {
+      // g2_begin with the start values read by an asm load: kz > 0 parts of a split-K launch and bias-less GEMMs start from
+      // zeros, a fold consumer too (its bias slot holds c2, added after the row scaling)
+      if (pend16)
+        SMI_WAIT_VMCNT(16);
+      else
+        SMI_WAIT_VMCNT(0);
+      SMI_LGKM0_BARRIER();  // slices 0..2 and the constants complete for everyone
+      const float* isrc = (folded || !bias || kz != 0) ? zero_lds : bias_lds;
+      const char* ip[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) ip[ni] = (const char*)(isrc + wc * 64 + ni * 16 + 4 * kg);
+      f32x4 iv[4];
+      lds_read_stage<4>(ip, iv);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc.v[ni][mi] = iv[ni];
+    } else {
+      g2_begin(acc, folded ? zero_lds : bias_lds, false);
+    }
     // Fold consumer: what the epilogue needs stays in REGISTERS, spread over the wave, and is fetched there with
     // ds_bpermute (a lane crossbar, no LDS memory access): after the next tile's LDS-DMA fill has been issued, hipcc puts
     // `s_waitcnt vmcnt(0)` in front of every LDS load (its alias tracking cannot tell the ring from the constant area),
@@ -516,17 +576,44 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     float2 row_sq[2] = {{0.f, 0.f}, {0.f, 0.f}};  // (sum, sum of squares) of the lane's two rows
     float col_c1 = 0.f, col_c2 = 0.f;
     if (folded) {
+      if constexpr (DMA_CONST) {
+        // the raw partials of the lane's two rows, summed in the order of the register path: (p0 + p2) + (p1 + p3)
+        float2 pr[2][4];
+        float c2v;
+        asm volatile(
+            "ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:2048\n\tds_read_b64 %2, %9 offset:4096\n\t"
+            "ds_read_b64 %3, %9 offset:6144\n\tds_read_b64 %4, %9 offset:512\n\tds_read_b64 %5, %9 offset:2560\n\t"
+            "ds_read_b64 %6, %9 offset:4608\n\tds_read_b64 %7, %9 offset:6656\n\tds_read_b32 %8, %10\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(pr[0][0]), "=&v"(pr[0][1]), "=&v"(pr[0][2]), "=&v"(pr[0][3]), "=&v"(pr[1][0]), "=&v"(pr[1][1]),
+              "=&v"(pr[1][2]), "=&v"(pr[1][3]), "=&v"(c2v)
+            : "v"((unsigned)(size_t)(statraw_lds + (wr * 128 + lane) * 2)), "v"((unsigned)(size_t)(bias_lds + wc * 64 + lane))
+            : "memory");
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int row = wr * 128 + u * 64 + lane;
-        const float2 h0 = stat_lds[row], h1 = stat_lds[256 + row];
-        row_sq[u] = float2{h0.x + h1.x, h0.y + h1.y};
+        for (int u = 0; u < 2; ++u) {
+          const float2 z = {0.f, 0.f};
+          const float2 p0 = pr[u][0], p1 = fold.nparts > 1 ? pr[u][1] : z, p2 = fold.nparts > 2 ? pr[u][2] : z,
+                       p3 = fold.nparts > 3 ? pr[u][3] : z;
+          row_sq[u] = float2{(p0.x + p2.x) + (p1.x + p3.x), (p0.y + p2.y) + (p1.y + p3.y)};
+        }
+        col_c2 = c2v;
+        if constexpr (FOLD_EXACT) {
+          if (!fold.centered) col_c1 = c1_lds[wc * 64 + lane];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = wr * 128 + u * 64 + lane;
+          const float2 h0 = stat_lds[row], h1 = stat_lds[256 + row];
+          row_sq[u] = float2{h0.x + h1.x, h0.y + h1.y};
+        }
+        if constexpr (FOLD_EXACT) col_c1 = c1_lds[wc * 64 + lane];
+        col_c2 = bias_lds[wc * 64 + lane];
       }
-      if constexpr (FOLD_EXACT) col_c1 = c1_lds[wc * 64 + lane];
-      col_c2 = bias_lds[wc * 64 + lane];
     }
     G2_TRACE(1);
-    g2_mainloop(acc, src, nt, smem);
+    g2_mainloop(acc, src, nt, smem, pend16);
+    first_tile = false;
     G2_TRACE(2);
     tile = seek(tile + (int)gridDim.x);  // (tile_m, tile_n) now name the NEXT tile; m0 / n0 keep this one
     if (tile < nvirt) {  // fill for the next tile, behind this tile's epilogue
@@ -536,6 +623,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       bias_next = fetch_bias(tile_n * G2_BN, kz);  // before the fill: see above
       c1_next = fetch_c1(tile_n * G2_BN);
       stat_next = fetch_rowstat(tile_m * G2_BM);
+      issue_consts(tile_m * G2_BM, tile_n * G2_BN, kz);
       g2_prefetch(src, nt, smem);
     }
     G2_TRACE(3);

@@ -133,8 +133,14 @@ __device__ __forceinline__ void g2_prefetch(const G2Src& s, int nt, char* smem) 
 // stores (vmcnt does not tell loads from stores) and the bias slice written to LDS by the caller; after
 // this only counted waits.  The accumulators start from the bias of their columns (bias_lds: the
 // tile's 256 bias values, zeros if there is none), so no epilogue has to add it.
-__device__ __forceinline__ void g2_begin(GemmTile256Acc& acc, const float* bias_lds) {
-  SMI_WAIT_VMCNT(0);
+// pend16 (round 5, register-direct epilogues only): the previous tile's >= 16 vector-memory operations per wave that were
+// issued AFTER the fill -- its 16 output stores -- may stay in flight: vmcnt retires vector-memory operations in issue order
+// on this ISA, so the fill is complete when at most 16 operations are outstanding.
+__device__ __forceinline__ void g2_begin(GemmTile256Acc& acc, const float* bias_lds, bool pend16 = false) {
+  if (pend16)
+    SMI_WAIT_VMCNT(16);
+  else
+    SMI_WAIT_VMCNT(0);
   SMI_LGKM0_BARRIER();  // slices 0..2 and the bias slice complete for everyone
   const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) & 3;
 #pragma unroll
@@ -145,8 +151,11 @@ __device__ __forceinline__ void g2_begin(GemmTile256Acc& acc, const float* bias_
   }
 }
 
-// K loop of one tile (after g2_begin).
-__device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& src, int nt, char* smem) {
+// K loop of one tile (after g2_begin).  pend16: see g2_begin -- the stores sit between the fill (slices 0..2) and the DMA of
+// slices 3, 4 in the queue, so the waits of iterations 0 and 1 ("my part of slice t + 1 has landed", t + 1 <= 2) tolerate
+// them; iteration 2 needs slice 3, which is younger than the stores, and so retires them: the store burst of a tile (16 x
+// 1 KiB per wave, ~2.7 us at the CU's store rate, round-2 experiment 26) overlaps the first two K slices of the next tile.
+__device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& src, int nt, char* smem, bool pend16 = false) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,7 +179,10 @@ __device__ __forceinline__ void g2_mainloop(GemmTile256Acc& acc, const G2Src& sr
     for (int mi = 0; mi < 8; ++mi) fx[mi] = *(const half8*)(slot + xoff + mi * 1024);
     if (t + 3 < nt) {
       g2_issue(src, t + 3, smem, wave);
-      SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
+      if (pend16 && t < 2)
+        SMI_WAIT_VMCNT(24);  // ... and the previous tile's >= 16 stores, which are older than slices 3, 4 but younger than 0..2
+      else
+        SMI_WAIT_VMCNT(8);  // my part of slice t+1 has landed; t+2, t+3 stay in flight
     } else if (t + 2 < nt) {
       SMI_WAIT_VMCNT(4);
     } else {

@@ -234,10 +234,12 @@ def test_beam_logits_storage_type(setup):
     try:
         for dt in (torch.float32, torch.float16):
             eng.set_beam_logits_dtype(dt)
+            eng.set_slab_dtype(dt)
             toks, lens, scores = [t.cpu() for t in eng.generate(emb, prompt, **kw)]
             out[dt] = (toks, lens, scores, eng.last_margins(n).cpu())
     finally:
         eng.set_beam_logits_dtype(torch.float16)
+        eng.set_slab_dtype(torch.float16)
     with pytest.raises(ValueError):
         eng.set_beam_logits_dtype(torch.bfloat16)
     t32, l32, s32, m32 = out[torch.float32]

@@ -440,12 +440,14 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
     try:
         for dt in (torch.float16, torch.float32):
             eng.set_beam_logits_dtype(dt)
+            eng.set_slab_dtype(dt)
             toks, lens, scores = [t.cpu() for t in eng.generate(emb.cuda().half(), prompt, **kw)]
             margins = eng.last_margins(n).cpu()
-            assert (lens[:, 0] == steps + 1).all()
+            assert (lens[:, 0] == steps).all()           # min_gen_len == max_gen_len: every hypothesis ends at the cap
             _check_hyps_vs_oracle(f"256 sentences, {dt} storage", ref, toks, lens, scores, margins, C5_SAMPLE, eps, 1)
     finally:
         eng.set_beam_logits_dtype(torch.float16)
+        eng.set_slab_dtype(torch.float16)
 
     # (3) twice the batch: the sampled embeddings sit at the even positions, so sentences 0..254 / 256..510 fall into both chains
     g2 = torch.Generator().manual_seed(78)
