@@ -300,9 +300,7 @@ int smi_text_decoder_set_chains(smi_text_decoder* dec, int32_t chains);
  * model produces fp16 logits (the tied final_proj is an fp16 Linear; fairseq2's beam search up-casts them inside
  * log_softmax, sonar/inference_pipelines/text.py:305-346 -> BeamSearchSeq2SeqGenerator), so SMI_F16 is what an fp16 model's
  * pipeline selects: the logits GEMM then rounds its fp32 accumulators to fp16 once, takes the softmax statistics of the
- * ROUNDED values and writes half the bytes (0.66 instead of 1.31 GB per position at 256 sentences x beam 5; since round 5 the
- * default beam search does not store the logits at all -- the candidates are selected in the GEMM's epilogue, DESIGN.md 3.4 --
- * and this setting only decides whether the values it compares are the rounded or the fp32 ones).
+ * ROUNDED values and writes half the bytes (0.66 instead of 1.31 GB per position at 256 sentences x beam 5).
  * smi_text_decoder_logits and smi_text_decoder_sample keep fp32 logits and fp32 partial sums. */
 int smi_text_decoder_set_beam_logits_dtype(smi_text_decoder* dec, int32_t dtype);
 

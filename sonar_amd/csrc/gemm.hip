@@ -360,11 +360,18 @@ __device__ unsigned long long g2_trace_buf[16 * 64 * 8];
 // id = round * gridDim + xcd_remap(block).  The pipeline fill of tile i+1 is issued before the
 // epilogue of tile i, and the epilogue leaves through two small staging buffers outside ring slots
 // 0..2 (gemm_tile256.hpp), so the ~2 us fill latency of the 32-slice (K = 1024) tiles is hidden.
-// -DSMI_G2_STORE_OVERLAP=0: tile starts drain the previous tile's stores (rounds 1-4) -- A/B builds
+// -DSMI_G2_STORE_OVERLAP=1: per-tile constants by LDS-DMA + the previous tile's stores left in flight under the first two K slices
+// (round 5 experiment 1: QKV -1.2 %, FFN-inner +2 %, C2 step +0.65 % -- NEGATIVE, the default stays 0; profiles/r05_experiments.txt)
 #ifndef SMI_G2_STORE_OVERLAP
-#define SMI_G2_STORE_OVERLAP 1
+#define SMI_G2_STORE_OVERLAP 0
 #endif
 constexpr bool G2_STORE_OVERLAP = SMI_G2_STORE_OVERLAP != 0;
+// -DSMI_G2_OVERLAP_BIAS_TM=1: the same for the <EPI_BIAS_F16, tile-major out> instantiation only (the encoder's QKV projection,
+// which gained 1.4 % in experiment 1, and the decoder's logits GEMM)
+#ifndef SMI_G2_OVERLAP_BIAS_TM
+#define SMI_G2_OVERLAP_BIAS_TM 0
+#endif
+constexpr bool G2_OVERLAP_BIAS_TM = SMI_G2_OVERLAP_BIAS_TM != 0;
 
 template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   const int tid = threadIdx.x;
   auto fetch_bias = [&](int n0, int kz) {  // one value per thread (tid < 256): ONE register held across the epilogue
     float v = 0.f;
-    if constexpr (!(G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3))) {
+    if constexpr (!((G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3)) || (G2_OVERLAP_BIAS_TM && EPI == EPI_BIAS_F16 && LAYOUT == 2))) {
       if (bias && kz == 0 && tid < 256) v = bias[n0 + tid];
     }
     return v;
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
   // pessimistic), and with it the previous tile's 16 output stores -- 2.7 us of a 26.6 us K = 1024 tile (round-2
   // experiment 26) that can run under the next tile's first K slices instead (gemm_tile256.hpp: pend16).  The constants
   // are then READ with asm loads (issue + wait in one statement), which hipcc's LDS-DMA alias tracking does not guard.
-  constexpr bool DMA_CONST = G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3);
+  constexpr bool DMA_CONST = (G2_STORE_OVERLAP && (LAYOUT == 2 || LAYOUT == 3)) ||
+                             (G2_OVERLAP_BIAS_TM && EPI == EPI_BIAS_F16 && LAYOUT == 2);
   float* zero_lds = bias_lds + (DMA_CONST ? 7936 : 1024);   // DMA_CONST: clear of the statistics / row-sum scratch below
   float* statraw_lds = bias_lds + 4096;                     // DMA_CONST fold consumer: [4 partials][256 rows] (sum, sum of squares)
   float2* rowsum_lds = (float2*)(bias_lds + 1536);  // fold producer: [4 column waves][256 rows]
@@ -678,8 +686,107 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     // (round 4: also with the tile-major fp16 store -- an fp16 model's logits are fp16 in the reference, the statistics are
     // then taken of the ROUNDED values, i.e. of exactly what the selection kernels will read)
     constexpr bool STATS_F16 = EPI == EPI_BIAS_F16 && LAYOUT == 2;
+    bool stats_stored = false;  // the fused statistics + store pass below has written the tile
+    (void)stats_stored;
+#ifndef SMI_STATS_FUSED
+#define SMI_STATS_FUSED 1
+#endif
+    if constexpr (STATS_F16 && SMI_STATS_FUSED) {
+      // Round 5: statistics of the fp16 logits and their tile-major store in ONE pass over the accumulators, every tile but the
+      // last column tile (whose padding columns need masking: the general code below).  Counted in the ISA, the round-4
+      // statistics cost ~12 VALU issue slots per element (128 elements per lane and tile): two conversions (round to fp16 and
+      // back), a multiply by scale * log2 e, TWO v_cndmask of the valid-column mask (the runtime `!full` test had been turned
+      // into selects on every element of every tile), max, subtract, v_exp_f32 (quarter rate), add -- and the store then
+      // converted every value again.  Here: ONE packed conversion shared by the store and the statistics (v_cvt_pk_f16_f32),
+      // the unpack, the maximum of the RAW rounded values (scale > 0: max and scaling commute, bit for bit), the scaled
+      // exponent as one v_pk_fma_f32 per two values, packed adds: ~8 slots per element, and the 16 stores of a wave leave
+      // spread over the pass instead of as one burst behind it.
+      if (stats.tile_max && n0 + G2_BN <= stats.valid_n && !folded) {
+        stats_stored = true;
+        float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
+        const float sc2 = stats.scale * 1.4426950408889634f;
+        const int cidx = (kg & 1) * 2 + (kg >> 1);
+        const int sw = tm_swz(l15);
+        f16* lane0 = (f16*)out + ((size_t)(m0 >> 8) * (N >> 5) + (n0 >> 5) + wc * 2) * TM_BLOCK +
+                     (wr * 128 + l15) * 32 + ((cidx ^ sw) << 3);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+          uint32_t h[4][2];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) {
+            const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(acc.v[ni][mi]));
+            h[ni][0] = hp.x;
+            h[ni][1] = hp.y;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {  // the store of store_tile (MODE 0) below
+            const auto s0 = __builtin_amdgcn_permlane16_swap(h[2 * j][0], h[2 * j + 1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(h[2 * j][1], h[2 * j + 1][1], false, false);
+            const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
+#ifndef SMI_PROBE_NOSTORE  // probe build (wrong results on purpose): what ANY scheme that never stores the logits could save
+            store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
+#else
+            if (chunk[0] == 0x12345678u && stats.valid_n < 0) store_nt((u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)), chunk);
+#endif
+          }
+          f32x2 t[8];  // the lane's 16 ROUNDED values of the row
+          float mx = -INFINITY;
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const half2v hv = __builtin_bit_cast(half2v, h[ni][q]);
+              t[ni * 2 + q] = f32x2{(float)hv[0], (float)hv[1]};
+              mx = fmaxf(mx, fmaxf(t[ni * 2 + q][0], t[ni * 2 + q][1]));
+            }
+          {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+          }
+          const float mxs = mx * sc2;                        // the row maximum in the log2 domain, as the general code has it
+          const float nb = mxs == -INFINITY ? 0.f : -mxs;
+          const f32x2 sc22 = {sc2, sc2}, nb2 = {nb, nb};
+          f32x2 se2 = {0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f32x2 a = __builtin_elementwise_fma(t[e], sc22, nb2);
+            se2 += f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+          }
+          float se = se2[0] + se2[1];
+          {
+            const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(se), __float_as_uint(se), false, false);
+            se = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+            const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(se), __float_as_uint(se), false, false);
+            se = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+          }
+          if (kg == 0) lds_write_b64_asm(&red[(wr * 128 + mi * 16 + l15) * 4 + wc], float2{mxs, se});
+        }
+        SMI_LGKM0_BARRIER();
+        if (tid < 256) {
+          f32x4 r01, r23;
+          {
+            const char* rp[2] = {(const char*)&red[tid * 4], (const char*)&red[tid * 4 + 2]};
+            f32x4 rv[2];
+            lds_read_stage<2>(rp, rv);
+            r01 = rv[0];
+            r23 = rv[1];
+          }
+          const float2 a0 = {r01[0], r01[1]}, a1 = {r01[2], r01[3]}, a2 = {r23[0], r23[1]}, a3 = {r23[2], r23[3]};
+          const float m = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+          const float ms = m == -INFINITY ? 0.f : m;
+          const float sum = a0.y * __builtin_amdgcn_exp2f(a0.x - ms) + a1.y * __builtin_amdgcn_exp2f(a1.x - ms) +
+                            a2.y * __builtin_amdgcn_exp2f(a2.x - ms) + a3.y * __builtin_amdgcn_exp2f(a3.x - ms);
+          const size_t o = (size_t)tile_n_cur * M + m0 + tid;
+          stats.tile_max[o] = m * 0.6931471805599453f;
+          stats.tile_sum[o] = sum;
+        }
+      }
+    }
     if constexpr (EPI == EPI_STORE_F32 || STATS_F16) {
-      if (stats.tile_max) {
+      if (stats.tile_max && !stats_stored) {
         // softmax statistics of this tile's 256 columns for each of its 256 rows (the decoder's logits
         // GEMM, no bias): branch-free and lane-local over the lane's 16 values of a row in the log2
         // domain (t = v * scale * log2 e, one v_exp_f32 per element), joined across the 4 lane groups
@@ -1026,7 +1133,9 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
         }
       };
       if constexpr (FOLD_CONSUMER) {
-        if (!folded)
+        if (stats_stored) {
+          // written by the fused statistics + store pass
+        } else if (!folded)
           store_tile(std::integral_constant<int, 0>{});
         else if (fold.centered || !FOLD_EXACT)
           store_tile(std::integral_constant<int, 2>{});
