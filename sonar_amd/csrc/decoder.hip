@@ -630,175 +630,12 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
   }
 }
 
-// Round 5: the same selection with ONE WAVE per row and no barrier.  The workgroup version above is a chain of 2 x k2 rounds,
-// each closed by __syncthreads (46 us per step at 1 280 rows: ~2.3 us per round, all of it barrier + LDS latency); a wave does
-// a round in ~45 VALU instructions on DPP / lane swaps.  What makes one wave enough: after the k2 best tiles are known, their
-// k2-th maximum T is a lower bound of the k2-th best VALUE (the k2 tile maxima are k2 distinct elements), so every candidate
-// below T -- all but a dozen of the ~4 400 values read -- is dropped before the ordered arg-max rounds; a lane rescans its
-// slots only in the rare round it wins with a second live candidate left.  Lane l reads 8 consecutive tokens (16 B fp16 /
-// 32 B fp32) of a selected tile; two tiles per load instruction.  Same total orders, same masks, same output as above
-// (tests/test_gpu_decoder.py compares the two kernels' lists bit for bit through the DEC_SELECT_WAVE switch).
-template <bool F16TM, int TPL>
-__global__ __launch_bounds__(256) void vocab_select_wave_kernel(const float* __restrict__ logits, int ldl, int vocab, int rows,
-                                                                const float* __restrict__ tile_max,
-                                                                const float* __restrict__ tile_sum, int ntiles,
-                                                                int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
-                                                                int unk_idx, float unk_penalty, int block_eos,
-                                                                float* __restrict__ pmax, float* __restrict__ psum,
-                                                                float* __restrict__ pval, int* __restrict__ pidx) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;  // wave-uniform
-  const float* tm = tile_max + row;  // [tile][stat_rows]
-  const float* ts = tile_sum + row;
-  float m[TPL], sm[TPL];
-  float lm = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < TPL; ++j) {
-    const int t = lane + 64 * j;
-    m[j] = t < ntiles ? tm[(size_t)t * stat_rows] : -INFINITY;
-    sm[j] = t < ntiles ? ts[(size_t)t * stat_rows] : 0.f;
-    lm = fmaxf(lm, m[j]);
-  }
-  // ---- 1. softmax normaliser of the row
-  const float M = wave_max(lm);
-  float se = 0.f;
-#pragma unroll
-  for (int j = 0; j < TPL; ++j)
-    if (m[j] != -INFINITY) se += sm[j] * __expf(m[j] - M);
-  se = wave_sum(se);
-  if (lane == 0) {
-    pmax[row] = M;
-    psum[row] = se;
-  }
-  if (k2 == 0) return;
-  // ---- 2a. the k2 best tiles among tiles >= 1 (value desc, tile asc); lane j keeps the j-th selected tile, lane 0 tile 0
-  unsigned long long tk[TPL];
-  unsigned long long tbest = 0ull;
-#pragma unroll
-  for (int j = 0; j < TPL; ++j) {
-    const int t = lane + 64 * j;
-    tk[j] = (m[j] != -INFINITY && t != 0) ? cand_key(m[j], t) : 0ull;
-    tbest = tk[j] > tbest ? tk[j] : tbest;
-  }
-  int mysel = 0;
-  int nsel = 1;
-  float thr = -INFINITY;  // the k2-th best tile maximum once k2 tiles are selected
-  for (int round = 0; round < k2; ++round) {
-    const unsigned long long b = wave_max_u64(tbest);
-    if (b == 0ull) break;  // fewer than k2 tiles
-    if (lane == nsel) mysel = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
-    ++nsel;
-    if (round == k2 - 1) {
-      unsigned u = (unsigned)(b >> 32);
-      u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-      thr = __uint_as_float(u);
-    }
-    if (b == tbest) {  // exactly one lane: the keys carry the tile index
-      tbest = 0ull;
-#pragma unroll
-      for (int j = 0; j < TPL; ++j) {
-        if (tk[j] == b) tk[j] = 0ull;
-        tbest = tk[j] > tbest ? tk[j] : tbest;
-      }
-    }
-  }
-  // the tile statistics went through (v * scale * log2 e) * ln 2, the candidates below are v * inv_temp: a few ulps apart.
-  // Dropping is an optimisation only, so the bound is lowered by more than that difference.
-  if (thr != -INFINITY) thr -= fabsf(thr) * 4e-6f + 1e-30f;
-  // ---- 2b. lane l owns tokens 8 (l & 31) .. + 7 of the tiles sel[2 p + (l >> 5)], p = 0 .. 8
-  constexpr int NP = (VSEL_SLOTS + 1) / 2;
-  unsigned long long ck[NP][8];
-  unsigned long long cbest = 0ull;
-  int nlive = 0;
-  const int half = lane >> 5, g = lane & 31;
-#pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    const int slot = 2 * p + half;
-    const int tile = __shfl(mysel, slot < 64 ? slot : 0, 64);
-    const bool have = slot < nsel;
-    const int tok0 = tile * 256 + g * 8;
-    float v8[8];
-    if (have) {
-      if constexpr (F16TM) {
-        const half8 hv = *(const half8*)((const f16*)logits + tm_offset(row, tok0, ldl));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v8[e] = (float)hv[e];
-      } else {
-        const f32x4 a = *(const f32x4*)(logits + (size_t)row * ldl + tok0), b4 = *(const f32x4*)(logits + (size_t)row * ldl + tok0 + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v8[e] = a[e];
-          v8[4 + e] = b4[e];
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      ck[p][e] = 0ull;
-      const int tok = tok0 + e;
-      if (have && tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
-        float v = v8[e] * inv_temp;
-        if (tok == unk_idx) v -= unk_penalty;
-        if (v != -INFINITY && v >= thr) {
-          ck[p][e] = cand_key(v, tok);
-          ++nlive;
-        }
-      }
-      cbest = ck[p][e] > cbest ? ck[p][e] : cbest;
-    }
-  }
-  // ---- 2c. ordered top-k2 by k2 wave-wide arg-max rounds
-  for (int round = 0; round < k2; ++round) {
-    const unsigned long long b = wave_max_u64(cbest);
-    if (lane == 0) {
-      float val = -INFINITY;
-      int idx = 0x7fffffff;
-      if (b != 0ull) {
-        unsigned u = (unsigned)(b >> 32);
-        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-        val = __uint_as_float(u);
-        idx = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
-      }
-      pval[(size_t)row * VS_K2MAX + round] = val;
-      pidx[(size_t)row * VS_K2MAX + round] = idx;
-    }
-    if (b != 0ull && b == cbest) {  // one lane (the keys carry the token)
-      cbest = 0ull;
-      if (--nlive > 0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            if (ck[p][e] == b) ck[p][e] = 0ull;
-            cbest = ck[p][e] > cbest ? ck[p][e] : cbest;
-          }
-      }
-    }
-  }
-}
-
 hipError_t launch_vocab_select(const float* logits, int ldl, int f16_tm, int rows, int vocab, const float* tile_max,
                                const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream) {
   if (rows <= 0 || stat_rows < rows || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
     return hipErrorInvalidValue;
-  // one wave per row (round 5); DEC_SELECT_WAVE=0: the workgroup-per-row kernel (A/B runs, and the twin of the parity test).
-  // The 16-B / 32-B candidate reads need ldl % 8 == 0 (the logits buffers are padded to 256 columns).
-  if (tune(TUNE_DEC_SELECT_WAVE, 1) != 0 && ldl % 8 == 0) {
-    const dim3 grid((rows + 3) / 4);
-#define SMI_VSW(F, T)                                                                                                        \
-  hipLaunchKernelGGL((vocab_select_wave_kernel<F, T>), grid, dim3(256), 0, stream, logits, ldl, vocab, rows, tile_max, tile_sum, \
-                     ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx)
-    if (ntiles <= 1024) {
-      if (f16_tm) SMI_VSW(true, 16); else SMI_VSW(false, 16);
-    } else {
-      if (f16_tm) SMI_VSW(true, 32); else SMI_VSW(false, 32);
-    }
-#undef SMI_VSW
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, f16_tm, vocab, tile_max, tile_sum,
                      ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
   return hipGetLastError();
