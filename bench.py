@@ -336,8 +336,17 @@ def speech_leg(dev, n=64, cpu=True):
         emb = run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # flops of one forward (matrix products only; T = 499 conformer frames per 10 s clip, d = 1024, F = 4096, 24 blocks):
+    # per frame and block 2 x 16 d F / 2 (two macaron FFNs) + 8 d^2 (q|k|v|out) + 2 d^2 (relative-position projection) +
+    # 6 d^2 (pointwise conv 1, GLU-doubled, and 2) + attention 4 T d (+ 4 T d relative scores); frame stacking GEMM and the
+    # 3-layer pooler are < 1 %
+    frames = 499
+    d_, f_ = 1024, 4096
+    flop_frame_block = 2 * (4 * d_ * f_) + 2 * (4 * d_ * d_) + 2 * d_ * d_ + 2 * (3 * d_ * d_) + 8 * frames * d_
+    flops = n * frames * 24 * flop_frame_block
     out = {"workload": f"sonar_speech_encoder_eng fp16, {n} clips x 10 s @ 16 kHz, GPU fbank + 24 conformer blocks + pooler",
-           "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt}
+           "ms": dt * 1e3, "clips_per_s": n / dt, "audio_seconds_per_s": n * 10 / dt,
+           "tflop_per_forward": flops / 1e12, "frac_of_mfma_peak": flops / dt / 1e12 / MFMA_PEAK_TFLOPS}
     if cpu:
         from oracle import speech_encoder as OS
 

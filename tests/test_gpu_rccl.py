@@ -44,3 +44,15 @@ def test_bench_multi_gpu_branch_over_rccl_with_one_rank():
     print("RCCL init:", rec["collective"].get("rccl_init_lines"))
     assert rec["n_gpus"] == 1 and rec["value"] > 0
     assert rec["xsim"]["top1_agreement_with_constructed_neighbours"] == 1.0
+
+
+def test_bench_xsim_ring_branch_over_rccl_with_one_rank():
+    """bench.py's `--xsim-ring` branch (Y shards rotated around the ranks under the mining) through the nccl
+    backend: with one forced rank the shard travels once around the one-rank ring -- isend / irecv to self in one RCCL group
+    call (sonar_amd/distributed.py) -- and the copy that arrived is mined; top-1 must still be the constructed neighbours."""
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--xsim-ring",
+                "--no-cpu-baseline", "--no-extras", "--xsim-n", "32768"], {"SONAR_BENCH_FORCE_DIST": "1"})
+    rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert rec["collective"]["backend"] == "nccl"
+    assert rec["xsim"]["y_exchange"].startswith("ring")
+    assert rec["xsim"]["top1_agreement_with_constructed_neighbours"] == 1.0
