@@ -181,9 +181,10 @@ def _ring_xsim_topk(be, xn, nx_local: int, y_local: torch.Tensor, k: int):
     cur[: yn_local.shape[0]] = yn_local
     nxt = torch.empty_like(cur)
     part_s, part_i = [], []
-    if ws == 1 and _force_collectives:
-        # a forced one-rank run (tests/test_gpu_rccl.py): the loop below never posts a transfer, so send the shard once
-        # around the one-rank "ring" -- isend + irecv to self through the backend -- and mine the copy that ARRIVED
+    if ws == 1 and _force_collectives and dist.get_backend() == "nccl":
+        # a forced one-rank run over RCCL (tests/test_gpu_rccl.py): the loop below never posts a transfer, so send the shard
+        # once around the one-rank "ring" -- isend + irecv to self in one group call (gloo has no self-send) -- and mine the
+        # copy that ARRIVED
         for r in dist.batch_isend_irecv([dist.P2POp(dist.isend, cur, 0), dist.P2POp(dist.irecv, nxt, 0)]):
             r.wait()
         cur, nxt = nxt, cur
