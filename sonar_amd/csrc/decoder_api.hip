@@ -51,7 +51,6 @@ struct DecWork {
   DevBuf anc[2], hist[2];
   DevBuf pmax, psum, pval, pidx;
   DevBuf tile_max, tile_sum;  // logits-GEMM tile statistics [rows_pad][vocab_pad / 256]
-  DevBuf sparse_cls;          // sparse logits store: class maxima [k2][rows_pad] followed by the bound [rows_pad] (kernels.hpp)
   int kv_positions = 0;       // positions per layer in the current kv allocation
   bool chained = false;       // this call runs next to other chains: per-launch tile choices differ (decoder_step)
   hipStream_t stream = nullptr;  // chains of a split call run on streams of their own
@@ -187,7 +186,7 @@ int flex_decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, i
 // rounded values; needs the tile-major table copy.  Halves the 1.3 GB the 256 x 5-row step wrote per position.
 int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int group, int n_pad, int pos,
                  const int32_t* anc, int anc_stride, hipStream_t stream, float stats_scale = 0.f, int logits_f16 = 0,
-                 int slab_f16 = 0, int sparse_k2 = 0) {
+                 int slab_f16 = 0) {
   if (D->flex) return flex_decoder_step(D, S, rows, rows_pad, group, n_pad, pos, anc, anc_stride, stream, stats_scale);
   const smi_text_decoder_config& c = D->cfg;
   const int d = c.model_dim, f = c.ffn_inner_dim;
@@ -258,15 +257,6 @@ int decoder_step(smi_text_decoder* D, DecWork& S, int rows, int rows_pad, int gr
   // beam search (stats_scale = 1 / temperature > 0): the GEMM also leaves per-tile softmax
   // statistics, so the candidate selection never re-reads the 1 MB logits rows
   GemmTileStats st{S.tile_max.as<float>(), S.tile_sum.as<float>(), stats_scale, (int)c.vocab_size};
-  // Sparse logits store (round 5, free beam-search steps of the fp16-logits path): a row's piece of a tile is written only
-  // if the tile can still be among the row's sparse_k2 best -- the only tiles (plus tile 0) the selection reads (kernels.hpp)
-  if (sparse_k2 > 0 && logits_f16 && ltm && stats_scale > 0.f && S.sparse_cls.p) {
-    const size_t nflt = (size_t)(sparse_k2 + 1) * rows_pad;
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)S.sparse_cls.p, (int)0xff800000u, nflt, stream));  // -inf
-    st.cls_max = S.sparse_cls.as<float>();
-    st.bound = S.sparse_cls.as<float>() + (size_t)sparse_k2 * rows_pad;
-    st.k2 = sparse_k2;
-  }
   if (S.chained && logits_grid_env > 0) set_gemm_grid_cap(logits_grid_env);
   const hipError_t le =
       logits_f16 && ltm && stats_scale > 0.f
@@ -408,20 +398,15 @@ int generate_chain(smi_text_decoder* D, DecWork& S, const void* emb, int emb_dty
   const int logits_f16 = !D->flex && D->embed_tm.p != nullptr && (lf_env >= 0 ? lf_env != 0 : D->beam_logits_f16 != 0);
   const int sf_env = tune(TUNE_DEC_SLAB_F16, -1);
   const int slab_f16 = !D->flex && (sf_env >= 0 ? sf_env != 0 : D->beam_slab_f16 != 0);
-  // sparse logits store: needs more tiles than classes to ever drop one (toy vocabularies store everything anyway)
-  const bool sparse_on = logits_f16 && tune(TUNE_DEC_SPARSE_LOGITS, 1) != 0 && ntiles > 4 * k2;
-  if (sparse_on) HIP_TRY(S.sparse_cls.reserve((size_t)(kVocabScanK2Max + 1) * rows_pad * 4));
 
   // everything one decode step enqueues (position pos; ancestry/history buffer pos & 1)
   auto enqueue_step = [&](int pos, hipStream_t s) -> int {
     const int cur = pos & 1, step_nr = pos + 1;
+    if (int rc = decoder_step(D, S, rows, rows_pad, beam, n_pad, pos, S.anc[cur].as<int32_t>(), stride, s, inv_temp,
+                              logits_f16, slab_f16))
+      return rc;
     const bool forced_prompt = step_nr < prompt_len;
     const bool force_eos = !forced_prompt && step_nr == max_len - 1;
-    // a forced prompt step reads the logit of ONE given token per row (any tile): dense store.  Free steps read tile 0 and
-    // the k2 best tiles; the forced EOS of the last step lives in tile 0.
-    if (int rc = decoder_step(D, S, rows, rows_pad, beam, n_pad, pos, S.anc[cur].as<int32_t>(), stride, s, inv_temp,
-                              logits_f16, slab_f16, sparse_on && !forced_prompt && c.eos_idx < 256 ? k2 : 0))
-      return rc;
     // forced steps need only the softmax normaliser (the candidate is a given token): k2 = 0
     const bool free_step = !forced_prompt && !force_eos;
     HIP_TRY(launch_vocab_select(S.logits.as<float>(), (int)D->vocab_pad, logits_f16, rows, (int)c.vocab_size,

@@ -704,16 +704,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       if (stats.tile_max && n0 + G2_BN <= stats.valid_n && !folded) {
         stats_stored = true;
         float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
-        int* keep_lds = (int*)(bias_lds + 2304);  // sparse store: [256 rows] "this row's piece of the tile is stored"
-        // sparse store (kernels.hpp: GemmTileStats): every tile but tile 0; the class maximum and the bound of the thread's row
-        // are requested here and used after the statistics
-        const bool sparse = stats.cls_max != nullptr && tile_n_cur > 0;
-        const int cls = sparse ? (tile_n_cur - 1) % stats.k2 : 0;
-        float g_old = -INFINITY, b_old = -INFINITY;
-        if (sparse && tid < 256) {
-          g_old = stats.cls_max[(size_t)cls * M + m0 + tid];
-          b_old = stats.bound[m0 + tid];
-        }
         const float sc2 = stats.scale * 1.4426950408889634f;
         const int cidx = (kg & 1) * 2 + (kg >> 1);
         const int sw = tm_swz(l15);
@@ -729,7 +719,6 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
             h[ni][0] = hp.x;
             h[ni][1] = hp.y;
           }
-          if (!sparse)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {  // the store of store_tile (MODE 0) below
             const auto s0 = __builtin_amdgcn_permlane16_swap(h[2 * j][0], h[2 * j + 1][0], false, false);
@@ -791,58 +780,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
           const float sum = a0.y * __builtin_amdgcn_exp2f(a0.x - ms) + a1.y * __builtin_amdgcn_exp2f(a1.x - ms) +
                             a2.y * __builtin_amdgcn_exp2f(a2.x - ms) + a3.y * __builtin_amdgcn_exp2f(a3.x - ms);
           const size_t o = (size_t)tile_n_cur * M + m0 + tid;
-          const float mt = m * 0.6931471805599453f;  // the value the selection ranks the tiles by: the bound lives in ITS domain
-          stats.tile_max[o] = mt;                    // (two maxima that round to one value here tie there, lower tile first)
+          stats.tile_max[o] = m * 0.6931471805599453f;
           stats.tile_sum[o] = sum;
-          if (sparse) {
-            float b = b_old;
-            if (mt > g_old) {  // a new class maximum: publish it and re-derive the row's bound (rare after the first rounds)
-              stats.cls_max[(size_t)cls * M + m0 + tid] = mt;
-              float bb = mt;
-              for (int c = 0; c < stats.k2; ++c)
-                if (c != cls) bb = fminf(bb, stats.cls_max[(size_t)c * M + m0 + tid]);
-              if (bb > b) {
-                stats.bound[m0 + tid] = bb;
-                b = bb;
-              }
-            }
-            keep_lds[tid] = mt >= b ? 1 : 0;
-          }
-        }
-        if (sparse) {
-          SMI_LGKM0_BARRIER();
-          int keep[8];
-          {
-            const unsigned ka = (unsigned)(size_t)(keep_lds + wr * 128 + l15);
-            asm volatile(
-                "ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\t"
-                "ds_read_b32 %3, %8 offset:192\n\tds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\t"
-                "ds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\ts_waitcnt lgkmcnt(0)"
-                : "=&v"(keep[0]), "=&v"(keep[1]), "=&v"(keep[2]), "=&v"(keep[3]), "=&v"(keep[4]), "=&v"(keep[5]), "=&v"(keep[6]),
-                  "=&v"(keep[7])
-                : "v"(ka)
-                : "memory");
-          }
-#pragma unroll
-          for (int mi = 0; mi < 8; ++mi) {
-            // (the accumulators are still there: packing them again -- 8 v_cvt_pk_f16_f32 -- is cheaper than keeping 64 packed
-            //  registers alive across the statistics: hipcc spilled 51 of them)
-            uint32_t h[4][2];
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-              const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(acc.v[ni][mi]));
-              h[ni][0] = hp.x;
-              h[ni][1] = hp.y;
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {  // lanes 16 apart hold the same row: the swap partners share the decision
-              const auto s0 = __builtin_amdgcn_permlane16_swap(h[2 * j][0], h[2 * j + 1][0], false, false);
-              const auto s1 = __builtin_amdgcn_permlane16_swap(h[2 * j][1], h[2 * j + 1][1], false, false);
-              const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};
-              // (plain stores: a kept row is a 64-B piece of a line, and non-temporal partial-line stores do not combine)
-              if (keep[mi]) *(u32x4*)(lane0 + (size_t)j * TM_BLOCK + mi * (16 * 32)) = chunk;
-            }
-          }
         }
       }
     }
@@ -1295,7 +1234,7 @@ static hipError_t launch_one256(const f16* X, const f16* W, const float* bias, v
   const int raster = (want_raster && ksplit == 1 && grid == 256 && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0)
                          ? want_raster : 0;
   hipLaunchKernelGGL((gemm_tn256_kernel<EPI, LAYOUT>), dim3(grid), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES,
-                     stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0, nullptr, nullptr, 0}, ksplit,
+                     stream, X, W, bias, out, M, N, K, ldo, stats ? *stats : GemmTileStats{nullptr, nullptr, 1.f, 0}, ksplit,
                      part_stride, raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0});
   return hipGetLastError();
 }

@@ -73,15 +73,6 @@ struct GemmTileStats {
   float* tile_sum;
   float scale;
   int valid_n;
-  // Sparse logits store (round 5; fp16 tile-major logits only, nullptr / 0 = store every tile).  The candidate selection reads
-  // tile 0 and, per row, the k2 tiles with the largest maxima among tiles >= 1 -- nothing else.  cls_max[k2][M]: the largest
-  // tile maximum seen so far (by ANY workgroup, plain loads and stores) among the tiles of residue class (tile - 1) % k2;
-  // bound[M]: min over the classes.  k2 classes with a value are k2 DISTINCT tiles whose maxima are >= bound, so the k2-th
-  // best tile maximum of the row is >= bound whatever the interleaving (a lost or stale update only loosens it): a row's
-  // piece of a tile is stored iff its maximum is >= bound.  Both arrays are reset to -inf before the launch.
-  float* cls_max = nullptr;
-  float* bound = nullptr;
-  int k2 = 0;
 };
 
 // LayerNorm folded into the GEMMs around it (256x256 engine, tile-major fp16 residual stream).

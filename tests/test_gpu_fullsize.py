@@ -445,16 +445,6 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
             margins = eng.last_margins(n).cpu()
             assert (lens[:, 0] == steps).all()           # min_gen_len == max_gen_len: every hypothesis ends at the cap
             _check_hyps_vs_oracle(f"256 sentences, {dt} storage", ref, toks, lens, scores, margins, C5_SAMPLE, eps, 1)
-            if dt == torch.float16:
-                # the sparse logits store (round 5: only the (row, tile) pieces the selection can read are written) against the
-                # dense store, V = 256 206: the selection must see the same values -- hypotheses, scores, margins bit for bit
-                from sonar_amd import _lib
-
-                with _lib.tuning(DEC_SPARSE_LOGITS=0):
-                    dense = [t.cpu() for t in eng.generate(emb.cuda().half(), prompt, **kw)]
-                    m_dense = eng.last_margins(n).cpu()
-                assert torch.equal(dense[0], toks) and torch.equal(dense[1], lens) and torch.equal(dense[2], scores)
-                assert torch.equal(m_dense, margins)
     finally:
         eng.set_beam_logits_dtype(torch.float16)
         eng.set_slab_dtype(torch.float16)
