@@ -630,176 +630,12 @@ __global__ __launch_bounds__(256) void vocab_select_kernel(const float* __restri
   }
 }
 
-// Round 5: the same selection with its two SEQUENTIAL parts -- k2 arg-max rounds over the tile maxima, k2 over the candidates --
-// run by ONE wave instead of the workgroup.  The kernel above closes each of its 2 x k2 rounds with __syncthreads, and a round
-// is ~40 VALU instructions of work: 43 us per step at 1 280 rows is barrier and LDS latency, not arithmetic.  Here the
-// workgroup does what is parallel (the normaliser; one candidate column per thread and selected tile) and wave 0 does what is
-// serial, on DPP / lane swaps, with no barrier inside: the tile maxima reach it through LDS (16 per lane), and of the ~4 400
-// candidates only those >= T survive -- T = the k2-th best tile maximum, a lower bound of the k2-th best VALUE because the k2
-// tile maxima are k2 distinct elements (lowered by a few ulps: the statistics went through (v * scale * log2 e) * ln 2, the
-// candidates are v * inv_temp) -- a dozen per row, appended to an LDS list that holds every candidate if it must (equal logits).
-// Same total orders, same masks, same arithmetic for the normaliser: the lists are those of the kernel above bit for bit
-// (tests/test_gpu_decoder.py::test_lead_wave_selection_equals_workgroup_selection, DEC_SELECT_LEAD switch).
-template <int TPL>
-__global__ __launch_bounds__(256) void vocab_select_lead_kernel(const float* __restrict__ logits, int ldl, int f16_tm, int vocab,
-                                                                const float* __restrict__ tile_max,
-                                                                const float* __restrict__ tile_sum, int ntiles,
-                                                                int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
-                                                                int unk_idx, float unk_penalty, int block_eos,
-                                                                float* __restrict__ pmax, float* __restrict__ psum,
-                                                                float* __restrict__ pval, int* __restrict__ pidx) {
-  __shared__ float s_f[4];
-  __shared__ float s_m[64 * TPL];
-  __shared__ int s_sel[VSEL_SLOTS];
-  __shared__ int s_nsel, s_ncand;
-  __shared__ float s_thr;
-  __shared__ unsigned long long s_cand[VSEL_SLOTS * 256];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const float* tm = tile_max + row;  // [tile][stat_rows]
-  const float* ts = tile_sum + row;
-  constexpr int TPT = TPL / 4;  // tiles per thread (8: up to 2048 tiles, as above)
-  float m[TPT], sm[TPT];
-  float lm = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < TPT; ++j) {
-    const int t = tid + 256 * j;
-    m[j] = t < ntiles ? tm[(size_t)t * stat_rows] : -INFINITY;
-    sm[j] = t < ntiles ? ts[(size_t)t * stat_rows] : 0.f;
-    lm = fmaxf(lm, m[j]);
-    s_m[t] = m[j];
-  }
-  // ---- 1. softmax normaliser of the row (the arithmetic and its order are those of vocab_select_kernel)
-  lm = wave_max(lm);
-  if (lane == 0) s_f[wv] = lm;
-  if (tid == 0) s_ncand = 0;
-  __syncthreads();
-  const float M = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
-  float se = 0.f;
-#pragma unroll
-  for (int j = 0; j < TPT; ++j)
-    if (m[j] != -INFINITY) se += sm[j] * __expf(m[j] - M);
-  se = wave_sum(se);
-  __syncthreads();
-  if (lane == 0) s_f[wv] = se;
-  __syncthreads();
-  if (tid == 0) {
-    pmax[row] = M;
-    psum[row] = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
-  }
-  if (k2 == 0) return;
-  // ---- 2a. wave 0: the k2 best tiles among tiles >= 1 (value desc, tile asc), plus tile 0
-  if (wv == 0) {
-    unsigned long long tk[TPL];
-    unsigned long long tbest = 0ull;
-#pragma unroll
-    for (int j = 0; j < TPL; ++j) {
-      const int t = lane + 64 * j;
-      const float mv = s_m[t];
-      tk[j] = (mv != -INFINITY && t != 0) ? cand_key(mv, t) : 0ull;
-      tbest = tk[j] > tbest ? tk[j] : tbest;
-    }
-    if (lane == 0) s_sel[0] = 0;
-    int nsel = 1;
-    float thr = -INFINITY;
-    for (int round = 0; round < k2; ++round) {
-      const unsigned long long b = wave_max_u64(tbest);
-      if (b == 0ull) break;  // fewer than k2 tiles
-      if (lane == 0) s_sel[nsel] = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
-      ++nsel;
-      if (round == k2 - 1) {
-        unsigned u = (unsigned)(b >> 32);
-        u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-        thr = __uint_as_float(u);
-      }
-      if (b == tbest) {  // exactly one lane: the keys carry the tile index
-        tbest = 0ull;
-#pragma unroll
-        for (int j = 0; j < TPL; ++j) {
-          if (tk[j] == b) tk[j] = 0ull;
-          tbest = tk[j] > tbest ? tk[j] : tbest;
-        }
-      }
-    }
-    if (thr != -INFINITY) thr -= fabsf(thr) * 4e-6f + 1e-30f;  // dropping is an optimisation only: stay below the rounding gap
-    if (lane == 0) {
-      s_nsel = nsel;
-      s_thr = thr;
-    }
-  }
-  __syncthreads();
-  // ---- 2b. thread t owns column t of every selected tile; survivors go to the list
-  {
-    const int nsel = s_nsel;
-    const float thr = s_thr;
-#pragma unroll
-    for (int j = 0; j < VSEL_SLOTS; ++j) {
-      if (j < nsel) {
-        const int tok = s_sel[j] * 256 + tid;
-        if (tok < vocab && tok != pad_idx && !(block_eos && tok == eos_idx)) {
-          float v = logit_at(logits, ldl, f16_tm, row, tok) * inv_temp;
-          if (tok == unk_idx) v -= unk_penalty;
-          if (v != -INFINITY && v >= thr) s_cand[atomicAdd(&s_ncand, 1)] = cand_key(v, tok);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  // ---- 2c. wave 0: ordered top-k2 of the survivors
-  if (wv == 0) {
-    const int n = s_ncand;
-    unsigned long long cbest = 0ull;
-    int cpos = -1;
-    auto rescan = [&]() {
-      cbest = 0ull;
-      cpos = -1;
-      for (int i = lane; i < n; i += 64) {
-        const unsigned long long c = s_cand[i];
-        if (c > cbest) {
-          cbest = c;
-          cpos = i;
-        }
-      }
-    };
-    rescan();
-    for (int round = 0; round < k2; ++round) {
-      const unsigned long long b = wave_max_u64(cbest);
-      if (lane == 0) {
-        float val = -INFINITY;
-        int idx = 0x7fffffff;
-        if (b != 0ull) {
-          unsigned u = (unsigned)(b >> 32);
-          u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-          val = __uint_as_float(u);
-          idx = (int)(0xffffffffu - (unsigned)(b & 0xffffffffu));
-        }
-        pval[(size_t)row * VS_K2MAX + round] = val;
-        pidx[(size_t)row * VS_K2MAX + round] = idx;
-      }
-      if (b != 0ull && b == cbest) {  // one lane (the keys carry the token): retire the winner, find this lane's next best
-        s_cand[cpos] = 0ull;
-        rescan();
-      }
-    }
-  }
-}
-
 hipError_t launch_vocab_select(const float* logits, int ldl, int f16_tm, int rows, int vocab, const float* tile_max,
                                const float* tile_sum, int ntiles, int stat_rows, int k2, float inv_temp, int pad_idx, int eos_idx,
                                int unk_idx, float unk_penalty, int block_eos, float* pmax, float* psum, float* pval,
                                int* pidx, hipStream_t stream) {
   if (rows <= 0 || stat_rows < rows || ntiles <= 0 || ntiles > 2048 || k2 < 0 || k2 > VS_K2MAX || (int64_t)ntiles * 256 < vocab)
     return hipErrorInvalidValue;
-  if (tune(TUNE_DEC_SELECT_LEAD, 1) != 0) {  // 0: the round 1-4 kernel (A/B runs, and the twin of the parity test)
-    if (ntiles <= 1024)
-      hipLaunchKernelGGL(vocab_select_lead_kernel<16>, dim3(rows), dim3(256), 0, stream, logits, ldl, f16_tm, vocab, tile_max,
-                         tile_sum, ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum,
-                         pval, pidx);
-    else
-      hipLaunchKernelGGL(vocab_select_lead_kernel<32>, dim3(rows), dim3(256), 0, stream, logits, ldl, f16_tm, vocab, tile_max,
-                         tile_sum, ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum,
-                         pval, pidx);
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL(vocab_select_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, f16_tm, vocab, tile_max, tile_sum,
                      ntiles, stat_rows, k2, inv_temp, pad_idx, eos_idx, unk_idx, unk_penalty, block_eos, pmax, psum, pval, pidx);
   return hipGetLastError();

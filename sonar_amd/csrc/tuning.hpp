@@ -26,7 +26,6 @@ namespace smi {
   X(DEC_SLAB_F16)    /* decoder split-K partial sums: [-1] the engine setting (smi_text_decoder_set_slab_dtype), 0 fp32, 1 fp16 */ \
   X(DEC_LOGITS_F16)  /* beam-search logits storage: [-1] the engine setting, 0 fp32, 1 fp16 */                          \
   X(DEC_CHAINS)      /* independent decode chains ([0] the engine's policy) */                                          \
-  X(DEC_SELECT_LEAD) /* beam-search candidate selection: [1] serial parts on one lead wave, 0 workgroup-wide barrier rounds */ \
   X(G2_RASTER)       /* 256x256 engine: [2] XCD-owned m-groups, 0 id-order raster */                                    \
   X(GT_RING)         /* stages of the lone-tile ring ([4]; anything else: never use it) */                              \
   X(LONE)            /* [1] 64x64 lone-tile units where they fit, 0 round 3's 128x128 ring */                           \

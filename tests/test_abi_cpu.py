@@ -97,7 +97,7 @@ def test_tuning_registry_and_no_environment_reads(monkeypatch):
 
     lib = _lib.load()
     names = _lib.tuning_names()
-    assert "LONE" in names and "DEC_KS_OUT" in names and "DEC_SELECT_LEAD" in names and len(set(names)) == len(names)
+    assert "LONE" in names and "DEC_KS_OUT" in names and "DEC_SLAB_F16" in names and len(set(names)) == len(names)
     und = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
     assert "getenv" not in und
     for src in (p for p in (pathlib.Path(ROOT) / "sonar_amd" / "csrc").iterdir() if p.suffix in (".hip", ".hpp", ".cpp")):

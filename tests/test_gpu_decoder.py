@@ -261,35 +261,6 @@ def test_beam_logits_storage_type(setup):
     print(f"fp16 / fp32 beam logits: {same}/{n} best hypotheses identical, logit scale {logit_scale:.2f}")
 
 
-@pytest.mark.parametrize("storage", [torch.float16, torch.float32])
-def test_lead_wave_selection_equals_workgroup_selection(setup, storage):
-    """Round 5: the candidate selection of a beam step runs its two serial parts (k2 arg-max rounds over the tile maxima, k2 over
-    the candidates) on ONE lead wave without barriers, and drops candidates below the k2-th best tile maximum before the ordered
-    rounds (vocab_select_lead_kernel).  It must return the lists of the round 1-4 kernel (workgroup-wide barrier rounds,
-    DEC_SELECT_LEAD=0) bit for bit: hypotheses, lengths, scores and margins of whole beam searches are compared, for beam
-    1 / 3 / 5 / 8 (k2 = 2 ... 16), with a temperature and an UNK penalty, on fp16 tile-major and fp32 logits."""
-    from sonar_amd import _lib
-
-    OD, ocfg, params, eng = setup
-    g = torch.Generator().manual_seed(515)
-    n = 37
-    emb = (torch.randn(n, ocfg.model_dim, generator=g) * 0.3).cuda()
-    try:
-        eng.set_beam_logits_dtype(storage)
-        for beam, kw in ((1, {}), (3, dict(temperature=0.7)), (5, dict(unk_penalty=0.5)), (8, dict(min_gen_len=4))):
-            args = dict(beam_size=beam, max_gen_len=(0, 20), **kw)
-            with _lib.tuning(DEC_SELECT_LEAD=0):
-                want = [t.cpu() for t in eng.generate(emb, [3, 701], **args)]
-                m_want = eng.last_margins(n).cpu()
-            got = [t.cpu() for t in eng.generate(emb, [3, 701], **args)]
-            m_got = eng.last_margins(n).cpu()
-            for a, b in zip(want, got):
-                assert torch.equal(a, b), (beam, storage)
-            assert torch.equal(m_want, m_got)
-    finally:
-        eng.set_beam_logits_dtype(torch.float16)
-
-
 def test_bf16_decoder_model_vs_oracle():
     """A bf16 decoder (`dtype=torch.bfloat16`, bf16 weights and bf16 sentence vectors; sonar/inference_pipelines/text.py:
     305-346 moves the model with `.to(device, dtype)`): bf16 weights are exact fp16 operands, the stream is fp32, the beam
