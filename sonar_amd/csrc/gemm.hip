@@ -372,6 +372,11 @@ constexpr bool G2_STORE_OVERLAP = SMI_G2_STORE_OVERLAP != 0;
 #define SMI_G2_OVERLAP_BIAS_TM 0
 #endif
 constexpr bool G2_OVERLAP_BIAS_TM = SMI_G2_OVERLAP_BIAS_TM != 0;
+// -DSMI_STATS_FUSED=0: the round-4 statistics epilogue of the fp16 logits GEMM (separate statistics and store passes) -- A/B builds
+#ifndef SMI_STATS_FUSED
+#define SMI_STATS_FUSED 1
+#endif
+constexpr bool G2_STATS_FUSED = SMI_STATS_FUSED != 0;
 
 template <int EPI, int LAYOUT = 0>
 __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __restrict__ X,
@@ -688,10 +693,7 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
     constexpr bool STATS_F16 = EPI == EPI_BIAS_F16 && LAYOUT == 2;
     bool stats_stored = false;  // the fused statistics + store pass below has written the tile
     (void)stats_stored;
-#ifndef SMI_STATS_FUSED
-#define SMI_STATS_FUSED 1
-#endif
-    if constexpr (STATS_F16 && SMI_STATS_FUSED) {
+    if constexpr (STATS_F16 && G2_STATS_FUSED) {
       // Round 5: statistics of the fp16 logits and their tile-major store in ONE pass over the accumulators, every tile but the
       // last column tile (whose padding columns need masking: the general code below).  Counted in the ISA, the round-4
       // statistics cost ~12 VALU issue slots per element (128 elements per lane and tile): two conversions (round to fp16 and
