@@ -9,6 +9,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "gemm_epi.hpp"
 #include "gemm_lone.hpp"
 #include "gemm_lone16.hpp"
 #include "gemm_tile.hpp"
@@ -29,52 +30,6 @@ namespace smi {
 // EPI_GLU_F16       : out_h[m][g*32+c] = f16(a * sigmoid(b)), a/b = columns g*64+c / g*64+32+c
 //                     (W rows interleaved in 32-channel groups at pack time), out width N/2
 // bias may be null for every epilogue.
-// Activations of the fp16 epilogues.  v_rcp_f32 (1 ulp) instead of an IEEE division: `/` expands to a
-// ~10-instruction div_scale / fma / div_fixup sequence per element, 128 elements per lane and tile,
-// for a result that is rounded to fp16 right after.
-__device__ __forceinline__ float sigmoid_f(float v) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-}
-__device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
-// tanh(v) = 1 - 2 / (exp(2v) + 1); exact limits at +-inf (exp -> inf gives 1, exp -> 0 gives -1)
-__device__ __forceinline__ float tanh_f(float v) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * v) + 1.0f);
-}
-
-template <int EPI>
-__device__ __forceinline__ f32x4 epi_act(f32x4 v) {
-  if constexpr (EPI == EPI_RELU_F16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-  } else if constexpr (EPI == EPI_SILU_F16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-  } else if constexpr (EPI == EPI_TANH_F16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = tanh_f(v[e]);
-  }
-  return v;
-}
-
-// Activation + rounding of 4 accumulator values to fp16.  relu runs on the rounded halves as a packed
-// signed 16-bit integer max with 0 (a negative fp16 is a negative int16): one v_pk_max_i16 per two
-// values instead of the canonicalise + v_max_f32 pair per value that fmaxf compiles to (MFMA results
-// are not known-canonical), and relu(round(x)) == round(relu(x)).
-template <int EPI>
-__device__ __forceinline__ half4 epi_act_pack(f32x4 v) {
-  typedef short short2v __attribute__((ext_vector_type(2)));
-  if constexpr (EPI != EPI_RELU_F16) v = epi_act<EPI>(v);
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  half2v lo = __builtin_convertvector(f32x2{v[0], v[1]}, half2v);  // v_cvt_pk_f16_f32
-  half2v hi = __builtin_convertvector(f32x2{v[2], v[3]}, half2v);
-  if constexpr (EPI == EPI_RELU_F16) {
-    const short2v z = {0, 0};
-    lo = __builtin_bit_cast(half2v, __builtin_elementwise_max(__builtin_bit_cast(short2v, lo), z));
-    hi = __builtin_bit_cast(half2v, __builtin_elementwise_max(__builtin_bit_cast(short2v, hi), z));
-  }
-  return half4{lo[0], lo[1], hi[0], hi[1]};
-}
-
 // Epilogue of the 128x128-family engines (gemm_tile.hpp, gemm_lone.hpp): a wave holds MI x NI blocks of 32x32, block
 // (ni, mi) element r is C[row0 + mi*32][col0 + ni*32 + 8*(r>>2) + (r&3)] with row0 = tile row + wave row + (lane&31),
 // col0 = tile column + wave column + 4*(lane>>5).  b[ni][q]: the bias of the lane's 4-column runs, loaded by the caller
@@ -1367,6 +1322,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     if (fold->part_in) {  // consumer: tile-major outputs (bias / relu / silu) or row-major ones (bias / GLU; centred weights)
       if (!fold->c1 || fold->nparts < 1 || fold->nparts > 4) return hipErrorInvalidValue;
       if (out_tm) {
+        // the 4-wave engine (gemm_v2.hip) where it applies: >= 24 K slices, several persistent rounds
+        if (gemm_v2_fits(epi, M, N, K, bias, fold)) return launch_gemm_v2(epi, X, W, bias, (f16*)out, M, N, K, stream, fold);
         if (epi == EPI_BIAS_F16) return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
         if (epi == EPI_RELU_F16) return launch_one256<EPI_RELU_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
         if (epi == EPI_SILU_F16 && fold->centered)
@@ -1397,6 +1354,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \
                   : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
   if (out_tm) {  // fp16 outputs that feed the next GEMM; EPI_RESID_F16: the tile-major residual stream
+    if (use256 && gemm_v2_fits(epi, M, N, K, bias, nullptr))
+      return launch_gemm_v2(epi, X, W, bias, (f16*)out, M, N, K, stream, nullptr);
     switch (epi) {
       SMI_EPI_CASE(EPI_BIAS_F16, 2)
       SMI_EPI_CASE(EPI_RELU_F16, 2)

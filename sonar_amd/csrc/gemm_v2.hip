@@ -1,0 +1,347 @@
+// Tile-major fp16 GEMMs on the second-generation 256x256 engine (gemm_v2.hpp): C = act(rstd * (X . W^T) [- rstd * mean * c1] + c2),
+// X [M, K] and W [N, K] tile-major fp16, C [M, N] tile-major fp16 (the X operand of the next GEMM).  These are the text
+// encoder's fused QKV and FFN-inner projections (reference wiring: sonar/models/sonar_text/factory.py:130-153), the
+// conformer's FFN-inner projections and every other <bias | relu | silu, tile-major in/out> launch with >= 24 K slices.
+//
+// Persistent: one workgroup of 4 waves per CU walks tiles in the raster of the 8-wave engine (gemm.hip).  A tile's life:
+//   step 0          its per-tile constants (c2 / bias, c1, the rows' LayerNorm partial sums) are fetched by LDS-DMA into
+//                   the wave's private LDS area; the accumulators start from the literal 0
+//   last 3 steps    the operand stream moves on to the next tile (the ring never drains)
+//   read-out        accumulators -> (LayerNorm fold) -> activation -> fp16 -> lane swaps -> 32 stores of 1 KiB per wave,
+//                   each issued as soon as its chunk exists: the stores use the CU's memory path while the matrix pipe
+//                   is idle anyway.  (Round 6, experiments 1-3, profiles/r06_experiments.txt: holding the finished tile
+//                   in 128 VGPRs and issuing 2 stores per K step of the next tile does NOT hide them -- the K loop pulls
+//                   32 KiB per 0.7 us through the CU's memory path, 89 % of the 52 GB/s per CU the L2s deliver, and every
+//                   store byte under the loop slows the loop by its own transfer time: -2.6 us of stores, +2.6 us of loop.)
+#include <algorithm>
+#include <type_traits>
+
+#include "gemm_epi.hpp"
+#include "gemm_v2.hpp"
+#include "kernels.hpp"
+
+// -DV2_PROBE=<bits> (measurement builds, wrong results): 1 = no stores under the K loop, 2 = no read-out, 4 = plain (not
+// non-temporal) stores
+#ifndef V2_PROBE
+#define V2_PROBE 0
+#endif
+
+namespace smi {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 0: out = act(acc + c2)  (c2 = the bias);  1: LayerNorm fold with the exact mean term;  2: fold with centred weights
+template <int EPI, bool FOLD>
+__global__ __launch_bounds__(V2_THREADS) void gemm_v2_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+                                                             const float* __restrict__ c2, f16* __restrict__ out, int M, int N,
+                                                             int K, int raster, GemmLnFold fold) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const V2Ring rg = v2_make_ring(smem, wave, lane);
+  const unsigned voff = wave * 4096 + lane * 16;
+
+  // ---- tile walk: the rasters of gemm_tn256_kernel (gemm.hip) ----
+  const int ntm = M / 256, ntn = N / 256, nt = K / 32, nout = ntm * ntn;
+  const int nq = ntn / 4;
+  const int nvirt = raster ? ((ntm + 63) / 64) * nq * 256 : nout;
+  auto coords = [&](int t, int& tm_, int& tn_) -> bool {
+    if (raster == 0) {
+      constexpr int GM = 8;  // grouped 8(m) x ntn super-tiles in id order (gemm_tile256.hpp: g2_tile_coords_of)
+      const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+      const int gsz = min(GM, ntm - first_m), in_group = t - group * per_group;
+      tm_ = first_m + in_group % gsz;
+      tn_ = in_group / gsz;
+      return true;
+    }
+    const int q = t / 256, c = (t % 256) / 32, j = t % 32;
+    tm_ = (c + 8 * (q / nq)) * 8 + j % 8;
+    tn_ = ((q + (raster == 2 ? c : 0)) % nq) * 4 + j / 8;
+    return tm_ < ntm;
+  };
+  int tile_m = 0, tile_n = 0;
+  auto seek = [&](int t) {
+    while (t < nvirt && !coords(t, tile_m, tile_n)) t += gridDim.x;
+    return t;
+  };
+  int tile = seek(xcd_remap(blockIdx.x, gridDim.x));
+  if (tile >= nvirt) return;
+
+  const size_t panel = (size_t)nt * (TM_BLOCK * 2);  // bytes of one 256-row operand panel
+  V2Stream st;
+  st.xp = (const char*)X + (size_t)tile_m * panel + voff;
+  st.wp = (const char*)W + (size_t)tile_n * panel + voff;
+  st.inc = TM_BLOCK * 2;
+  V2Frag f;
+  v2_start(f, st, rg);
+
+  // ---- per-wave constant area: c2[128] | c1[128] | partial sums p = 0..3: float2[128 rows] ----
+  const unsigned cbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + V2_RING_BYTES + wave * V2_CONST_BYTES);
+  auto fetch_consts = [&](int m0, int n0) {
+    const float* c2p = c2 + n0 + wc * 128 + lane;
+    if constexpr (FOLD) {
+      const float* c1p = fold.c1 + n0 + wc * 128 + lane;
+      // partial p of the wave's 128 rows: 1 KiB contiguous; the instruction offset applies to the LDS side too, so the
+      // source pointers are pre-biased by -p KiB
+      const char* rp[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        rp[p] = (const char*)(fold.part_in + (size_t)(p < fold.nparts ? p : 0) * M + m0 + wr * 128) + lane * 16 - p * 1024;
+      asm volatile(
+          "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+          "global_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256\n\t"
+          "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+          "global_load_lds_dword %1, off\n\tglobal_load_lds_dword %1, off offset:256\n\t"
+          "s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+          "global_load_lds_dwordx4 %2, off\n\tglobal_load_lds_dwordx4 %3, off offset:1024\n\t"
+          "global_load_lds_dwordx4 %4, off offset:2048\n\tglobal_load_lds_dwordx4 %5, off offset:3072"
+          :
+          : "v"(c2p), "v"(c1p), "v"(rp[0]), "v"(rp[1]), "v"(rp[2]), "v"(rp[3]), "s"(cbase), "s"(cbase + 512), "s"(cbase + 1024)
+          : "memory");
+    } else {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256"
+                   :
+                   : "v"(c2p), "s"(cbase)
+                   : "memory");
+    }
+  };
+  constexpr int NCONST = FOLD ? 8 : 2;  // vector-memory operations of fetch_consts per wave
+
+  // store address of chunk (j, mi) = k-block j of the wave's 4, 16-row block mi: wave-uniform tile base + lane part +
+  // j * 16 KiB + mi * 1 KiB
+  const int cidx = (kg & 1) * 2 + (kg >> 1);
+  const unsigned lane_part = (unsigned)(((wr * 128 + l15) * 32 + ((cidx ^ tm_swz(l15)) << 3)) * 2);
+  auto tile_out = [&](int tm_, int tn_) {
+    return (char*)out + ((size_t)tm_ * (N >> 5) + (size_t)tn_ * 8 + wc * 4) * (TM_BLOCK * 2);
+  };
+  constexpr int NST = (V2_PROBE & 3) ? 0 : 32;  // stores per wave and tile
+
+  bool more = true, first_tile = true;
+  while (more) {
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    // ---- steps 0..3.  In the wave's in-order queue the previous tile's NST stores sit behind the DMA of slices 1 and 2
+    // (issued by the previous tile's last two steps) and in front of slice 3 (issued by step 0): the counted waits of steps
+    // 0 and 1 let them stay in flight, step 2 (slice 3) retires them -- 2 steps + the read-out after the first was issued.
+    if (first_tile) {
+      v2_step_top<8>();
+      fetch_consts(m0, n0);
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8 + NCONST>();
+    } else {
+      v2_step_top<8 + NST>();
+      fetch_consts(m0, n0);
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8 + NCONST + NST>();
+    }
+    first_tile = false;
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<3, false>(f, st, rg);
+    for (int kb = 4; kb < nt - 4; kb += 4) {
+      v2_step_top<8>();
+      v2_step_body<0, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<1, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<2, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<3, false>(f, st, rg);
+    }
+    // ---- the last four steps: step nt-4 issues this tile's last slice, the other three the next tile's slices 0..2 ----
+    v2_step_top<8>();
+    v2_step_body<0, false>(f, st, rg);
+    const int tm_cur = tile_m, tn_cur = tile_n;
+    tile = seek(tile + (int)gridDim.x);
+    more = tile < nvirt;
+    if (more) {
+      st.xp = (const char*)X + (size_t)tile_m * panel + voff;
+      st.wp = (const char*)W + (size_t)tile_n * panel + voff;
+    } else {
+      st.xp -= st.inc;
+      st.wp -= st.inc;
+      st.inc = 0;
+    }
+    v2_step_top<8>();
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<3, false>(f, st, rg);
+
+    // ---- read-out: accumulators -> 32 stores ----
+    char* const obase = tile_out(tm_cur, tn_cur);
+    // the lane's share of the tile constants (kept spread over the wave, fetched with ds_bpermute below): (sum, sum of
+    // squares) partials of rows wr*128 + lane and + 64 + lane, c2 / c1 of columns wc*128 + lane and + 64 + lane.  They
+    // landed long ago (the waits of steps 2.. retired them: in-order queue); asm loads, issue + wait in one statement.
+    float c2r[2], c1r[2] = {0.f, 0.f};
+    float row_rs[2] = {1.f, 1.f}, row_nm[2] = {0.f, 0.f};
+    const unsigned ca = cbase + lane * 4, ra = cbase + 1024 + lane * 8;
+    if constexpr (FOLD) {
+      float2 pr[2][4];
+      asm volatile(
+          "ds_read_b64 %0, %12\n\tds_read_b64 %1, %12 offset:1024\n\tds_read_b64 %2, %12 offset:2048\n\t"
+          "ds_read_b64 %3, %12 offset:3072\n\tds_read_b64 %4, %12 offset:512\n\tds_read_b64 %5, %12 offset:1536\n\t"
+          "ds_read_b64 %6, %12 offset:2560\n\tds_read_b64 %7, %12 offset:3584\n\t"
+          "ds_read_b32 %8, %13\n\tds_read_b32 %9, %13 offset:256\n\tds_read_b32 %10, %13 offset:512\n\t"
+          "ds_read_b32 %11, %13 offset:768\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(pr[0][0]), "=&v"(pr[0][1]), "=&v"(pr[0][2]), "=&v"(pr[0][3]), "=&v"(pr[1][0]), "=&v"(pr[1][1]),
+            "=&v"(pr[1][2]), "=&v"(pr[1][3]), "=&v"(c2r[0]), "=&v"(c2r[1]), "=&v"(c1r[0]), "=&v"(c1r[1])
+          : "v"(ra), "v"(ca)
+          : "memory");
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float2 z = {0.f, 0.f};
+        // the summation order of the 8-wave engine: (p0 + p2) + (p1 + p3)
+        const float2 p0 = pr[u][0], p1 = fold.nparts > 1 ? pr[u][1] : z, p2 = fold.nparts > 2 ? pr[u][2] : z,
+                     p3 = fold.nparts > 3 ? pr[u][3] : z;
+        const float sx = (p0.x + p2.x) + (p1.x + p3.x), sy = (p0.y + p2.y) + (p1.y + p3.y);
+        const float mean = sx * fold.inv_k;
+        const float var = fmaxf(sy * fold.inv_k - mean * mean, 0.f);
+        row_rs[u] = __builtin_amdgcn_rsqf(var + fold.eps);
+        row_nm[u] = -row_rs[u] * mean;
+      }
+    } else {
+      asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c2r[0]), "=&v"(c2r[1])
+                   : "v"(ca)
+                   : "memory");
+    }
+    asm volatile(V2_RDOUT_FIRST_STR);
+    auto put = [&](int i, const u32x4& chunk) {  // chunk i = (j, mi)
+      u32x4* dst = (u32x4*)(obase + (size_t)(i >> 3) * (TM_BLOCK * 2) + (i & 7) * 1024 + lane_part);
+      if constexpr ((V2_PROBE & 1) != 0)
+        asm volatile("" ::"v"(chunk), "v"(dst));
+      else if constexpr ((V2_PROBE & 4) != 0)
+        *dst = chunk;
+      else
+        store_nt(dst, chunk);
+    };
+    auto readout = [&](auto mode_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      float rsall[8], nmall[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {  // row mi*16 + l15 of the wave's 128: lane (mi*16 + l15) & 63, register mi >> 2
+        rsall[mi] = 1.f;
+        nmall[mi] = 0.f;
+        if constexpr (MODE != 0) {
+          const int src = ((mi & 3) * 16 + l15) * 4;
+          rsall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_rs[mi >> 2])));
+          if constexpr (MODE == 1) nmall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_nm[mi >> 2])));
+        }
+      }
+#define SMI_V2_PAIR(J, MI)                                                                                              \
+  {                                                                                                                    \
+    f32x4 va, vb;                                                                                                      \
+    SMI_V2_RDOUT_IDX(J, 0, MI, va);                                                                                    \
+    SMI_V2_RDOUT_IDX(J, 1, MI, vb);                                                                                    \
+    put((J) * 8 + (MI), finish(va, vb, c2v, c1v, rsall[MI], nmall[MI]));                                               \
+  }
+      auto finish = [&](f32x4 va, f32x4 vb, const f32x4 (&c2v)[2], const f32x4 (&c1v)[2], float rs, float nm) {
+        uint32_t h[2][2];
+#pragma unroll
+        for (int nl = 0; nl < 2; ++nl) {
+          f32x4 v = nl ? vb : va;
+          const f32x2 rs2 = {rs, rs}, nm2 = {nm, nm};
+#pragma unroll
+          for (int hp2 = 0; hp2 < 2; ++hp2) {
+            const f32x2 c2p = {c2v[nl][2 * hp2], c2v[nl][2 * hp2 + 1]};
+            f32x2 vp = {v[2 * hp2], v[2 * hp2 + 1]};
+            if constexpr (MODE == 1) {
+              const f32x2 c1p = {c1v[nl][2 * hp2], c1v[nl][2 * hp2 + 1]};
+              vp = __builtin_elementwise_fma(rs2, vp, __builtin_elementwise_fma(nm2, c1p, c2p));
+            } else if constexpr (MODE == 2) {
+              vp = __builtin_elementwise_fma(rs2, vp, c2p);
+            } else {
+              vp = vp + c2p;
+            }
+            v[2 * hp2] = vp[0];
+            v[2 * hp2 + 1] = vp[1];
+          }
+          const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI>(v));
+          h[nl][0] = hp.x;
+          h[nl][1] = hp.y;
+        }
+        // rows 16..31 / 48..63 of h[0] <-> rows 0..15 / 32..47 of h[1]: every lane then holds one whole 16-B chunk
+        // (lane group kg owns chunk (kg&1)*2 + (kg>>1) of the 32-column k-block; gemm.hip, LAYOUT 2)
+        const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+        return u32x4{s0[0], s1[0], s0[1], s1[1]};
+      };
+#define SMI_V2_KBLOCK(J)                                                                                               \
+  {                                                                                                                    \
+    f32x4 c2v[2], c1v[2];                                                                                              \
+    _Pragma("unroll") for (int nl = 0; nl < 2; ++nl) _Pragma("unroll") for (int r = 0; r < 4; ++r) {                   \
+      const int col = (2 * (J) + nl) * 16 + 4 * kg + r; /* of the wave's 128: lane col & 63, register col >> 6 */      \
+      c2v[nl][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((col & 63) * 4, __float_as_int(c2r[(2 * (J) + nl) >> 2]))); \
+      c1v[nl][r] = 0.f;                                                                                                \
+      if constexpr (MODE == 1)                                                                                         \
+        c1v[nl][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((col & 63) * 4, __float_as_int(c1r[(2 * (J) + nl) >> 2]))); \
+    }                                                                                                                  \
+    SMI_V2_PAIR(J, 0) SMI_V2_PAIR(J, 1) SMI_V2_PAIR(J, 2) SMI_V2_PAIR(J, 3) SMI_V2_PAIR(J, 4) SMI_V2_PAIR(J, 5)        \
+    SMI_V2_PAIR(J, 6) SMI_V2_PAIR(J, 7)                                                                                \
+  }
+      SMI_V2_KBLOCK(0) SMI_V2_KBLOCK(1) SMI_V2_KBLOCK(2) SMI_V2_KBLOCK(3)
+#undef SMI_V2_KBLOCK
+#undef SMI_V2_PAIR
+    };
+    if constexpr ((V2_PROBE & 2) != 0) {
+    } else if constexpr (FOLD) {
+      if (fold.centered)
+        readout(std::integral_constant<int, 2>{});
+      else
+        readout(std::integral_constant<int, 1>{});
+    } else {
+      readout(std::integral_constant<int, 0>{});
+    }
+  }
+}
+
+template <int EPI, bool FOLD>
+static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* out, int M, int N, int K, hipStream_t stream,
+                            const GemmLnFold* fold) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v2_kernel<EPI, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       V2_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done.set();
+  }
+  const int ntm = M / 256, ntn = N / 256;
+  const int grid = std::min(ntm * ntn, num_cus());
+  const int want_raster = tune(TUNE_G2_RASTER, 2);
+  const int raster = (want_raster && grid == 256 && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0) ? want_raster : 0;
+  hipLaunchKernelGGL((gemm_v2_kernel<EPI, FOLD>), dim3(grid), dim3(V2_THREADS), V2_LDS_BYTES, stream, X, W, c2, out, M, N, K,
+                     raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0});
+  return hipGetLastError();
+}
+
+bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnFold* fold) {
+  if (tune(TUNE_G2V2, 1) == 0) return false;
+  if (epi != EPI_BIAS_F16 && epi != EPI_RELU_F16 && epi != EPI_SILU_F16) return false;
+  if (M % 256 || N % 256 || K % 128 || K / 32 < V2_MIN_SLICES || !bias) return false;
+  if (fold && (!fold->part_in || !fold->c1 || fold->nparts < 1 || fold->nparts > 4)) return false;
+  if (fold && epi == EPI_SILU_F16 && !fold->centered) return false;
+  // persistent rounds: the deferred stores pay when a workgroup walks several tiles
+  return (int64_t)(M / 256) * (N / 256) >= tune(TUNE_G2V2_MIN, 2 * 256);
+}
+
+hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias, f16* out, int M, int N, int K,
+                          hipStream_t stream, const GemmLnFold* fold) {
+#define SMI_V2_CASE(E)                                                                           \
+  case E:                                                                                        \
+    return fold ? launch_v2<E, true>(X, W, bias, out, M, N, K, stream, fold)                     \
+                : launch_v2<E, false>(X, W, bias, out, M, N, K, stream, nullptr);
+  switch (epi) {
+    SMI_V2_CASE(EPI_BIAS_F16)
+    SMI_V2_CASE(EPI_RELU_F16)
+    SMI_V2_CASE(EPI_SILU_F16)
+  }
+#undef SMI_V2_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace smi

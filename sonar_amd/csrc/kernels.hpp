@@ -102,6 +102,12 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
                           int N, int K, int ldo, hipStream_t stream, const GemmTileStats* stats = nullptr,
                           const GemmLnFold* fold = nullptr);
 
+// The 4-wave 256x256 engine (gemm_v2.hip): tile-major fp16 in / out, epi in {bias, relu, silu}, optional LayerNorm-fold
+// consumer.  gemm_v2_fits: the launch qualifies (shape, switches); launch_gemm_tn routes to it by itself.
+bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnFold* fold);
+hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias, f16* out, int M, int N, int K,
+                          hipStream_t stream, const GemmLnFold* fold);
+
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)
 // slab_f16: fp16 slabs [ksplit][M][N] instead of fp32 ones (the consumers take the same flag)
 hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, void* parts, int M,

@@ -115,6 +115,50 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
+@pytest.mark.parametrize("m,n,k", [(6144, 4096, 768),      # 384 tiles on 256 workgroups, the shortest K loop the engine takes (24 slices)
+                                   (6144, 4096, 1024),     # the encoder's K; some workgroups walk two tiles, some one
+                                   (16384, 4096, 1280),    # 1024 tiles: XCD-owned raster, four tiles per workgroup, 40 slices
+                                   (2560, 1024, 8192),     # 40 tiles, K = 8192: one tile per workgroup, long loop
+                                   (512, 256, 1024)])      # two tiles: most of the chip idle
+@pytest.mark.parametrize("epi", [0, 1, 5])
+def test_gemm_v2_engine(lib, m, n, k, epi):
+    """The 4-wave 256x256 engine (gemm_v2.hip: accumulators in AGPRs, the previous tile's stores under the next tile's K
+    loop) against the fp32 reference AND against the 8-wave engine on the same operands; three launches in a row must be
+    bit-identical (the deferred stores and the ring that streams across tiles are where a race would show)."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + 3 * n + k + epi)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    xt, wt = to_tile_major(x), to_tile_major(w)
+    ref = x.float() @ w.float().T + bias
+    want = torch.relu(ref) if epi == 1 else (torch.nn.functional.silu(ref) if epi == 5 else ref)
+    flags = _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM | (2 << 8)
+    outs = {}
+    for v2 in (0, 1):
+        with _lib.tuning(G2V2=v2, G2V2_MIN=1):
+            runs = []
+            for rep in range(3 if v2 else 1):
+                out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
+                _lib.check(lib.smi_gemm_tn(epi | flags, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                           m, n, k, n, _stream()))
+                torch.cuda.synchronize()
+                runs.append(out)
+            for r in runs[1:]:
+                assert torch.equal(r, runs[0])
+            outs[v2] = from_tile_major(runs[0], m, n).float()
+    scale = max(want.abs().max().item(), 1.0)
+    for v2 in (0, 1):
+        assert torch.isfinite(outs[v2]).all()
+        err = (outs[v2] - want).abs().max().item()
+        assert err <= 2e-3 * scale, (v2, err, scale)
+    # the two engines add the bias at different ends of the K sum: equal within one rounding of the fp16 result
+    d = (outs[0] - outs[1]).abs().max().item()
+    assert d <= 2e-3 * scale, d
+    assert (outs[0] != outs[1]).float().mean().item() <= 0.02
+
+
 @pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
                                           (1280, 1024, 1024, 2, 0),      # its attention output projection: lone-tile units
                                           (256, 1024, 8192, 8, 1),       # small-batch encoder: 64x64 lone units
