@@ -16,8 +16,8 @@ fairseq training checkpoint).  The fixture stores the inputs and, for the refere
 so the test needs neither /root/reference nor this script.  Run in the build container:
     python tests/golden/make_golden_ckpt.py
 """
-import copy
 import importlib.util
+import io
 import os
 import re
 import sys
@@ -41,6 +41,15 @@ def convert_fairseq_checkpoint(checkpoint, key_map):
         return old
 
     return {"model": {new_key(k): v for k, v in checkpoint["model"].items()}}
+
+
+def clone_ckpt(ck):
+    """A private copy that keeps storage sharing (embed_tokens module <-> state dict entry; the decoder's tied
+    output_projection): what torch.load gives for a checkpoint file.  copy.deepcopy does not keep Parameter / .data sharing."""
+    buf = io.BytesIO()
+    torch.save(ck, buf)
+    buf.seek(0)
+    return torch.load(buf, weights_only=False)
 
 
 def _stub(name, **attrs):
@@ -105,15 +114,16 @@ def make_inputs():
 def main():
     text, speech = load_reference_handlers()
     enc, dec, sp = make_inputs()
-    fixture = {"inputs": {"text_encoder": copy.deepcopy(enc), "text_decoder": copy.deepcopy(dec),
-                          "speech_encoder": copy.deepcopy(sp)}}
+    fixture = {"inputs": {"text_encoder": clone_ckpt(enc), "text_decoder": clone_ckpt(dec),
+                          "speech_encoder": clone_ckpt(sp)}}
     # the reference converters modify their argument in place (key deletion, the in-place row permutation): they get
-    # their own deep copies
-    r_enc = text.convert_sonar_text_encoder_checkpoint(copy.deepcopy(enc))
-    r_dec = text.convert_sonar_text_decoder_checkpoint(copy.deepcopy(dec))
+    # their own copies
+    r_enc = text.convert_sonar_text_encoder_checkpoint(clone_ckpt(enc))
+    r_dec = text.convert_sonar_text_decoder_checkpoint(clone_ckpt(dec))
     cfg = types.SimpleNamespace(w2v2_encoder_config=types.SimpleNamespace(use_conformer=True))
-    r_sp = speech.convert_sonar_speech_checkpoint(copy.deepcopy(sp), cfg)
-    # the encoder converter leaves the permuted table at the TOP level of its result (handler.py:92) next to "model"
+    r_sp = speech.convert_sonar_speech_checkpoint(clone_ckpt(sp), cfg)
+    # the encoder converter permutes checkpoint["embed_tokens"].weight IN PLACE (handler.py:86-91) and leaves it at the TOP
+    # level of its result (:92) next to "model"; the table inside "model" is permuted because it shares that storage
     fixture["reference"] = {
         "text_encoder": {"model": dict(r_enc["model"]),
                          "top_level_embed": r_enc["encoder_frontend.embed.weight"].clone()},

@@ -120,3 +120,45 @@ def test_packed_cache(tmp_path, monkeypatch):
     assert q["encoder.layers.0.self_attn.sdpa.u_bias"].dtype == torch.float32
     assert torch.equal(q["encoder.layers.0.self_attn.sdpa.u_bias"], ub)
     assert torch.equal(q["encoder.layers.0.self_attn.sdpa.v_bias"], ub + 1)
+
+
+def _load_ckpt_reference():
+    import os
+
+    return torch.load(os.path.join(os.path.dirname(__file__), "golden", "ckpt_reference.pt"), weights_only=False)
+
+
+def test_converters_equal_the_reference_handlers():
+    """The three converters against the outputs of the REFERENCE'S OWN converter functions -- sonar_text/handler.py:52-94,
+    :122-172 and sonar_speech/handler.py:46-110, imported by path and executed in the build container by
+    tests/golden/make_golden_ckpt.py (fixture: inputs + every output key with its tensor) -- on the same fairseq1-layout
+    checkpoints.  Key sets and tensors must be identical; the documented differences of this package's flat format are
+    spelled out below."""
+    from sonar_amd.speech_encoder import convert_sonar_speech_checkpoint
+    from sonar_amd.text_decoder import convert_sonar_text_decoder_checkpoint
+    from sonar_amd.text_encoder import convert_sonar_text_encoder_checkpoint
+
+    fx = _load_ckpt_reference()
+    ins, ref = fx["inputs"], fx["reference"]
+
+    # text encoder: the reference returns {"model": renamed state dict} and ALSO leaves the permuted table at the top level
+    # (handler.py:92); in "model" the table is permuted too because the checkpoint's embed_tokens module shares its storage
+    got = convert_sonar_text_encoder_checkpoint((ins["text_encoder"]))
+    want = ref["text_encoder"]["model"]
+    _same(got, want)
+    assert torch.equal(got["encoder_frontend.embed.weight"], ref["text_encoder"]["top_level_embed"])
+    src = ins["text_encoder"]["state_dict"]["embed_tokens.weight"]
+    assert torch.equal(got["encoder_frontend.embed.weight"][[0, 1, 2, 3]], src[[1, 3, 0, 2]])   # (BOS,PAD,EOS,UNK) -> (PAD,UNK,BOS,EOS)
+    assert torch.equal(got["encoder_frontend.embed.weight"][4:], src[4:])
+
+    # text decoder: identical but for final_proj.weight, which this package drops (the engine multiplies by the embedding
+    # table itself: TiedProjection, factory.py:306-307) -- in the reference's output it IS the permuted table
+    got = convert_sonar_text_decoder_checkpoint((ins["text_decoder"]))
+    want = dict(ref["text_decoder"]["model"])
+    tied = want.pop("final_proj.weight")
+    assert torch.equal(tied, want["decoder_frontend.embed.weight"])
+    _same(got, want)
+
+    # speech encoder: identical
+    got = convert_sonar_speech_checkpoint((ins["speech_encoder"]))
+    _same(got, ref["speech_encoder"]["model"])
