@@ -298,10 +298,20 @@ def _decoder_step_cached(params, cfg: OracleTextDecoderConfig, emb: torch.Tensor
 def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: torch.Tensor, prompt: Sequence[int],
                             beam_size: int = 5, min_gen_len: int = 1, max_gen_len: Tuple[int, int] = (1, 128),
                             max_seq_len: Optional[int] = None, normalize_scores: bool = True, len_penalty: float = 1.0,
-                            pad_idx: int = 0, eos_idx: int = 3, source_len: Optional[int] = None) -> List[List[Hypothesis]]:
+                            pad_idx: int = 0, eos_idx: int = 3, source_len: Optional[int] = None,
+                            margins_out: Optional[list] = None) -> List[List[Hypothesis]]:
     """beam_search() with incremental decoding (K/V cache, index_select re-ordering): the evaluation order of the
     reference's generator.  Same hypotheses as beam_search (tests/test_oracle_decoder_cpu.py); linear instead of
-    quadratic work in the output length, so this is the variant bench.py times as the CPU baseline."""
+    quadratic work in the output length, so this is the variant bench.py times as the CPU baseline.
+
+    margins_out (a list): per sentence (decision margin, final margin) of THIS search is appended --
+    decision margin = over all steps, the smallest gap between neighbours of the sorted candidate list among the candidates
+    the beam rules consumed plus the first one they did not (a gap below the arithmetic noise of another implementation
+    means that implementation may legitimately order the two candidates the other way round); final margin = score gap
+    between the best finished hypothesis and the runner-up; third entry = the decision margin without the step at the
+    length cap (every candidate a forced EOS: the engine ranks those by the final scores and reports that gap as its final
+    margin) -- the number the engine's own decision margin is cross-checked against.  The parity tests excuse a token
+    mismatch ONLY by these oracle-side numbers (VERDICT r5 "weak" 2), never by the engine's own report."""
     model_max = max_seq_len if max_seq_len is not None else cfg.max_seq_len
     plen = len(prompt)
     if source_len is None:
@@ -319,6 +329,7 @@ def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: to
             cum[0, pos + 1] = cum[0, pos] + lp[0, seqs[0, pos + 1]]
         finished: List[Hypothesis] = []
         step_nr = plen
+        dec_margin = dec_margin_free = float("inf")
         while True:
             b = seqs.shape[0]
             logits = _decoder_step_cached(params, cfg, emb.expand(b, -1), seqs[:, -1], step_nr - 1, st)
@@ -337,7 +348,9 @@ def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: to
             eos_mask = vocab_idx == eos_idx
             done = False
             head = eos_mask[:beam_size]
-            for si, sc in zip(seq_idx[:beam_size][head].tolist(), top_scores[:beam_size][head].tolist()):
+            completing = -1          # sorted index of the EOS candidate that completes the beam in this step
+            head_pos = torch.nonzero(head).view(-1).tolist()
+            for hp, si, sc in zip(head_pos, seq_idx[:beam_size][head].tolist(), top_scores[:beam_size][head].tolist()):
                 seq = torch.cat([seqs[si], torch.tensor([eos_idx])])
                 steps = torch.cat([cum[si], torch.tensor([sc])])
                 seq_len = step_nr + 1
@@ -346,7 +359,24 @@ def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: to
                 finished.append(Hypothesis(seq[plen:], float(score), out_steps))
                 if len(finished) == beam_size:
                     done = True
+                    completing = hp
                     break
+            if margins_out is not None:
+                # candidates the beam rules consumed (csrc/decoder.hip states the same rule for the engine's own report): up to
+                # the EOS candidate that completed the beam, else up to the beam_size-th non-EOS candidate; + the first
+                # candidate NOT consumed
+                last = completing
+                if not done:
+                    non_eos = torch.nonzero(~eos_mask).view(-1)
+                    last = int(non_eos[min(beam_size, non_eos.numel()) - 1]) if non_eos.numel() else top_scores.numel() - 1
+                upto = min(last + 1, top_scores.numel() - 1)
+                if upto >= 1:
+                    gaps = top_scores[:upto] - top_scores[1:upto + 1]
+                    gaps = gaps[torch.isfinite(gaps)]
+                    if gaps.numel():
+                        dec_margin = min(dec_margin, float(gaps.min()))
+                        if step_nr != max_len - 1:   # not the step at the length cap, where every candidate is a forced EOS
+                            dec_margin_free = min(dec_margin_free, float(gaps.min()))
             if done:
                 break
             keep = ~eos_mask
@@ -359,6 +389,9 @@ def beam_search_incremental(params, cfg: OracleTextDecoderConfig, embeddings: to
                 break
         finished.sort(key=lambda h: h.score, reverse=True)
         results.append(finished)
+        if margins_out is not None:
+            fin = finished[0].score - finished[1].score if len(finished) > 1 else float("inf")
+            margins_out.append((dec_margin, fin, dec_margin_free))
     return results
 
 

@@ -56,9 +56,10 @@ def _rescored(OD, params, ocfg, e, prompt, seq):
 
 # "Exact token-id match for greedy decode" (BASELINE north_star), stated honestly: every token of every
 # best hypothesis equals the fp32 CPU oracle's, EXCEPT for a sentence whose decision margin -- measured
-# by the engine itself during the run (smi_text_decoder_last_margins) -- is below EPS_REL of the logit
-# range, i.e. where two candidates are closer than fp16 arithmetic can separate.  Such a sentence must
-# still return a hypothesis whose oracle score equals the oracle's best within the same epsilon.
+# BY THE ORACLE on its own candidate lists (tests/neartie.py; the engine's report, smi_text_decoder_last_margins,
+# is only cross-checked against it) -- is below EPS_REL of the logit range, i.e. where two candidates are
+# closer than fp16 arithmetic can separate.  Such a sentence must still return a hypothesis whose oracle
+# score equals the oracle's best within the same epsilon.
 EPS_REL = 1e-3
 
 
@@ -69,13 +70,16 @@ def _logit_range(OD, params, ocfg, emb, prompt):
 
 @pytest.mark.parametrize("beam", [1, 3, 5])
 def test_beam_search_vs_oracle(setup, beam):
+    from tests.neartie import check_engine_margin, oracle_excuses
+
     OD, ocfg, params, eng = setup
     g = torch.Generator().manual_seed(10 + beam)
     n = 24
     emb = torch.randn(n, ocfg.model_dim, generator=g) * 0.3
     prompt = [3, 700]
     kw = dict(beam_size=beam, max_gen_len=(0, 13))
-    ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
+    om = []
+    ref = OD.beam_search_incremental(params, ocfg, emb, prompt, margins_out=om, **kw)
     toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
     margins = eng.last_margins(n).cpu()
     torch.cuda.synchronize()
@@ -96,11 +100,12 @@ def test_beam_search_vs_oracle(setup, beam):
         assert k == beam
         assert all(scores[i, j] >= scores[i, j + 1] - 1e-6 for j in range(k - 1))
         assert margins[i, 0] >= 0 and (beam == 1 or margins[i, 1] >= 0)
+        check_engine_margin(margins[i], om[i], eps, f"beam {beam}, sentence {i}")
         if seq != ref[i][0].seq.tolist():
-            step_gap, final_gap = margins[i, 0].item(), margins[i, 1].item()
-            assert step_gap < eps or final_gap < eps, (
-                f"sentence {i}: tokens differ from the oracle although every decision margin the engine "
-                f"measured (step {step_gap:.3e}, final {final_gap:.3e}) is above eps {eps:.3e}")
+            step_gap, final_gap = om[i][:2]
+            assert oracle_excuses(om[i], eps), (
+                f"sentence {i}: tokens differ from the oracle although every decision margin the ORACLE "
+                f"measured (step {step_gap:.3e}, final {final_gap:.3e}) is above eps {eps:.3e}; engine's: {margins[i].tolist()}")
             # a measured near-tie: the returned hypothesis must be as good as the oracle's best
             assert abs(norm - ref[i][0].score) <= 2 * eps, (norm, ref[i][0].score)
             excused.append((i, step_gap, final_gap))
@@ -216,7 +221,7 @@ def test_independent_chains_return_the_single_chain_hypotheses(setup, chains):
         assert torch.equal(a, b)
     same = int((free_one[:, 0] == free_got[:, 0]).all(dim=1).sum())
     print(f"chains {chains}: bit-identical with pinned tile shapes; {same}/{n} best hypotheses identical with free ones")
-    assert same >= 0.9 * n
+    assert same >= n - max(3, n // 50)   # observed (r05, r06): 300 / 301; the difference is a near-tie under another summation order
 
 
 def test_beam_logits_storage_type(setup):

@@ -135,7 +135,10 @@ def test_beam5_long_runs_rescored_and_vs_oracle_search(setup, forced):
     toks, lens, scores = eng.generate(emb.cuda(), prompt, beam_size=beam, **kw)
     margins = eng.last_margins(n).cpu()
     toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
-    ref = OD.beam_search(params, ocfg, emb, prompt, beam_size=beam, **kw)
+    from tests.neartie import check_engine_margin, oracle_excuses
+
+    om = []
+    ref = OD.beam_search_incremental(params, ocfg, emb, prompt, beam_size=beam, margins_out=om, **kw)
     eps = EPS_REL * _logit_range(OD, params, ocfg, emb, prompt)
     same, excused = 0, []
     for i in range(n):
@@ -150,13 +153,14 @@ def test_beam5_long_runs_rescored_and_vs_oracle_search(setup, forced):
             assert abs(total / (len(prompt) + L - 1) - scores[i, j].item()) <= 5e-3, (i, j, total, scores[i, j].item())
         assert all(scores[i, j] >= scores[i, j + 1] - 1e-6 for j in range(beam - 1))
         best = toks[i, 0, : int(lens[i, 0])].tolist()
+        check_engine_margin(margins[i], om[i], eps, f"{forced} forced steps, sentence {i}")
         if best == ref[i][0].seq.tolist():
             same += 1
             continue
-        step_gap, final_gap = margins[i, 0].item(), margins[i, 1].item()
-        assert step_gap < eps or final_gap < eps, (
-            f"sentence {i}: best hypothesis differs from the oracle's although every decision margin the engine "
-            f"measured (step {step_gap:.3e}, final {final_gap:.3e}) is above eps {eps:.3e}")
+        step_gap, final_gap = om[i][:2]
+        assert oracle_excuses(om[i], eps), (
+            f"sentence {i}: best hypothesis differs from the oracle's although every decision margin the ORACLE "
+            f"measured (step {step_gap:.3e}, final {final_gap:.3e}) is above eps {eps:.3e}; engine's: {margins[i].tolist()}")
         # a measured near tie somewhere in > 700 candidate rankings: the returned hypothesis must still be as
         # good as the oracle's best
         assert abs(scores[i, 0].item() - ref[i][0].score) <= 2 * eps, (scores[i, 0].item(), ref[i][0].score)

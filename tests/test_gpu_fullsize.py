@@ -258,6 +258,28 @@ def basic_decoder():
     return OD, ocfg, params, eng
 
 
+# observed on MI355X (r06h): 1.0000 on 36 / 140 / 24 (row, position) pairs.  One flip between two candidates the fp16 arithmetic
+# cannot separate is box-to-box noise (1 / 36 = 2.8 %); anything beyond that is a defect.
+ARGMAX_AGREE_MIN = 0.97
+
+
+def _argmax_agreement(got, ref):
+    """Share of (row, position) pairs whose arg-max token equals the oracle's; where it differs the oracle's top-2 gap must
+    be within the logit error bound of the test (a flip between two candidates the arithmetic cannot separate)."""
+    ga, ra = got.argmax(-1), ref.argmax(-1)
+    agree = (ga == ra).float().mean().item()
+    bad = (ga != ra).nonzero()
+    worst = 0.0
+    for idx in bad.tolist():
+        row = ref[tuple(idx)]
+        worst = max(worst, (row.max() - row[ga[tuple(idx)]]).item())
+    print(f"arg-max agreement with the oracle: {agree:.4f} ({bad.shape[0]} of {ga.numel()} differ; largest oracle gap at a "
+          f"differing position {worst:.3e})")
+    assert agree >= ARGMAX_AGREE_MIN, agree
+    assert worst <= 2 * 5e-3 * ref.abs().max().item(), worst
+    return agree
+
+
 def test_basic_decoder_logits_vs_oracle_full_size(basic_decoder):
     """text_sonar_basic_decoder (24 layers, d 1024, F 8192, V 256206): teacher-forced logits of 4 sentences x 9
     positions against the fp32 oracle (the reference's own logits check has this shape, test_text_sonar.py:61-105)."""
@@ -274,20 +296,23 @@ def test_basic_decoder_logits_vs_oracle_full_size(basic_decoder):
     print(f"basic decoder logits: max |diff| {err:.3e} on scale {scale:.3f} ({err / scale:.2e} relative)")
     assert got.shape == ref.shape == (4, 9, 256206)
     assert err <= 5e-3 * scale
-    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+    _argmax_agreement(got, ref)
 
 
 @pytest.mark.parametrize("beam", [1, 5])
 def test_basic_decoder_tokens_vs_oracle_full_size(basic_decoder, beam):
-    """Exact token ids at full size: every best hypothesis equals the fp32 oracle's unless the engine's own
-    measured decision margin is below 1e-3 of the logit range (see tests/test_gpu_decoder.py)."""
+    """Exact token ids at full size: every best hypothesis equals the fp32 oracle's unless the ORACLE's own decision margin
+    is below 1e-3 of the logit range (tests/neartie.py); the engine's reported margin must agree with the oracle's."""
+    from tests.neartie import check_engine_margin, oracle_excuses
+
     OD, ocfg, params, eng = basic_decoder
     g = torch.Generator().manual_seed(43 + beam)
     n, steps = 4, 9
     emb = F.normalize(torch.randn(n, 1024, generator=g), dim=-1) * 0.2
     prompt = [3, 256047]
     kw = dict(beam_size=beam, max_gen_len=(0, steps))
-    ref = OD.beam_search(params, ocfg, emb, prompt, **kw)
+    om = []
+    ref = OD.beam_search_incremental(params, ocfg, emb, prompt, margins_out=om, **kw)
     toks, lens, scores = eng.generate(emb.cuda(), prompt, **kw)
     margins = eng.last_margins(n).cpu()
     toks, lens, scores = toks.cpu(), lens.cpu(), scores.cpu()
@@ -297,12 +322,13 @@ def test_basic_decoder_tokens_vs_oracle_full_size(basic_decoder, beam):
     for i in range(n):
         seq = toks[i, 0, : int(lens[i, 0])].tolist()
         want = ref[i][0].seq.tolist()
+        check_engine_margin(margins[i], om[i], eps, f"beam {beam}, sentence {i}")
         assert abs(scores[i, 0].item() - ref[i][0].score) <= 5e-3 or seq != want
         if seq != want:
-            assert margins[i, 0].item() < eps or margins[i, 1].item() < eps, (i, seq, want, margins[i].tolist(), eps)
+            assert oracle_excuses(om[i], eps), (i, seq, want, om[i], margins[i].tolist(), eps)
             excused += 1
     print(f"basic decoder beam {beam}: {n - excused}/{n} token-identical to the oracle, eps {eps:.2e}, "
-          f"margins {margins.tolist()}")
+          f"oracle margins {om}, engine margins {margins.tolist()}")
     assert excused <= 1
 
 
@@ -326,7 +352,7 @@ def test_basic_decoder_long_prefix_vs_oracle_full_size(basic_decoder):
     print(f"basic decoder logits over {t} positions: max |diff| / scale {err.max().item() / scale:.2e} "
           f"(worst position {int(err.argmax())}), last position {err[-1].item() / scale:.2e}")
     assert err.max().item() <= 5e-3 * scale
-    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.9
+    _argmax_agreement(got, ref)
     del got, ref
 
     prompt = [3, 256047]
@@ -402,19 +428,23 @@ def test_basic_decoder_chains_bit_identical_full_size(basic_decoder):
 C5_SAMPLE = [0, 51, 52, 101, 127, 128, 204, 255]     # rows 0, 255|256|260, 505, 635, 640, 1 020|1 024, 1 275..1 279
 
 
-def _check_hyps_vs_oracle(tag, ref, toks, lens, scores, margins, where, eps, max_excused):
-    """Best hypothesis of sentence where[j] of the GPU call == the oracle's j-th, or the engine's own decision margin is a near-tie."""
+def _check_hyps_vs_oracle(tag, ref, omargins, toks, lens, scores, margins, where, eps, max_excused):
+    """Best hypothesis of sentence where[j] of the GPU call == the oracle's j-th; a mismatch is excused ONLY by the ORACLE's own
+    near-tie measurement (tests/neartie.py), and the engine's reported decision margin must agree with the oracle's."""
+    from tests.neartie import check_engine_margin, oracle_excuses
+
     excused = 0
     for j, i in enumerate(where):
         seq = toks[i, 0, : int(lens[i, 0])].tolist()
         want = ref[j][0].seq.tolist()
+        check_engine_margin(margins[i], omargins[j], eps, f"{tag}, sentence {i}")
         if seq == want:
             assert abs(scores[i, 0].item() - ref[j][0].score) <= 5e-3, (tag, i, scores[i, 0].item(), ref[j][0].score)
         else:
-            assert margins[i, 0].item() < eps or margins[i, 1].item() < eps, (tag, i, seq, want, margins[i].tolist(), eps)
+            assert oracle_excuses(omargins[j], eps), (tag, i, seq, want, omargins[j], margins[i].tolist(), eps)
             excused += 1
     print(f"basic decoder C5 shape [{tag}]: {len(where) - excused}/{len(where)} sampled best hypotheses token-identical to the oracle "
-          f"(eps {eps:.2e}, margins of the sample {[round(m, 4) for m in margins[where, 0].tolist()]})")
+          f"(eps {eps:.2e}; oracle decision margins {[round(m[0], 4) for m in omargins]}, engine's {[round(m, 4) for m in margins[where, 0].tolist()]})")
     assert excused <= max_excused
     return excused
 
@@ -434,7 +464,8 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
     emb = emb.half().float()                 # what the fp16 pipeline hands over; the oracle sees the same values
     prompt = [3, 256047]
     kw = dict(beam_size=5, min_gen_len=steps, max_gen_len=(0, steps))
-    ref = OD.beam_search_incremental(params, ocfg, emb[C5_SAMPLE], prompt, **kw)
+    om = []
+    ref = OD.beam_search_incremental(params, ocfg, emb[C5_SAMPLE], prompt, margins_out=om, **kw)
     lg = OD.decoder_logits(params, ocfg, emb[:1], torch.tensor([prompt]))
     eps = 1e-3 * (lg.max() - lg.min()).item()
     try:
@@ -444,7 +475,7 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
             toks, lens, scores = [t.cpu() for t in eng.generate(emb.cuda().half(), prompt, **kw)]
             margins = eng.last_margins(n).cpu()
             assert (lens[:, 0] == steps).all()           # min_gen_len == max_gen_len: every hypothesis ends at the cap
-            _check_hyps_vs_oracle(f"256 sentences, {dt} storage", ref, toks, lens, scores, margins, C5_SAMPLE, eps, 1)
+            _check_hyps_vs_oracle(f"256 sentences, {dt} storage", ref, om, toks, lens, scores, margins, C5_SAMPLE, eps, 1)
     finally:
         eng.set_beam_logits_dtype(torch.float16)
         eng.set_slab_dtype(torch.float16)
@@ -456,7 +487,7 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
     emb2[1::2] = (F.normalize(torch.randn(n, 1024, generator=g2), dim=-1) * 0.2).half().float()
     toks, lens, scores = [t.cpu() for t in eng.generate(emb2.cuda().half(), prompt, **kw)]
     margins = eng.last_margins(2 * n).cpu()
-    _check_hyps_vs_oracle("512 sentences, default chains", ref, toks, lens, scores, margins, [2 * i for i in C5_SAMPLE], eps, 1)
+    _check_hyps_vs_oracle("512 sentences, default chains", ref, om, toks, lens, scores, margins, [2 * i for i in C5_SAMPLE], eps, 1)
     del toks, lens, scores
 
     # (2) teacher-forced logits, 1 280 rows x 3 positions: row r carries embedding r // 5 (the beam layout of the C5 call)
@@ -473,7 +504,7 @@ def test_basic_decoder_c5_shape_vs_oracle_full_size(basic_decoder):
     err = (got - want).abs().max().item()
     print(f"basic decoder logits at 1280 rows: max |diff| {err:.3e} on scale {scale:.3f} ({err / scale:.2e} relative)")
     assert err <= 5e-3 * scale
-    assert (got.argmax(-1) == want.argmax(-1)).float().mean().item() >= 0.9
+    _argmax_agreement(got, want)
 
 
 def test_speech_encoder_english_10s_clip_vs_oracle_full_size():
