@@ -327,8 +327,8 @@ def load() -> C.CDLL:
     if lib.smi_abi_version() != ABI_VERSION:  # the structs carry no size field: refuse a library of another revision
         raise RuntimeError(f"{LIB_PATH} has ABI revision {lib.smi_abi_version()}, this binding speaks {ABI_VERSION}: "
                            "rebuild with `python -m sonar_amd.build --force`")
+    _forward_env_switches(lib)   # BEFORE the handle is cached: a malformed SMI_<NAME> raises on every load(), not only the first
     _lib = lib
-    _forward_env_switches(lib)
     return lib
 
 
@@ -360,14 +360,23 @@ def _forward_env_switches(lib: C.CDLL) -> None:
             iv = int(v)
         except ValueError:
             raise RuntimeError(f"SMI_{nm.decode()}={v!r}: tuning switches are integers") from None
+        _check_i32(nm.decode(), iv)
         if lib.smi_tuning_set(nm, iv) != SMI_OK:
             raise RuntimeError(lib.smi_last_error().decode("utf-8", "replace"))
+
+
+def _check_i32(name: str, value: int) -> None:
+    """smi_tuning_set takes an int32: refuse what ctypes would silently truncate."""
+    if not -2 ** 31 <= value < 2 ** 31:
+        raise ValueError(f"tuning switch {name}={value} does not fit an int32")
 
 
 def set_tuning(**switches) -> None:
     """set_tuning(LONE=0, DEC_KS_OUT=2): process-wide tuning switches (None unsets one)."""
     lib = load()
     for name, value in switches.items():
+        if value is not None:
+            _check_i32(name, int(value))
         rc = lib.smi_tuning_unset(name.encode()) if value is None else lib.smi_tuning_set(name.encode(), int(value))
         check(rc)
 

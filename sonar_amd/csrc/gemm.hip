@@ -658,7 +658,8 @@ __global__ __launch_bounds__(G2_THREADS) void gemm_tn256_kernel(const f16* __res
       // the unpack, the maximum of the RAW rounded values (scale > 0: max and scaling commute, bit for bit), the scaled
       // exponent as one v_pk_fma_f32 per two values, packed adds: ~8 slots per element, and the 16 stores of a wave leave
       // spread over the pass instead of as one burst behind it.
-      if (stats.tile_max && n0 + G2_BN <= stats.valid_n && !folded) {
+      // (stats.scale > 0 is what lets the maximum be taken before the scaling; any other scale takes the general code below)
+      if (stats.tile_max && n0 + G2_BN <= stats.valid_n && !folded && stats.scale > 0.f) {
         stats_stored = true;
         float2* red = (float2*)(bias_lds + 256);  // [256 rows][4 column waves]
         const float sc2 = stats.scale * 1.4426950408889634f;

@@ -38,7 +38,7 @@ namespace smi {
   X(SPEECH_MID_TM)   /* speech encoder: [1] tile-major outputs of the per-clip kernels (at create) */                   \
   X(SPEECH_X_TM)     /* speech encoder: [1] tile-major residual stream + LayerNorm fold (at create) */                  \
   X(XSIM_TM)         /* xsim: [1] tile-major normalised operands, 0 row-major */                                        \
-  X(XSIM_LL)         /* xsim k >= 2: [1] per-row lists in LDS, 0 per-lane register lists (set before the first workspace query) */
+  X(XSIM_LL)         /* xsim k >= 2: [1] per-row lists in LDS, 0 per-lane register lists */
 
 enum Tune : int {
 #define SMI_TUNE_ENUM(n) TUNE_##n,

@@ -762,7 +762,7 @@ static bool xsim_tm() {
   return tune(TUNE_XSIM_TM, 1) != 0;
 }
 // SMI_XSIM_LL=0: per-lane top-k lists in registers (rounds 1-3; k = 8 then runs on the 128x128 engine) instead of the
-// per-row lists in LDS -- A/B switch, read once (the workspace formula depends on it)
+// per-row lists in LDS -- A/B switch (the workspace formula does not depend on it)
 static bool xsim_ll() {
   return tune(TUNE_XSIM_LL, 1) != 0;
 }
@@ -776,9 +776,12 @@ static size_t xsim_lists_bytes(int64_t nx_pad, int64_t ny_pad, int K) {
   return (size_t)xsim_chunks(ny_pad / GT_BN) * nx_pad * K * 8;
 }
 // ... followed (256x256 engine) by the tile-major copies of Xn and Yn
+// The formula does NOT depend on the tuning switches (XSIM_LL decides whether k = 8 runs on the 256x256 engine and therefore
+// whether the copies are written): it is the upper bound over their states, so a switch set by another host thread between a
+// caller's workspace query and its smi_xsim_topk can never make xsim_run write past the size the API validated.
 size_t xsim_workspace_bytes(int64_t nx_pad, int64_t ny_pad, int k, int d) {
   const int K = round_k(k);
-  const size_t tm = xsim_on_256(K) ? (size_t)(nx_pad + ny_pad) * d * sizeof(f16) : 0;
+  const size_t tm = (size_t)(nx_pad + ny_pad) * d * sizeof(f16);
   return xsim_lists_bytes(nx_pad, ny_pad, K) + tm;
 }
 

@@ -399,10 +399,13 @@ class SonarEncoderDecoderModel:
         """The engines live on the HIP device they were created on; `.to` accepts that device and nothing else."""
         if device is not None and torch.device(device).type != "cpu":
             want, have = torch.device(device), torch.device(self.device)
-            if want.type == "cuda" and want.index is None:      # `.to("cuda")`: the current device, as torch resolves it
-                want = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+            # an index-less "cuda" means the CURRENT device on both sides, as torch resolves it (ADVICE r5: resolving one side
+            # to the current device and the other to cuda:0 made `.to("cuda")` fail on a rank whose current device is not 0)
+            cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
+            if want.type == "cuda" and want.index is None:
+                want = torch.device("cuda", cur)
             if have.type == "cuda" and have.index is None:
-                have = torch.device("cuda", 0)
+                have = torch.device("cuda", cur)
             if want != have:
                 raise RuntimeError(f"the engine-backed model lives on {self.device}")
         return self
