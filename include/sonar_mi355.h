@@ -548,7 +548,7 @@ int smi_host_audio_decode(const uint8_t* bytes, int64_t nbytes, float* out, int6
  * 256x256 tile engine, so one K slice of a tile is one linear 16 KiB read.  The encoder keeps
  * every GEMM operand (weights, LayerNorm / attention / FFN-inner outputs) in this layout. */
 #define SMI_GEMM_IN_TM (1 << 12)  /* x and w are tile-major (m, n % 256 == 0) */
-#define SMI_GEMM_OUT_TM (1 << 13) /* f16 output tile-major, as the next GEMM's x (needs IN_TM, ldo == n); with epilogue 8: the
+#define SMI_GEMM_OUT_TM (1 << 13) /* f16 output tile-major, as the next GEMM's x (needs IN_TM, ldo == n); with epilogues 8 / 9: the
                                    * f16 residual stream that is read-modified-written is tile-major */
 /* dst <- tile-major(src) (inverse == 0) or dst <- row-major(src) (inverse != 0); f16, device. */
 int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_t k, int32_t inverse,
@@ -558,7 +558,7 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
  * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out, 8 f16 residual accumulate
  * (out_f16 = f16(float(out_f16) + ...), one rounding), 9 the same with 0.5 * (...) (bias may be NULL);
  * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
- * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 6, 8, 9) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5, 8).
+ * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 6, 8, 9) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5, 8, 9).
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);

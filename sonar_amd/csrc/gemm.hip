@@ -1338,6 +1338,8 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     }
     // producer: the tile-major residual epilogue (part_out may be null: plain read-modify-write of the stream)
     if (!out_tm) return hipErrorInvalidValue;
+    if ((epi == EPI_RESID_F16 || epi == EPI_RESID_HALF_F16) && gemm_v2_fits(epi, M, N, K, bias, fold))
+      return launch_gemm_v2(epi, X, W, bias, (f16*)out, M, N, K, stream, fold);
     if (epi == EPI_RESID_F16) return launch_one256<EPI_RESID_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);
     if (epi == EPI_RESID_HALF_F16)
       return launch_one256<EPI_RESID_HALF_F16, 3>(X, W, bias, out, M, N, K, ldo, stream, nullptr, 1, 0, fold);

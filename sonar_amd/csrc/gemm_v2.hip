@@ -158,8 +158,10 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_kernel(const f16* __restri
     tile = seek(tile + (int)gridDim.x);
     more = tile < nvirt;
     if (more) {
-      st.xp = (const char*)X + (size_t)tile_m * panel + voff;
-      st.wp = (const char*)W + (size_t)tile_n * panel + voff;
+      unsigned vo = voff;  // opaque: keeps hipcc from holding X + voff / W + voff in four VGPRs across the loop (it spilled them)
+      asm volatile("" : "+v"(vo));
+      st.xp = (const char*)X + (size_t)tile_m * panel + vo;
+      st.wp = (const char*)W + (size_t)tile_n * panel + vo;
     } else {
       st.xp -= st.inc;
       st.wp -= st.inc;
@@ -300,6 +302,260 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_kernel(const f16* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The fp16 tile-major RESIDUAL STREAM on the same engine: x[m][n] = f16(float(x[m][n]) + RSTEP * (acc + bias[n])), read-modify-
+// write in place (EPI_RESID_F16, RSTEP = 1: attention output / FFN output projections; EPI_RESID_HALF_F16, 0.5: the conformer's
+// macaron FFNs), optionally leaving the LayerNorm-fold partial sums of the rows it has just written (EMIT; GemmLnFold
+// producer: part_out[N/256][M] (sum, sum of squares) over the tile's 256 columns of the ROUNDED new values).
+//   * the 32 old chunks of a lane (its piece of the old tile) are requested by asm loads the compiler does not see (it would
+//     drain the LDS-DMA queue in front of the first use): k-blocks 0..2 in the tile's last three K steps, 8 loads per step,
+//     k-block 3 at the start of the read-out, where its latency hides behind the arithmetic of k-blocks 0..2.  Vector-memory
+//     operations retire in issue order, so two counted waits in the read-out cover them (the first one also retires slice 1
+//     of the next tile, which step 0 needs anyway).  Nothing of the old tile's latency is exposed.
+//   * a wave covers 128 of the tile's 256 columns: the two column waves of a row half leave their row sums in LDS during
+//     the read-out and wave u adds and stores rows 64u .. 64u+63 behind the barrier of the next K step.
+template <int EPI, bool EMIT>
+__global__ __launch_bounds__(V2_THREADS) void gemm_v2_resid_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+                                                                   const float* __restrict__ bias, f16* __restrict__ out, int M,
+                                                                   int N, int K, int raster, float2* __restrict__ part_out) {
+  static_assert(EPI == EPI_RESID_F16 || EPI == EPI_RESID_HALF_F16, "fp16 residual stream epilogues");
+  constexpr float RSTEP = EPI == EPI_RESID_HALF_F16 ? 0.5f : 1.0f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const V2Ring rg = v2_make_ring(smem, wave, lane);
+  const unsigned voff = wave * 4096 + lane * 16;
+
+  const int ntm = M / 256, ntn = N / 256, nt = K / 32, nout = ntm * ntn;
+  const int nq = ntn / 4;
+  const int nvirt = raster ? ((ntm + 63) / 64) * nq * 256 : nout;
+  auto coords = [&](int t, int& tm_, int& tn_) -> bool {
+    if (raster == 0) {
+      constexpr int GM = 8;
+      const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+      const int gsz = min(GM, ntm - first_m), in_group = t - group * per_group;
+      tm_ = first_m + in_group % gsz;
+      tn_ = in_group / gsz;
+      return true;
+    }
+    const int q = t / 256, c = (t % 256) / 32, j = t % 32;
+    tm_ = (c + 8 * (q / nq)) * 8 + j % 8;
+    tn_ = ((q + (raster == 2 ? c : 0)) % nq) * 4 + j / 8;
+    return tm_ < ntm;
+  };
+  int tile_m = 0, tile_n = 0;
+  auto seek = [&](int t) {
+    while (t < nvirt && !coords(t, tile_m, tile_n)) t += gridDim.x;
+    return t;
+  };
+  int tile = seek(xcd_remap(blockIdx.x, gridDim.x));
+  if (tile >= nvirt) return;
+
+  const size_t panel = (size_t)nt * (TM_BLOCK * 2);
+  V2Stream st;
+  st.xp = (const char*)X + (size_t)tile_m * panel + voff;
+  st.wp = (const char*)W + (size_t)tile_n * panel + voff;
+  st.inc = TM_BLOCK * 2;
+  V2Frag f;
+  v2_start(f, st, rg);
+
+  // per-wave LDS area above the ring: bias[128] at +0; this wave's row sums float2[128] at +6144
+  const unsigned cbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + V2_RING_BYTES + wave * V2_CONST_BYTES);
+  const unsigned lds_const0 = (unsigned)(size_t)smem + V2_RING_BYTES;
+  const bool has_bias = bias != nullptr;
+  const float* bias_src = has_bias ? bias : (const float*)W;  // no bias: the same two DMA instructions from a valid address
+  auto fetch_consts = [&](int n0) {
+    const float* bp = bias_src + (has_bias ? n0 + wc * 128 : 0) + lane;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off\n\tglobal_load_lds_dword %0, off offset:256"
+                 :
+                 : "v"(bp), "s"(cbase)
+                 : "memory");
+  };
+  constexpr int NCONST = 2;
+  constexpr int NEMIT = EMIT ? 1 : 0;
+  constexpr int NST = 32;
+
+  const int cidx = (kg & 1) * 2 + (kg >> 1);
+  const unsigned lane_part = (unsigned)(((wr * 128 + l15) * 32 + ((cidx ^ tm_swz(l15)) << 3)) * 2);
+  auto tile_out = [&](int tm_, int tn_) {
+    return (char*)out + ((size_t)tm_ * (N >> 5) + (size_t)tn_ * 8 + wc * 4) * (TM_BLOCK * 2);
+  };
+  // the row sums of the PREVIOUS tile: wave u adds the two column waves' halves of rows 64u .. 64u+63 and stores them
+  int prev_m0 = 0, prev_tn = 0;
+  auto emit_rowsums = [&]() {
+    if constexpr (EMIT) {
+      const int r = wave * 64 + lane;                      // tile row
+      const unsigned src = lds_const0 + ((r >> 7) * 2) * V2_CONST_BYTES + 6144 + (r & 127) * 8;
+      float2 a, b;
+      asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(a), "=&v"(b)
+                   : "v"(src), "n"(V2_CONST_BYTES)
+                   : "memory");
+      part_out[(size_t)prev_tn * M + prev_m0 + r] = float2{a.x + b.x, a.y + b.y};
+    }
+  };
+
+  half8 oldv[4][8];  // [k-block j][16-row block mi]
+  bool more = true, first_tile = true;
+  while (more) {
+    const int n0 = tile_n * 256;
+    // ---- steps 0..3 (queue: ... DMA slice 1, DMA slice 2, [previous tile: NST stores] | step 0: consts, row sums, DMA slice 3)
+    if (first_tile) {
+      v2_step_top<8>();
+      fetch_consts(n0);
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8 + NCONST>();
+    } else {
+      v2_step_top<8 + NST>();
+      fetch_consts(n0);
+      emit_rowsums();
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8 + NCONST + NEMIT + NST>();
+    }
+    first_tile = false;
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<3, false>(f, st, rg);
+    for (int kb = 4; kb < nt - 4; kb += 4) {
+      v2_step_top<8>();
+      v2_step_body<0, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<1, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<2, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<3, false>(f, st, rg);
+    }
+    // ---- the last four steps: the operand stream moves on; the old tile is requested, k-block j in step nt-3+j (8 loads
+    // in front of the step's DMA: the next step's counted wait is 8 + 8)
+    const int tm_cur = tile_m, tn_cur = tile_n;
+    char* const obase = tile_out(tm_cur, tn_cur);
+#define SMI_V2_OLD(J)                                                                                                   \
+  {                                                                                                                     \
+    const char* o0 = obase + (size_t)(J) * (TM_BLOCK * 2) + lane_part;                                                  \
+    const char* o1 = o0 + 4096;                                                                                         \
+    asm volatile(                                                                                                       \
+        "global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:1024\n\t"                           \
+        "global_load_dwordx4 %2, %8, off offset:2048\n\tglobal_load_dwordx4 %3, %8, off offset:3072\n\t"               \
+        "global_load_dwordx4 %4, %9, off\n\tglobal_load_dwordx4 %5, %9, off offset:1024\n\t"                           \
+        "global_load_dwordx4 %6, %9, off offset:2048\n\tglobal_load_dwordx4 %7, %9, off offset:3072"                    \
+        : "=&v"(oldv[J][0]), "=&v"(oldv[J][1]), "=&v"(oldv[J][2]), "=&v"(oldv[J][3]), "=&v"(oldv[J][4]),                \
+          "=&v"(oldv[J][5]), "=&v"(oldv[J][6]), "=&v"(oldv[J][7])                                                       \
+        : "v"(o0), "v"(o1)                                                                                              \
+        : "memory");                                                                                                    \
+  }
+    v2_step_top<8>();
+    v2_step_body<0, false>(f, st, rg);
+    tile = seek(tile + (int)gridDim.x);
+    more = tile < nvirt;
+    if (more) {
+      unsigned vo = voff;  // opaque: keeps hipcc from holding X + voff / W + voff in four VGPRs across the loop (it spilled them)
+      asm volatile("" : "+v"(vo));
+      st.xp = (const char*)X + (size_t)tile_m * panel + vo;
+      st.wp = (const char*)W + (size_t)tile_n * panel + vo;
+    } else {
+      st.xp -= st.inc;
+      st.wp -= st.inc;
+      st.inc = 0;
+    }
+    v2_step_top<8>();
+    SMI_V2_OLD(0)
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<16>();
+    SMI_V2_OLD(1)
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<16>();
+    SMI_V2_OLD(2)
+    v2_step_body<3, false>(f, st, rg);
+
+    // ---- read-out.  k-block 3 of the old tile is requested now (its latency hides behind the read-out of k-blocks 0..2;
+    // 96 instead of 128 registers of old data across the last K steps: with 128 hipcc spilled).  In the queue: ..., old 2,
+    // DMA x 8 (step nt-1), old 3 x 8 -> the first counted wait (old 0..2 landed) leaves 16 in flight; the second, in front
+    // of k-block 3, the 24 stores of k-blocks 0..2.  (The first wait statement names half of its destinations, the second
+    // -- which nothing can be moved across -- the other half.)
+    SMI_V2_OLD(3)
+#undef SMI_V2_OLD
+#define SMI_V2_OV(J) "+v"(oldv[J][0]), "+v"(oldv[J][1]), "+v"(oldv[J][2]), "+v"(oldv[J][3]), "+v"(oldv[J][4]), "+v"(oldv[J][5]), "+v"(oldv[J][6]), "+v"(oldv[J][7])
+    asm volatile("s_waitcnt vmcnt(16)" : SMI_V2_OV(0), SMI_V2_OV(1)::"memory");
+    asm volatile("" : SMI_V2_OV(2)::"memory");
+    asm volatile(V2_RDOUT_FIRST_STR);
+    float rs_sum[8], rs_sq[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) rs_sum[mi] = rs_sq[mi] = 0.f;
+    const unsigned ba = cbase + cidx * 32;  // the lane's 8 bias values of k-block j: columns j*32 + cidx*8 .. +7 of the wave's 128
+#define SMI_V2_RCHUNK(J, MI)                                                                                            \
+  {                                                                                                                     \
+    f32x4 va, vb;                                                                                                       \
+    SMI_V2_RDOUT_IDX(J, 0, MI, va);                                                                                     \
+    SMI_V2_RDOUT_IDX(J, 1, MI, vb);                                                                                     \
+    float c8[8];                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                     \
+      const auto sp = __builtin_amdgcn_permlane16_swap(__float_as_uint(va[i]), __float_as_uint(vb[i]), false, false);   \
+      c8[i] = __uint_as_float(sp[0]);                                                                                   \
+      c8[4 + i] = __uint_as_float(sp[1]);                                                                               \
+    }                                                                                                                   \
+    half8 o;                                                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                       \
+        o[i] = (f16)__builtin_fmaf(c8[i] + (i < 4 ? b0[i] : b1[i - 4]), RSTEP, (float)oldv[J][MI][i]);                  \
+    store_nt((half8*)(obase + (size_t)(J) * (TM_BLOCK * 2) + (MI) * 1024 + lane_part), o);                             \
+    if constexpr (EMIT) {                                                                                               \
+      const half2v ones = {(f16)1.f, (f16)1.f};                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
+        const half2v t2 = {o[2 * i], o[2 * i + 1]};                                                                     \
+        rs_sum[MI] = __builtin_amdgcn_fdot2(t2, ones, rs_sum[MI], false);                                               \
+        rs_sq[MI] = __builtin_amdgcn_fdot2(t2, t2, rs_sq[MI], false);                                                   \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  }
+#define SMI_V2_RKBLOCK(J)                                                                                               \
+  {                                                                                                                     \
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};                                                         \
+    if (has_bias)                                                                                                       \
+      asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"           \
+                   : "=&v"(b0), "=&v"(b1)                                                                               \
+                   : "v"(ba), "n"((J) * 128), "n"((J) * 128 + 16)                                                       \
+                   : "memory");                                                                                         \
+    SMI_V2_RCHUNK(J, 0) SMI_V2_RCHUNK(J, 1) SMI_V2_RCHUNK(J, 2) SMI_V2_RCHUNK(J, 3) SMI_V2_RCHUNK(J, 4)                 \
+    SMI_V2_RCHUNK(J, 5) SMI_V2_RCHUNK(J, 6) SMI_V2_RCHUNK(J, 7)                                                         \
+  }
+    SMI_V2_RKBLOCK(0) SMI_V2_RKBLOCK(1) SMI_V2_RKBLOCK(2)
+    asm volatile("s_waitcnt vmcnt(24)" : SMI_V2_OV(3)::"memory");
+#undef SMI_V2_OV
+    SMI_V2_RKBLOCK(3)
+#undef SMI_V2_RKBLOCK
+#undef SMI_V2_RCHUNK
+    if constexpr (EMIT) {
+      // join the 4 lane groups of a row (lanes 16 apart); lane group 0 leaves the wave's 128 row sums in LDS
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        float v0 = rs_sum[mi], v1 = rs_sq[mi];
+        auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+        v0 = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v0), false, false);
+        v0 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+        s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+        v1 = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+        s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v1), __float_as_uint(v1), false, false);
+        v1 = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
+        if (kg == 0) {
+          const float2 pv = {v0, v1};
+          asm volatile("ds_write_b64 %0, %1" ::"v"(cbase + 6144 + (mi * 16 + l15) * 8), "v"(pv) : "memory");
+        }
+      }
+      prev_m0 = tm_cur * 256;
+      prev_tn = tn_cur;
+    }
+  }
+  if constexpr (EMIT) {  // the last tile's row sums
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    emit_rowsums();
+  }
+}
+
 template <int EPI, bool FOLD>
 static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* out, int M, int N, int K, hipStream_t stream,
                             const GemmLnFold* fold) {
@@ -321,16 +577,47 @@ static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* ou
 
 bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnFold* fold) {
   if (tune(TUNE_G2V2, 1) == 0) return false;
+  if (M % 256 || N % 256 || K % 128 || K / 32 < V2_MIN_SLICES) return false;
+  // persistent rounds: the engine pays when a workgroup walks several tiles
+  if ((int64_t)(M / 256) * (N / 256) < tune(TUNE_G2V2_MIN, 2 * 256)) return false;
+  if (epi == EPI_RESID_F16 || epi == EPI_RESID_HALF_F16)  // tile-major residual stream; fold: producer side only
+    return !fold || !fold->part_in;
   if (epi != EPI_BIAS_F16 && epi != EPI_RELU_F16 && epi != EPI_SILU_F16) return false;
-  if (M % 256 || N % 256 || K % 128 || K / 32 < V2_MIN_SLICES || !bias) return false;
+  if (!bias) return false;
   if (fold && (!fold->part_in || !fold->c1 || fold->nparts < 1 || fold->nparts > 4)) return false;
   if (fold && epi == EPI_SILU_F16 && !fold->centered) return false;
-  // persistent rounds: the deferred stores pay when a workgroup walks several tiles
-  return (int64_t)(M / 256) * (N / 256) >= tune(TUNE_G2V2_MIN, 2 * 256);
+  return true;
+}
+
+template <int EPI, bool EMIT>
+static hipError_t launch_v2_resid(const f16* X, const f16* W, const float* bias, f16* out, int M, int N, int K,
+                                  hipStream_t stream, float2* part_out) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v2_resid_kernel<EPI, EMIT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done.set();
+  }
+  const int ntm = M / 256, ntn = N / 256;
+  const int grid = std::min(ntm * ntn, num_cus());
+  const int want_raster = tune(TUNE_G2_RASTER, 2);
+  const int raster = (want_raster && grid == 256 && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0) ? want_raster : 0;
+  hipLaunchKernelGGL((gemm_v2_resid_kernel<EPI, EMIT>), dim3(grid), dim3(V2_THREADS), V2_LDS_BYTES, stream, X, W, bias, out, M,
+                     N, K, raster, part_out);
+  return hipGetLastError();
 }
 
 hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias, f16* out, int M, int N, int K,
                           hipStream_t stream, const GemmLnFold* fold) {
+  if (epi == EPI_RESID_F16 || epi == EPI_RESID_HALF_F16) {
+    float2* po = fold ? fold->part_out : nullptr;
+    if (epi == EPI_RESID_F16)
+      return po ? launch_v2_resid<EPI_RESID_F16, true>(X, W, bias, out, M, N, K, stream, po)
+                : launch_v2_resid<EPI_RESID_F16, false>(X, W, bias, out, M, N, K, stream, nullptr);
+    return po ? launch_v2_resid<EPI_RESID_HALF_F16, true>(X, W, bias, out, M, N, K, stream, po)
+              : launch_v2_resid<EPI_RESID_HALF_F16, false>(X, W, bias, out, M, N, K, stream, nullptr);
+  }
 #define SMI_V2_CASE(E)                                                                           \
   case E:                                                                                        \
     return fold ? launch_v2<E, true>(X, W, bias, out, M, N, K, stream, fold)                     \

@@ -120,11 +120,12 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                                    (16384, 4096, 1280),    # 1024 tiles: XCD-owned raster, four tiles per workgroup, 40 slices
                                    (2560, 1024, 8192),     # 40 tiles, K = 8192: one tile per workgroup, long loop
                                    (512, 256, 1024)])      # two tiles: most of the chip idle
-@pytest.mark.parametrize("epi", [0, 1, 5])
+@pytest.mark.parametrize("epi", [0, 1, 5, 8, 9])
 def test_gemm_v2_engine(lib, m, n, k, epi):
-    """The 4-wave 256x256 engine (gemm_v2.hip: accumulators in AGPRs, the previous tile's stores under the next tile's K
-    loop) against the fp32 reference AND against the 8-wave engine on the same operands; three launches in a row must be
-    bit-identical (the deferred stores and the ring that streams across tiles are where a race would show)."""
+    """The 4-wave 256x256 engine (gemm_v2.hip: accumulators in AGPRs, inline-asm K steps, a ring that streams across tiles;
+    epi 8 / 9: the tile-major fp16 residual stream, read-modify-write, old tile requested by asm loads under the last K
+    steps) against the fp32 reference AND against the 8-wave engine on the same operands; three launches in a row must be
+    bit-identical (the counted waits and the cross-tile stream are where a race would show)."""
     from sonar_amd import _lib
 
     g = torch.Generator(device="cuda").manual_seed(m + 3 * n + k + epi)
@@ -133,14 +134,20 @@ def test_gemm_v2_engine(lib, m, n, k, epi):
     bias = torch.randn(n, device="cuda", generator=g)
     xt, wt = to_tile_major(x), to_tile_major(w)
     ref = x.float() @ w.float().T + bias
-    want = torch.relu(ref) if epi == 1 else (torch.nn.functional.silu(ref) if epi == 5 else ref)
+    resid = None
+    if epi in (8, 9):
+        resid = torch.randn(m, n, device="cuda", generator=g).half()
+        want = resid.float() + (ref if epi == 8 else 0.5 * ref)
+    else:
+        want = torch.relu(ref) if epi == 1 else (torch.nn.functional.silu(ref) if epi == 5 else ref)
     flags = _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM | (2 << 8)
     outs = {}
     for v2 in (0, 1):
         with _lib.tuning(G2V2=v2, G2V2_MIN=1):
             runs = []
             for rep in range(3 if v2 else 1):
-                out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
+                out = (to_tile_major(resid) if resid is not None
+                       else torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16))
                 _lib.check(lib.smi_gemm_tn(epi | flags, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                            m, n, k, n, _stream()))
                 torch.cuda.synchronize()
@@ -157,6 +164,13 @@ def test_gemm_v2_engine(lib, m, n, k, epi):
     d = (outs[0] - outs[1]).abs().max().item()
     assert d <= 2e-3 * scale, d
     assert (outs[0] != outs[1]).float().mean().item() <= 0.02
+    if epi == 8:   # without a bias: the residual kernel's two DMA instructions read a dummy address, the values are not used
+        with _lib.tuning(G2V2=1, G2V2_MIN=1):
+            out = to_tile_major(resid)
+            _lib.check(lib.smi_gemm_tn(epi | flags, xt.data_ptr(), wt.data_ptr(), None, out.data_ptr(), m, n, k, n, _stream()))
+            torch.cuda.synchronize()
+        got = from_tile_major(out, m, n).float()
+        assert (got - (want - bias)).abs().max().item() <= 2e-3 * scale
 
 
 @pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
