@@ -578,8 +578,9 @@ static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* ou
 bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnFold* fold) {
   if (tune(TUNE_G2V2, 1) == 0) return false;
   if (M % 256 || N % 256 || K % 128 || K / 32 < V2_MIN_SLICES) return false;
-  // persistent rounds: the engine pays when a workgroup walks several tiles
-  if ((int64_t)(M / 256) * (N / 256) < tune(TUNE_G2V2_MIN, 2 * 256)) return false;
+  // from half a chip of tiles up (the automatic 256x256 threshold): measured same box with the threshold at 128 instead of
+  // 512, decoder C5 3.62 -> 3.58 ms per step, C1 2.66 -> 2.63 ms (profiles/r06_experiments.txt, experiment 6)
+  if ((int64_t)(M / 256) * (N / 256) < tune(TUNE_G2V2_MIN, 128)) return false;
   if (epi == EPI_RESID_F16 || epi == EPI_RESID_HALF_F16)  // tile-major residual stream; fold: producer side only
     return !fold || !fold->part_in;
   if (epi != EPI_BIAS_F16 && epi != EPI_RELU_F16 && epi != EPI_SILU_F16) return false;

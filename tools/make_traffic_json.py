@@ -7,7 +7,8 @@ import sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pmc = json.load(open(os.path.join(root, "gpurun_out", "pmc_traffic.json")))
-key = next(k for k in pmc if "gemm_tn256_kernelILi1ELi2E" in k)      # EPI_RELU_F16, tile-major in/out = FFN inner
+# EPI_RELU_F16, tile-major in/out, LayerNorm-fold consumer = FFN inner: the 4-wave engine's kernel since round 6, else the 8-wave one
+key = next((k for k in pmc if "gemm_v2_kernelILi1ELb1E" in k), None) or next(k for k in pmc if "gemm_tn256_kernelILi1ELi2E" in k)
 e = pmc[key]
 out = {
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1 "
