@@ -23,6 +23,8 @@ import re
 import sys
 import types
 
+sys.dont_write_bytecode = True   # importing the reference by path must not leave __pycache__ in /root/reference (read-only by contract)
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

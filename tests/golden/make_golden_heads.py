@@ -12,6 +12,8 @@ import importlib.util
 import os
 import sys
 import types
+
+sys.dont_write_bytecode = True   # importing the reference by path must not leave __pycache__ in /root/reference (read-only by contract)
 from dataclasses import dataclass
 
 import torch
