@@ -139,3 +139,42 @@ def test_xsim_margin_matches_laser_formula_twin():
         err, pred = OX.laser_xsim(fx["x"], fx["y"], m, fx["k"])
         assert err == fx[m + "_err"] and torch.equal(pred, fx[m + "_pred"]), m
     assert fx["ratio_err"] != fx["cosine_err"]        # the fixture does separate the variants
+
+
+def _pooling_fixture():
+    import os
+
+    return torch.load(os.path.join(os.path.dirname(__file__), "golden", "pooling_reference.pt"), weights_only=False)
+
+
+def test_pooling_equals_the_reference_function_on_random_batches():
+    """oracle.static_pooling against outputs of the REFERENCE'S OWN `SonarTextTransformerEncoderModel.static_pooling`
+    (sonar/models/sonar_text/model.py:86-128, imported by path and executed in the build container by
+    tests/golden/make_golden_pooling.py): 25 cases -- last / max / mean, with and without a padding mask, fp32 and fp16, a
+    trailing extra dimension, an empty row under LAST -- bit for bit."""
+    fx = _pooling_fixture()
+    assert len(fx["static_pooling"]) == 25
+    for c in fx["static_pooling"]:
+        got = O.static_pooling(c["seqs"].clone(), c["seq_lens"], c["pooling"])
+        assert got.dtype == c["out"].dtype and got.shape == c["out"].shape
+        assert torch.equal(got, c["out"]), (c["pooling"], c["seqs"].dtype, c["seq_lens"])
+
+
+def test_model_level_layernorm_precedes_pooling_as_in_the_reference_forward():
+    """`SonarTextTransformerEncoderModel.forward` of the reference (model.py:130-143), executed with pass-through frontend / encoder
+    stand-ins: the model-level LayerNorm is applied to every position, THEN the pooling runs on its output (what
+    oracle.text_encoder_forward restates and the fused ln_pool kernel implements)."""
+    fx = _pooling_fixture()
+    for c in fx["forward"]:
+        y = torch.nn.functional.layer_norm(c["x"] * 1.5 + 0.25, (c["x"].shape[-1],), c["ln_weight"], c["ln_bias"], 1e-5)
+        assert torch.equal(y, c["encoded_seqs"])
+        assert torch.equal(O.static_pooling(y, c["seq_lens"], c["pooling"]), c["sentence_embeddings"])
+
+
+def test_translation_glue_hands_the_decoder_a_length_one_source_without_mask():
+    """`SonarEncoderDecoderModel.encode` + `DummyEncoderModel` of the reference (sonar_translation/model.py:48-53, 80-95),
+    executed by path: the decoder is conditioned on `embeddings.unsqueeze(1)` with NO padding mask -- the fact the folded
+    cross-attention of the engine rests on (one key: softmax weight 1)."""
+    g = _pooling_fixture()["translation_glue"]
+    assert g["encoder_padding_mask_is_none"]
+    assert torch.equal(g["encoder_output"], g["embeddings"].unsqueeze(1))
