@@ -176,3 +176,41 @@ def test_tokenizer_decode_renders_unk(tmp_path):
     assert text == tok.sp.decode([i - 1 for i in ids if 4 <= i < tok.lang_base or i == 1])
     assert "⁇" in text and "hello" in text                # rendered, not dropped
     assert tok.decode([tok.lang_idx("eng_Latn"), 3, 0, 2]) == ""  # control symbols never render
+
+
+def test_arch_configs_equal_the_reference_registrations():
+    """Every field of every architecture this package registers (`basic` / `small` text encoder; `basic` / `small` / `toy`
+    decoder; `english` / `non_english` speech encoder) against the values the REFERENCE'S OWN registration functions return
+    (sonar_text/config.py:87-127, 192-255; sonar_speech/config.py:54-100), executed by path in the build container
+    (tests/golden/make_golden_configs.py -> configs_reference.json).  The reference's field set is a subset of ours (we add
+    `input_dim` to the decoder, which its factory takes as an argument, and flatten the w2v-BERT encoder sub-config)."""
+    import dataclasses
+    import json
+    import os
+
+    from sonar_amd.speech_encoder import get_speech_encoder_config
+    from sonar_amd.text_decoder import get_text_decoder_config
+    from sonar_amd.text_encoder import get_text_encoder_config
+
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "configs_reference.json")))
+
+    def plain(v):
+        return {f.name: plain(getattr(v, f.name)) for f in dataclasses.fields(v)} if dataclasses.is_dataclass(v) else v
+
+    for kls, getter in (("SonarTextEncoderConfig", get_text_encoder_config), ("SonarTextDecoderConfig", get_text_decoder_config)):
+        assert sorted(ref[kls]) == sorted({"SonarTextEncoderConfig": ["basic", "small"],
+                                           "SonarTextDecoderConfig": ["basic", "small", "toy"]}[kls])
+        for arch, want in ref[kls].items():
+            got = plain(getter(arch))
+            for field, value in want.items():
+                assert got[field] == value, (kls, arch, field, got[field], value)
+    # speech: the SONAR-level fields (the nested w2v-BERT "600m" encoder config is fairseq2's, recorded as a sentinel)
+    names = {"model_dim": "model_dim", "max_seq_len": "max_seq_len", "pad_idx": "pad_idx", "bos_idx": "bos_idx",
+             "num_decoder_layers": "num_decoder_layers", "num_decoder_attn_heads": "num_decoder_attn_heads",
+             "ffn_inner_dim": "decoder_ffn_inner_dim"}
+    assert sorted(ref["SonarSpeechEncoderConfig"]) == ["english", "non_english"]
+    for arch, want in ref["SonarSpeechEncoderConfig"].items():
+        got = plain(get_speech_encoder_config(arch))
+        assert want["decoder_norm_order"] == "POST"          # the pooler's layers are POST-norm: what speech.hip implements
+        for rf, ours in names.items():
+            assert got[ours] == want[rf], (arch, rf, got[ours], want[rf])
