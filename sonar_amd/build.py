@@ -18,7 +18,7 @@ CSRC = ROOT / "csrc"
 OUT_DIR = ROOT / "lib"
 LIB_NAME = "libsonar_mi355.so"
 ARCH = "gfx950"
-SOURCES = ["api.hip", "gemm.hip", "gemm_v2.hip", "rowops.hip", "attention.hip", "xsim.hip", "decoder.hip", "decoder_api.hip", "speech.hip", "speech_api.hip", "host_input.cpp", "host_audio.cpp", "heads.hip", "sampling.hip", "flex.hip", "flex_encoder.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_v2.hip", "gemm_v2_lone.hip", "rowops.hip", "attention.hip", "xsim.hip", "decoder.hip", "decoder_api.hip", "speech.hip", "speech_api.hip", "host_input.cpp", "host_audio.cpp", "heads.hip", "sampling.hip", "flex.hip", "flex_encoder.hip"]
 
 
 def hipcc() -> str:

@@ -1357,6 +1357,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     return use256 ? launch_one256<E, L>(X, W, bias, out, M, N, K, ldo, stream) \
                   : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
   if (out_tm) {  // fp16 outputs that feed the next GEMM; EPI_RESID_F16: the tile-major residual stream
+    // a decode step's FFN-inner projection (M = 1280 rows): 256 lone units of 160 x 256 instead of 160 of 256 x 256
+    if (epi == EPI_RELU_F16 && sel != 1 && gemm_v2_lone_fits(M, N, K, 1))
+      return launch_gemm_v2_lone(1, X, W, bias, out, M, N, K, 1, stream);
     if (use256 && gemm_v2_fits(epi, M, N, K, bias, nullptr))
       return launch_gemm_v2(epi, X, W, bias, (f16*)out, M, N, K, stream, nullptr);
     switch (epi) {
@@ -1413,6 +1416,8 @@ hipError_t launch_gemm_tn_splitk(const f16* X, const f16* W, const float* bias, 
   const bool big = M % G2_BM == 0 && N % G2_BN == 0 && (K / G2_BK) / ksplit >= 16 && units256 >= min_units && units256 <= num_cus();
   if (!big && K % (GT_BK * ksplit)) return hipErrorInvalidValue;  // the 128x128 engine splits K evenly
   if (slab_f16) {
+    // ... and its FFN-output projection: 8 x 4 tiles x 8 K parts = 256 lone units (gemm_v2_lone.hip)
+    if (in_tm && gemm_v2_lone_fits(M, N, K, ksplit)) return launch_gemm_v2_lone(0, X, W, bias, parts, M, N, K, ksplit, stream);
     if (big)
       return in_tm ? launch_one256<EPI_BIAS_F16, 1>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps)
                    : launch_one256<EPI_BIAS_F16, 0>(X, W, bias, parts, M, N, K, N, stream, nullptr, ksplit, ps);

@@ -173,6 +173,50 @@ def test_gemm_v2_engine(lib, m, n, k, epi):
         assert (got - (want - bias)).abs().max().item() <= 2e-3 * scale
 
 
+@pytest.mark.parametrize("n,k,ks", [(8192, 1024, 1),     # the decode step's FFN-inner projection: 8 x 32 = 256 units, relu, tile-major out
+                                    (1024, 8192, 8),     # its FFN-output projection: 8 x 4 x 8 = 256 units, fp16 slabs
+                                    (512, 2048, 4),      # 64 units, 16 slices per unit
+                                    (256, 256, 1)])      # 8 units, the shortest K loop the unit takes (8 slices)
+def test_gemm_v2_lone_units(lib, n, k, ks):
+    """The 160 x 256 lone units (gemm_v2_lone.hip; M = 1280 = the C5 decode step's rows): X pieces that straddle the 256-row blocks
+    of the tile-major image, the half piece under an EXEC mask, the 6-slot ring with a run-time slot index -- against the fp32
+    reference and against the 256-row tiles (DEC_M160=0) on the same operands; three launches bit-identical."""
+    from sonar_amd import _lib
+
+    m = 1280
+    g = torch.Generator(device="cuda").manual_seed(n + 7 * k + ks)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    xt, wt = to_tile_major(x), to_tile_major(w)
+    ref = x.float() @ w.float().T + bias
+    outs = {}
+    for m160 in (0, 1):
+        with _lib.tuning(DEC_M160=m160):
+            runs = []
+            for rep in range(3 if m160 else 1):
+                if ks == 1:
+                    out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
+                    _lib.check(lib.smi_gemm_tn(1 | _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(),
+                                               bias.data_ptr(), out.data_ptr(), m, n, k, n, _stream()))
+                else:
+                    out = torch.full((ks, m, n), float("nan"), device="cuda", dtype=torch.float16)
+                    _lib.check(lib.smi_gemm_tn_splitk(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, ks, 1,
+                                                      _lib.SMI_F16, _stream()))
+                torch.cuda.synchronize()
+                runs.append(out)
+            for r in runs[1:]:
+                assert torch.equal(r, runs[0])
+            outs[m160] = from_tile_major(runs[0], m, n).float() if ks == 1 else runs[0].float().sum(0)
+    want = torch.relu(ref) if ks == 1 else ref
+    scale = max(want.abs().max().item(), 1.0)
+    for m160 in (0, 1):
+        assert torch.isfinite(outs[m160]).all()
+        err = (outs[m160] - want).abs().max().item()
+        assert err <= (2e-3 if ks == 1 else 4e-3) * scale, (m160, err, scale)
+    assert (outs[0] - outs[1]).abs().max().item() <= 4e-3 * scale
+
+
 @pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
                                           (1280, 1024, 1024, 2, 0),      # its attention output projection: lone-tile units
                                           (256, 1024, 8192, 8, 1),       # small-batch encoder: 64x64 lone units

@@ -118,8 +118,8 @@ struct V2Ring {
 };
 
 // block J of a step (engine_v2_asm.inc): 16 MFMAs of `cur`, 4 fragment reads of the next slice into `nxt`, 2 LDS-DMA
-#define V2_BLOCK(J, cur, nxt, XA, WA, GP, M0V)                                                                              \
-  asm volatile(V2_BLOCK##J##_STR                                                                                            \
+#define V2_BLOCK_N(NAME, J, cur, nxt, XA, WA, GP, M0V)                                                                      \
+  asm volatile(NAME##_STR                                                                                            \
                : [nw0] "=&v"(nxt.w[2 * J]), [nw1] "=&v"(nxt.w[2 * J + 1]), [nx0] "=&v"(nxt.x[2 * J]),                       \
                  [nx1] "=&v"(nxt.x[2 * J + 1])                                                                              \
                : [w0] "v"(cur.w[2 * J]), [w1] "v"(cur.w[2 * J + 1]), [x0] "v"(cur.x[0]), [x1] "v"(cur.x[1]),                \
@@ -152,16 +152,33 @@ __device__ __forceinline__ void v2_fill(V2Stream& st, unsigned m0x, unsigned m0w
 
 // one slice: consume `cur` (slice s, ring slot SLOT), read slice s + 1 (slot SLOT + 1) into `nxt`, issue slice s + 4 into
 // slot SLOT.  Entry: this wave's part of slice s + 1 may still be in flight.
-template <int SLOT>
+// VAR 0: the full step.  1: 10 of 16 MFMAs per block (the MFMA count of a 160-row workgroup tile).  2: that + 6 instead of 8
+// DMA instructions per wave and slice (24 KiB slices) -- lone-tile probes, wrong results on purpose.
+template <int SLOT, int VAR>
 __device__ __forceinline__ void v2_step(const V2Frag& cur, V2Frag& nxt, V2Stream& st, const V2Ring& rg) {
   // my pieces of slice s + 1 have landed (s + 2, s + 3 stay in flight); everybody's have, and everybody has finished reading
   // slice s (slot SLOT is free) once the barrier is passed
-  asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (VAR == 2)
+    asm volatile("s_waitcnt vmcnt(12)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   constexpr int NS = (SLOT + 1) & 3;
-  V2_BLOCK(0, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
-  V2_BLOCK(1, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
-  V2_BLOCK(2, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
-  V2_BLOCK(3, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+  if constexpr (VAR == 0) {
+    V2_BLOCK_N(V2_BLOCK0, 0, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK1, 1, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK2, 2, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+    V2_BLOCK_N(V2_BLOCK3, 3, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+  } else if constexpr (VAR == 1) {
+    V2_BLOCK_N(V2_BLOCK0R, 0, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK1R, 1, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK2R, 2, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+    V2_BLOCK_N(V2_BLOCK3R, 3, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+  } else {
+    V2_BLOCK_N(V2_BLOCK0RD, 0, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK1RD, 1, cur, nxt, rg.xa[NS], rg.wa[NS], st.xp, rg.m0x[SLOT]);
+    V2_BLOCK_N(V2_BLOCK2RD, 2, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+    V2_BLOCK_N(V2_BLOCK3RD, 3, cur, nxt, rg.xa[NS], rg.wa[NS], st.wp, rg.m0w[SLOT]);
+  }
   st.xp += st.inc;
   st.wp += st.inc;
 }
@@ -173,7 +190,7 @@ __device__ __forceinline__ void v2_init_acc(float v) {
   asm volatile(V2_INIT3_STR ::"v"(v) : V2_BLOCK3_CLOB);
 }
 
-template <bool CHECK>
+template <bool CHECK, int VAR = 0>
 __global__ __launch_bounds__(V2_THREADS) void k_v2(const f16* __restrict__ X, const f16* __restrict__ W,
                                                    float* __restrict__ out, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,10 +235,10 @@ __global__ __launch_bounds__(V2_THREADS) void k_v2(const f16* __restrict__ X, co
     const int m0 = tm * 256, n0 = tn * 256;
     v2_init_acc(0.f);
     for (int kb = 0; kb < nt - 4; kb += 4) {
-      v2_step<0>(fa, fb, st, rg);
-      v2_step<1>(fb, fa, st, rg);
-      v2_step<2>(fa, fb, st, rg);
-      v2_step<3>(fb, fa, st, rg);
+      v2_step<0, VAR>(fa, fb, st, rg);
+      v2_step<1, VAR>(fb, fa, st, rg);
+      v2_step<2, VAR>(fa, fb, st, rg);
+      v2_step<3, VAR>(fb, fa, st, rg);
     }
     // the last four slices of this tile: the cursor moves to the next tile's first block
     more = tile_of(i + 1, blockIdx.x, gridDim.x, ntm, ntn, tm, tn);
@@ -233,10 +250,10 @@ __global__ __launch_bounds__(V2_THREADS) void k_v2(const f16* __restrict__ X, co
       st.wp -= st.inc;
       st.inc = 0;
     }
-    v2_step<0>(fa, fb, st, rg);
-    v2_step<1>(fb, fa, st, rg);
-    v2_step<2>(fa, fb, st, rg);
-    v2_step<3>(fb, fa, st, rg);
+    v2_step<0, VAR>(fa, fb, st, rg);
+    v2_step<1, VAR>(fb, fa, st, rg);
+    v2_step<2, VAR>(fa, fb, st, rg);
+    v2_step<3, VAR>(fb, fa, st, rg);
     if constexpr (CHECK) {
       // acc[ni][mi][r] = a[(ni*8+mi)*4 + r] = C[m0 + wr*128 + mi*16 + l15][n0 + wc*128 + ni*16 + 4*kg + r]
       float* o = out + (size_t)(m0 + wr * 128 + l15) * N + n0 + wc * 128 + 4 * kg;
@@ -350,6 +367,49 @@ int main(int argc, char** argv) {
   if (bad) {
     printf("CHECK FAILED\n");
     return 1;
+  }
+  if (argc > 1 && !strcmp(argv[1], "lone")) {
+    // LONE TILES: M = 1280 rows (the decode step: 256 sentences x beam 5) x N 8192 x K 1024 = 160 tiles on 256 CUs, one per
+    // workgroup; the weights rotate over NW matrices (NW x 16.8 MB > the Infinity Cache) so that every launch streams them
+    // from HBM as a decode step does.  What bounds a lone tile: its MFMA count, its operand bytes, or the latency of a slice?
+    const int M = 1280, N = 8192, K = 1024, NW = 24;
+    std::vector<f16> hx((size_t)M * K), hw((size_t)N * K);
+    fill(hx, 21, false);
+    fill(hw, 22, false);
+    f16 *dx, *dw;
+    float* dout;
+    HIP_OK(hipMalloc(&dx, hx.size() * 2));
+    HIP_OK(hipMalloc(&dw, hw.size() * 2 * NW));
+    HIP_OK(hipMalloc(&dout, 256 * 512 * 4));
+    HIP_OK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    for (int i = 0; i < NW; ++i) HIP_OK(hipMemcpy(dw + (size_t)i * N * K, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    HIP_OK(hipFuncSetAttribute((const void*)k_v1<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_KERNEL_LDS_BYTES));
+    HIP_OK(hipFuncSetAttribute((const void*)k_v2<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * V2_SLOT));
+    HIP_OK(hipFuncSetAttribute((const void*)k_v2<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * V2_SLOT));
+    HIP_OK(hipFuncSetAttribute((const void*)k_v2<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * V2_SLOT));
+    for (int hot = 0; hot < 2; ++hot) {
+      int wi = 0;
+      auto wsel = [&] { f16* p = dw + (size_t)(hot ? 0 : (wi++ % NW)) * N * K; return p; };
+      auto l1 = [&] { hipLaunchKernelGGL((k_v1<false>), dim3(160), dim3(G2_THREADS), G2_KERNEL_LDS_BYTES, 0, dx, wsel(), dout, M, N, K); };
+      auto l20 = [&] { hipLaunchKernelGGL((k_v2<false, 0>), dim3(160), dim3(V2_THREADS), 4 * V2_SLOT, 0, dx, wsel(), dout, M, N, K); };
+      auto l21 = [&] { hipLaunchKernelGGL((k_v2<false, 1>), dim3(160), dim3(V2_THREADS), 4 * V2_SLOT, 0, dx, wsel(), dout, M, N, K); };
+      auto l22 = [&] { hipLaunchKernelGGL((k_v2<false, 2>), dim3(160), dim3(V2_THREADS), 4 * V2_SLOT, 0, dx, wsel(), dout, M, N, K); };
+      std::vector<float> t[4];
+      for (int r = 0; r < 6; ++r) {
+        t[0].push_back(time_ms(l1, 48));
+        t[1].push_back(time_ms(l20, 48));
+        t[2].push_back(time_ms(l21, 48));
+        t[3].push_back(time_ms(l22, 48));
+      }
+      const char* names[4] = {"8-wave ping-pong, 256x256 unit", "4-wave, 256x256 unit (64 MFMA / step)", "4-wave, 40 MFMA / step (160-row MFMA count)",
+                              "4-wave, 40 MFMA / step + 24 KiB slices"};
+      for (int v = 0; v < 4; ++v) {
+        std::sort(t[v].begin(), t[v].end());
+        printf("lone tiles, %s weights: %-46s %.2f us per launch (min %.2f), back-to-back launches incl. launch overhead\n",
+               hot ? "L2-hot " : "HBM-cold", names[v], t[v][t[v].size() / 2] * 1e3, t[v][0] * 1e3);
+      }
+    }
+    return 0;
   }
   const int M = argc > 1 ? atoi(argv[1]) : 131072, N = argc > 2 ? atoi(argv[2]) : 8192, K = argc > 3 ? atoi(argv[3]) : 1024;
   const int rounds = argc > 4 ? atoi(argv[4]) : 7;
