@@ -29,7 +29,7 @@ namespace smi {
   X(G2_RASTER)       /* 256x256 engine: [2] XCD-owned m-groups, 0 id-order raster */                                    \
   X(G2V2)            /* [1] 4-wave engine (gemm_v2.hpp) for the tile-major fp16 outputs it covers, 0 the 8-wave engine */ \
   X(G2V2_MIN)        /* 256x256 tiles from which a launch takes the 4-wave engine ([128]) */                            \
-  X(DEC_M160)        /* [1] 160x256 lone units for the FFN projections at M % 1280 == 0 rows (gemm_v2_lone.hip), 0 256-row tiles */ \
+  X(DEC_M160)        /* [1] 128 / 160 / 192-row lone units for FFN projections whose 256-row tiles leave CUs idle (gemm_v2_lone.hip), 0 off, 2 also short K loops */ \
   X(GT_RING)         /* stages of the lone-tile ring ([4]; anything else: never use it) */                              \
   X(LONE)            /* [1] 64x64 lone-tile units where they fit, 0 round 3's 128x128 ring */                           \
   X(LONE16)          /* [1] k-sliced 64x64 unit on tile-major operands, 0 the LDS-ring unit */                          \

@@ -173,25 +173,30 @@ def test_gemm_v2_engine(lib, m, n, k, epi):
         assert (got - (want - bias)).abs().max().item() <= 2e-3 * scale
 
 
-@pytest.mark.parametrize("n,k,ks", [(8192, 1024, 1),     # the decode step's FFN-inner projection: 8 x 32 = 256 units, relu, tile-major out
-                                    (1024, 8192, 8),     # its FFN-output projection: 8 x 4 x 8 = 256 units, fp16 slabs
-                                    (512, 2048, 4),      # 64 units, 16 slices per unit
-                                    (256, 256, 1)])      # 8 units, the shortest K loop the unit takes (8 slices)
-def test_gemm_v2_lone_units(lib, n, k, ks):
-    """The 160 x 256 lone units (gemm_v2_lone.hip; M = 1280 = the C5 decode step's rows): X pieces that straddle the 256-row blocks
-    of the tile-major image, the half piece under an EXEC mask, the 6-slot ring with a run-time slot index -- against the fp32
-    reference and against the 256-row tiles (DEC_M160=0) on the same operands; three launches bit-identical."""
+@pytest.mark.parametrize("m,n,k,ks", [(1280, 8192, 1024, 1),  # the decode step's FFN-inner projection: 8 x 32 = 256 units of 160 rows, relu, tile-major out
+                                      (1280, 1024, 8192, 8),  # its FFN-output projection: 8 x 4 x 8 = 256 units, fp16 slabs
+                                      (1280, 512, 2048, 4),   # 64 units, 16 slices per unit
+                                      (1280, 256, 256, 1),    # 8 units, the shortest K loop the unit takes (8 slices)
+                                      (1536, 8192, 1024, 1),  # BASELINE configs[0] (1312 tokens): 8 x 32 units of 192 rows (5-slot ring)
+                                      (1536, 1024, 8192, 8),  # ... and its split-K FFN output projection
+                                      (1024, 8192, 1024, 1),  # 8 x 32 units of 128 rows
+                                      (768, 1024, 4096, 8),   # 192-row units: 4 x 4 x 8 = 128 units
+                                      (512, 2048, 512, 2)])   # 128-row units, 8 slices per unit
+def test_gemm_v2_lone_units(lib, m, n, k, ks):
+    """The 128 / 160 / 192 x 256 lone units (gemm_v2_lone.hip; 1280 rows = the C5 decode step, 1536 = C1's tokens): X pieces that
+    straddle the 256-row blocks of the tile-major image, the half piece under an EXEC mask (160), three whole pieces and a
+    5-slot ring (192), the run-time slot index -- against the fp32 reference and against the 256-row tiles (DEC_M160=0) on the
+    same operands; three launches bit-identical."""
     from sonar_amd import _lib
 
-    m = 1280
-    g = torch.Generator(device="cuda").manual_seed(n + 7 * k + ks)
+    g = torch.Generator(device="cuda").manual_seed(m + n + 7 * k + ks)
     x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
     w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
     bias = torch.randn(n, device="cuda", generator=g)
     xt, wt = to_tile_major(x), to_tile_major(w)
     ref = x.float() @ w.float().T + bias
     outs = {}
-    for m160 in (0, 1):
+    for m160 in (0, 2):       # 2: the lone units for every K loop the ring can run (the default takes them from 32 slices up)
         with _lib.tuning(DEC_M160=m160):
             runs = []
             for rep in range(3 if m160 else 1):
@@ -210,11 +215,11 @@ def test_gemm_v2_lone_units(lib, n, k, ks):
             outs[m160] = from_tile_major(runs[0], m, n).float() if ks == 1 else runs[0].float().sum(0)
     want = torch.relu(ref) if ks == 1 else ref
     scale = max(want.abs().max().item(), 1.0)
-    for m160 in (0, 1):
+    for m160 in (0, 2):
         assert torch.isfinite(outs[m160]).all()
         err = (outs[m160] - want).abs().max().item()
         assert err <= (2e-3 if ks == 1 else 4e-3) * scale, (m160, err, scale)
-    assert (outs[0] - outs[1]).abs().max().item() <= 4e-3 * scale
+    assert (outs[0] - outs[2]).abs().max().item() <= 4e-3 * scale
 
 
 @pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
