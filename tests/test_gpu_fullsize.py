@@ -410,7 +410,8 @@ def test_basic_decoder_chains_bit_identical_full_size(basic_decoder):
     # summation orders.  Pin the family for both.
     # G2_AUTO_MIN: ... and the fused QKV projection: 2 816 rows x 3 072 columns are 132 tiles of the 256x256 engine (its automatic
     # choice from 128 tiles up), a chain's 1 024 rows are 48 (the 128x128 family)
-    with _lib.tuning(DEC_KS_OUT=2, DEC_FFN1_ENGINE=2, G2_SPLITK_MIN=1000000, G2_AUTO_MIN=1000000):
+    # DEC_M160: the lone 128 / 160 / 192-row units are chosen from the row count (round 6): off, like the other row-count choices
+    with _lib.tuning(DEC_KS_OUT=2, DEC_FFN1_ENGINE=2, G2_SPLITK_MIN=1000000, G2_AUTO_MIN=1000000, DEC_M160=0):
         try:
             eng.set_chains(1)
             one = [t.cpu() for t in eng.generate(emb, [3, 256047], **kw)]
