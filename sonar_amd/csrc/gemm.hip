@@ -1358,8 +1358,9 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
                   : launch_one<E, L>(X, W, bias, out, M, N, K, ldo, stream);
   if (out_tm) {  // fp16 outputs that feed the next GEMM; EPI_RESID_F16: the tile-major residual stream
     // a decode step's FFN-inner projection (M = 1280 rows): 256 lone units of 160 x 256 instead of 160 of 256 x 256
-    if (epi == EPI_RELU_F16 && sel != 1 && gemm_v2_lone_fits(M, N, K, 1))
-      return launch_gemm_v2_lone(1, X, W, bias, out, M, N, K, 1, stream);
+    // (and the small-batch encoder's fused QKV projection: bias, tile-major out)
+    if ((epi == EPI_RELU_F16 || epi == EPI_BIAS_F16) && sel != 1 && gemm_v2_lone_fits(M, N, K, 1))
+      return launch_gemm_v2_lone(epi == EPI_RELU_F16 ? 1 : 2, X, W, bias, out, M, N, K, 1, stream);
     if (use256 && gemm_v2_fits(epi, M, N, K, bias, nullptr))
       return launch_gemm_v2(epi, X, W, bias, (f16*)out, M, N, K, stream, nullptr);
     switch (epi) {

@@ -176,20 +176,22 @@ __device__ __forceinline__ void vm_fill(VmStream& st, const VmDst& d, unsigned l
 #define SMI_VM_RDOUT(MIV, J, NL, MI_, V) \
   asm volatile(V2M##MIV##_RD_##J##_##NL##_##MI_##_STR : "=v"(V[0]), "=v"(V[1]), "=v"(V[2]), "=v"(V[3]))
 
-// EPI_RELU_F16: out = tile-major fp16 [M][N].  EPI_BIAS_F16: out = row-major fp16 slabs, part kz at out + kz * part_stride bytes.
+// SLAB = false: out = act(X W^T + bias) as tile-major fp16 [M][N] (EPI_RELU_F16 / EPI_BIAS_F16).  SLAB = true: out = row-major fp16
+// split-K slabs, part kz at out + kz * part_stride bytes, the bias in part 0, saturating.
 // Unit id -> (row tile tm of 32 MI rows, column tile tn of 256, K part kz of nt slices each).
-template <int EPI, int MI>
+template <int EPI, int MI, bool SLAB>
 __global__ __launch_bounds__(V2_THREADS) void gemm_v2_lone_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
                                                                   const float* __restrict__ bias, void* __restrict__ out_, int M,
                                                                   int N, int K, int ksplit, size_t part_stride) {
-  static_assert(EPI == EPI_RELU_F16 || EPI == EPI_BIAS_F16, "tile-major relu hidden activation or fp16 split-K slabs");
+  static_assert(EPI == EPI_RELU_F16 || EPI == EPI_BIAS_F16, "bias / relu outputs");
+  static_assert(!SLAB || EPI == EPI_BIAS_F16, "slabs carry partial sums: no activation");
   using S = VmShape<MI>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int l15 = lane & 15, kg = lane >> 4;
-  if constexpr (EPI == EPI_BIAS_F16) fp16_saturate_on();  // fp16 partial sums saturate instead of overflowing to inf
+  if constexpr (SLAB) fp16_saturate_on();  // fp16 partial sums saturate instead of overflowing to inf
 
   // XCD x (blocks b = x mod 8) owns a contiguous range of the (tn, kz) panel space and all row tiles of each panel: a W panel
   // part is fetched from HBM once per XCD and hit by the other row tiles in that XCD's L2
@@ -287,14 +289,14 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_lone_kernel(const f16* __r
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = r0 + wr * 16 * MI + mi * 16 + l15;
-    if constexpr (EPI == EPI_RELU_F16)
+    if constexpr (!SLAB)
       // tile-major [M][N]: row m sits in block (m >> 8, k-block) at (m & 255) * 64 B
       rp[mi] = (char*)out_ + ((size_t)(m >> 8) * (N >> 5) + (size_t)tn * 8 + wc * 4) * (TM_BLOCK * 2) + (m & 255) * 64 +
                ((cidx ^ tm_swz(l15)) << 4);
     else
       rp[mi] = (char*)out_ + (size_t)kz * part_stride + ((size_t)m * N + tn * 256 + wc * 128 + cidx * 8) * 2;
   }
-  constexpr size_t JSTEP = EPI == EPI_RELU_F16 ? (size_t)TM_BLOCK * 2 : 64;  // next 32-column k-block
+  constexpr size_t JSTEP = !SLAB ? (size_t)TM_BLOCK * 2 : 64;  // next 32-column k-block
 #define SMI_VM_CHUNK(MIV, J, MI_)                                                                                    \
   if constexpr ((MI_) < MI) {                                                                                        \
     f32x4 va, vb;                                                                                                    \
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_lone_kernel(const f16* __r
     const auto s1 = __builtin_amdgcn_permlane16_swap(ha.y, hb.y, false, false);                                      \
     const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};                                                                \
     u32x4* dst = (u32x4*)(rp[MI_] + (J) * JSTEP);                                                                    \
-    if constexpr (EPI == EPI_RELU_F16)                                                                               \
+    if constexpr (!SLAB)                                                                                             \
       store_nt(dst, chunk);                                                                                          \
     else                                                                                                             \
       *dst = chunk;                                                                                                  \
@@ -357,31 +359,32 @@ static int lone_rows(int M, int N, int K, int ksplit) {
 
 bool gemm_v2_lone_fits(int M, int N, int K, int ksplit) { return lone_rows(M, N, K, ksplit) != 0; }
 
-template <int EPI, int MI>
+template <int EPI, int MI, bool SLAB>
 static hipError_t launch_lone_unit(const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ksplit,
                                    size_t part_stride, hipStream_t stream) {
   static DeviceOnce attr_done;
   if (!attr_done.done()) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_v2_lone_kernel<EPI, MI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v2_lone_kernel<EPI, MI, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        VmShape<MI>::LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done.set();
   }
   const int grid = (M / VmShape<MI>::ROWS) * (N / 256) * ksplit;
-  hipLaunchKernelGGL((gemm_v2_lone_kernel<EPI, MI>), dim3(grid), dim3(V2_THREADS), VmShape<MI>::LDS_BYTES, stream, X, W, bias, out,
+  hipLaunchKernelGGL((gemm_v2_lone_kernel<EPI, MI, SLAB>), dim3(grid), dim3(V2_THREADS), VmShape<MI>::LDS_BYTES, stream, X, W, bias, out,
                      M, N, K, ksplit, part_stride);
   return hipGetLastError();
 }
 
-// relu = 1: tile-major fp16 relu output [M][N] (ksplit must be 1); relu = 0: row-major fp16 slabs [ksplit][M][N]
-hipError_t launch_gemm_v2_lone(int relu, const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ksplit,
+// mode 0: row-major fp16 slabs [ksplit][M][N]; 1: tile-major fp16 relu output [M][N]; 2: tile-major fp16 bias output (ksplit 1)
+hipError_t launch_gemm_v2_lone(int mode, const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ksplit,
                                hipStream_t stream) {
   const int rows = lone_rows(M, N, K, ksplit);
-  if (!rows || (relu && ksplit != 1)) return hipErrorInvalidValue;
+  if (!rows || (mode && ksplit != 1)) return hipErrorInvalidValue;
   const size_t ps = (size_t)M * N * 2;
-#define SMI_VM_LAUNCH(MIV)                                                                                     \
-  return relu ? launch_lone_unit<EPI_RELU_F16, MIV>(X, W, bias, out, M, N, K, 1, 0, stream)                    \
-              : launch_lone_unit<EPI_BIAS_F16, MIV>(X, W, bias, out, M, N, K, ksplit, ps, stream)
+#define SMI_VM_LAUNCH(MIV)                                                                                                \
+  return mode == 1   ? launch_lone_unit<EPI_RELU_F16, MIV, false>(X, W, bias, out, M, N, K, 1, 0, stream)                 \
+         : mode == 2 ? launch_lone_unit<EPI_BIAS_F16, MIV, false>(X, W, bias, out, M, N, K, 1, 0, stream)                 \
+                     : launch_lone_unit<EPI_BIAS_F16, MIV, true>(X, W, bias, out, M, N, K, ksplit, ps, stream)
   if (rows == 128) SMI_VM_LAUNCH(4);
   if (rows == 160) SMI_VM_LAUNCH(5);
   SMI_VM_LAUNCH(6);

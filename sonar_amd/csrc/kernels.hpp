@@ -109,9 +109,10 @@ hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias
                           hipStream_t stream, const GemmLnFold* fold);
 
 // 160x256 lone units of the 4-wave engine (gemm_v2_lone.hip): M % 1280 == 0 rows, tile-major operands, every unit on its own CU.
-// relu = 1: out = tile-major fp16 relu(X W^T + bias) (ksplit 1); relu = 0: out = row-major fp16 split-K slabs [ksplit][M][N].
+// mode 1 / 2: out = tile-major fp16 relu(X W^T + bias) / X W^T + bias (ksplit 1); mode 0: out = row-major fp16 split-K slabs
+// [ksplit][M][N].  (The 160x256 name is historic: units are 128 / 160 / 192 rows.)
 bool gemm_v2_lone_fits(int M, int N, int K, int ksplit);
-hipError_t launch_gemm_v2_lone(int relu, const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ksplit,
+hipError_t launch_gemm_v2_lone(int mode, const f16* X, const f16* W, const float* bias, void* out, int M, int N, int K, int ksplit,
                                hipStream_t stream);
 
 // in_tm: X and W tile-major (common.hpp; M, N % 256 == 0)

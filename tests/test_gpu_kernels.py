@@ -195,31 +195,32 @@ def test_gemm_v2_lone_units(lib, m, n, k, ks):
     bias = torch.randn(n, device="cuda", generator=g)
     xt, wt = to_tile_major(x), to_tile_major(w)
     ref = x.float() @ w.float().T + bias
-    outs = {}
-    for m160 in (0, 2):       # 2: the lone units for every K loop the ring can run (the default takes them from 32 slices up)
-        with _lib.tuning(DEC_M160=m160):
-            runs = []
-            for rep in range(3 if m160 else 1):
-                if ks == 1:
-                    out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
-                    _lib.check(lib.smi_gemm_tn(1 | _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(),
-                                               bias.data_ptr(), out.data_ptr(), m, n, k, n, _stream()))
-                else:
-                    out = torch.full((ks, m, n), float("nan"), device="cuda", dtype=torch.float16)
-                    _lib.check(lib.smi_gemm_tn_splitk(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, ks, 1,
-                                                      _lib.SMI_F16, _stream()))
-                torch.cuda.synchronize()
-                runs.append(out)
-            for r in runs[1:]:
-                assert torch.equal(r, runs[0])
-            outs[m160] = from_tile_major(runs[0], m, n).float() if ks == 1 else runs[0].float().sum(0)
-    want = torch.relu(ref) if ks == 1 else ref
-    scale = max(want.abs().max().item(), 1.0)
-    for m160 in (0, 2):
-        assert torch.isfinite(outs[m160]).all()
-        err = (outs[m160] - want).abs().max().item()
-        assert err <= (2e-3 if ks == 1 else 4e-3) * scale, (m160, err, scale)
-    assert (outs[0] - outs[2]).abs().max().item() <= 4e-3 * scale
+    for epi in ((1, 0) if ks == 1 else (None,)):      # tile-major relu / bias outputs, or fp16 split-K slabs
+        outs = {}
+        for m160 in (0, 2):       # 2: the lone units for every K loop the ring can run (the default takes them from 32 slices up)
+            with _lib.tuning(DEC_M160=m160):
+                runs = []
+                for rep in range(3 if m160 else 1):
+                    if ks == 1:
+                        out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
+                        _lib.check(lib.smi_gemm_tn(epi | _lib.SMI_GEMM_IN_TM | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(),
+                                                   bias.data_ptr(), out.data_ptr(), m, n, k, n, _stream()))
+                    else:
+                        out = torch.full((ks, m, n), float("nan"), device="cuda", dtype=torch.float16)
+                        _lib.check(lib.smi_gemm_tn_splitk(xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, ks, 1,
+                                                          _lib.SMI_F16, _stream()))
+                    torch.cuda.synchronize()
+                    runs.append(out)
+                for r in runs[1:]:
+                    assert torch.equal(r, runs[0])
+                outs[m160] = from_tile_major(runs[0], m, n).float() if ks == 1 else runs[0].float().sum(0)
+        want = torch.relu(ref) if epi == 1 else ref
+        scale = max(want.abs().max().item(), 1.0)
+        for m160 in (0, 2):
+            assert torch.isfinite(outs[m160]).all()
+            err = (outs[m160] - want).abs().max().item()
+            assert err <= (2e-3 if ks == 1 else 4e-3) * scale, (epi, m160, err, scale)
+        assert (outs[0] - outs[2]).abs().max().item() <= 4e-3 * scale
 
 
 @pytest.mark.parametrize("m,n,k,ks,tm", [(1280, 1024, 8192, 8, 1),      # the decode step's FFN output projection: 160 units, 256x256 engine
