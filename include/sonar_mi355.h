@@ -142,7 +142,7 @@ const char* smi_version(void);
 /* ABI revision of this header: bumped whenever a struct grows, an argument list changes or a workspace formula
  * changes (round 2 = 2, round 3 = 3, ...).  A binding compares it with SMI_ABI_VERSION at load time and refuses a
  * library built from another revision (the structs carry no size field). */
-#define SMI_ABI_VERSION 5
+#define SMI_ABI_VERSION 6
 int smi_abi_version(void);
 const char* smi_last_error(void);
 /* Tuning registry (round 5).  Every A/B switch of the library -- engine-family thresholds, split-K part counts, storage
@@ -567,6 +567,12 @@ int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* 
  * projections).  fp16 slabs saturate at +-65504.  in_tm: x and w tile-major. */
 int smi_gemm_tn_splitk(const void* x_f16, const void* w_f16, const float* bias, void* parts, int32_t m, int32_t n, int32_t k,
                        int32_t ksplit, int32_t in_tm, int32_t slab_dtype, void* stream);
+/* The decoder's logits projection with its fused softmax statistics (exported for tests; TiedProjection + the beam search's
+ * log_softmax, sonar/models/sonar_text/factory.py:300-315, sonar/inference_pipelines/text.py:305-346): x, w and the f16 output
+ * tile-major, no bias (m, n % 256 == 0, k % 64 == 0), scale > 0; per (256-column tile t, row r), over the columns c < valid_n of
+ * the tile: tile_max[t*m + r] = max_c scale*v, tile_sum[t*m + r] = sum_c exp(scale*v - tile_max), v = the ROUNDED f16 logit. */
+int smi_gemm_tn_tile_stats(const void* x_f16_tm, const void* w_f16_tm, void* out_f16_tm, int32_t m, int32_t n, int32_t k,
+                           float scale, int32_t valid_n, float* tile_max, float* tile_sum, void* stream);
 /* dst[i] = (dst_dtype) src[i] for n elements of DEVICE memory (dtypes: smi_dtype incl. SMI_BF16; fp32 -> bf16 rounds to
  * nearest even).  The bf16 side of the pipelines' `dtype=` argument: `model.to(device, dtype)` / the embeddings returned by
  * TextToEmbeddingModelPipeline.predict (sonar/inference_pipelines/text.py:161-162, 262-268). */

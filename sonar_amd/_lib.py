@@ -235,7 +235,7 @@ class smi_mlp_head_layer(C.Structure):
     _fields_ = [("w", smi_tensor), ("b", smi_tensor), ("out_dim", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 5  # SMI_ABI_VERSION of include/sonar_mi355.h
+ABI_VERSION = 6  # SMI_ABI_VERSION of include/sonar_mi355.h
 
 # every symbol include/sonar_mi355.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -286,6 +286,7 @@ SYMBOLS = {
     "smi_xsim_merge_topk": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "smi_xsim_margin_select": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "smi_gemm_tn": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "smi_gemm_tn_tile_stats": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp, _vp]),
     "smi_gemm_tn_splitk": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "smi_mlp_head_create": (C.c_int, [C.POINTER(smi_mlp_head_config), C.POINTER(smi_mlp_head_layer), C.POINTER(_vp)]),
     "smi_mlp_head_destroy": (None, [_vp]),

@@ -717,6 +717,18 @@ int smi_gemm_tn_splitk(const void* x, const void* w, const float* bias, void* pa
   return SMI_OK;
 }
 
+int smi_gemm_tn_tile_stats(const void* x, const void* w, void* out, int32_t m, int32_t n, int32_t k, float scale, int32_t valid_n,
+                           float* tile_max, float* tile_sum, void* stream) {
+  if (!x || !w || !out || !tile_max || !tile_sum) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (m <= 0 || m % 256 || n <= 0 || n % 256 || k <= 0 || k % 64 || !(scale > 0.f) || valid_n <= 0 || valid_n > n)
+    return fail(SMI_ERR_UNSUPPORTED, "tile-statistics gemm m=%d n=%d k=%d scale=%g valid_n=%d", m, n, k, (double)scale, valid_n);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  const GemmTileStats st{tile_max, tile_sum, scale, valid_n};
+  HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | GEMM_IN_TM | GEMM_OUT_TM, (const f16*)x, (const f16*)w, nullptr, out, m, n, k, n,
+                         (hipStream_t)stream, &st));
+  return SMI_OK;
+}
+
 int smi_cast(const void* src, int32_t src_dtype, void* dst, int32_t dst_dtype, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!src || !dst))) return fail(SMI_ERR_INVALID_ARG, "bad argument");
   if (src_dtype < SMI_F32 || src_dtype > SMI_BF16 || dst_dtype < SMI_F32 || dst_dtype > SMI_BF16)

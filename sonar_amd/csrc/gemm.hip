@@ -1346,8 +1346,10 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
     return hipErrorInvalidValue;
   }
   if (stats) {  // tile statistics: the 256x256 engine's fp32-store epilogue or its tile-major fp16 store, without a bias
-    if (epi == EPI_BIAS_F16 && out_tm && in_tm && can256 && sel != 1 && !bias)
+    if (epi == EPI_BIAS_F16 && out_tm && in_tm && can256 && sel != 1 && !bias) {
+      if (gemm_v2_stats_fits(M, N, K, stats)) return launch_gemm_v2_stats(X, W, (f16*)out, M, N, K, stream, stats, g2_grid_cap);
       return launch_one256<EPI_BIAS_F16, 2>(X, W, bias, out, M, N, K, ldo, stream, stats);
+    }
     if (epi != EPI_STORE_F32 || out_tm || !can256 || sel == 1 || bias) return hipErrorInvalidValue;
     return in_tm ? launch_one256<EPI_STORE_F32, 1>(X, W, bias, out, M, N, K, ldo, stream, stats)
                  : launch_one256<EPI_STORE_F32, 0>(X, W, bias, out, M, N, K, ldo, stream, stats);

@@ -556,6 +556,202 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_resid_kernel(const f16* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The decoder's tied logits projection on the same engine (beam search of an fp16 model: fp16 tile-major logits, no bias;
+// reference: TiedProjection at sonar/models/sonar_text/factory.py:300-315, consumed by the beam search of
+// sonar/inference_pipelines/text.py:305-346): out = f16(X W^T), and per (row, 256-column tile) the softmax statistics of the
+// ROUNDED values -- tile_max = max_n v * scale, tile_sum = sum_n exp(v * scale - tile_max) over the columns n < valid_n -- so that
+// the candidate selection never re-reads the 1 MB logits rows (GemmTileStats, kernels.hpp).  The read-out runs row block by row
+// block (all 8 column blocks of a 16-row block: the lane's 32 values of a row), as the 8-wave engine's fused pass does; the two
+// column waves of a row half leave (max, sum) of their 128 columns in LDS and wave u combines and stores rows 64u .. 64u+63
+// behind the barrier of the next K step (two 4-B stores per lane).
+__global__ __launch_bounds__(V2_THREADS) void gemm_v2_stats_kernel(const f16* __restrict__ X, const f16* __restrict__ W,
+                                                                   f16* __restrict__ out, int M, int N, int K, GemmTileStats stats) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const V2Ring rg = v2_make_ring(smem, wave, lane);
+  const unsigned voff = wave * 4096 + lane * 16;
+
+  // id-order raster (grouped 8(m) x ntn super-tiles): M = beam x batch rows are a handful of row tiles
+  const int ntm = M / 256, ntn = N / 256, nt = K / 32, nout = ntm * ntn;
+  int tile_m = 0, tile_n = 0;
+  auto coords = [&](int t) {
+    constexpr int GM = 8;
+    const int per_group = GM * ntn, group = t / per_group, first_m = group * GM;
+    const int gsz = min(GM, ntm - first_m), in_group = t - group * per_group;
+    tile_m = first_m + in_group % gsz;
+    tile_n = in_group / gsz;
+  };
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  if (tile >= nout) return;
+  coords(tile);
+
+  const size_t panel = (size_t)nt * (TM_BLOCK * 2);
+  V2Stream st;
+  st.xp = (const char*)X + (size_t)tile_m * panel + voff;
+  st.wp = (const char*)W + (size_t)tile_n * panel + voff;
+  st.inc = TM_BLOCK * 2;
+  V2Frag f;
+  v2_start(f, st, rg);
+
+  const unsigned cbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)smem + V2_RING_BYTES + wave * V2_CONST_BYTES);
+  const unsigned lds_const0 = (unsigned)(size_t)smem + V2_RING_BYTES;
+  const float sc2 = stats.scale * 1.4426950408889634f;  // > 0 (the launcher checks): max and scaling commute
+  constexpr int NST = 32, NEMIT = 2;
+  const int cidx = (kg & 1) * 2 + (kg >> 1);
+  const unsigned lane_part = (unsigned)(((wr * 128 + l15) * 32 + ((cidx ^ tm_swz(l15)) << 3)) * 2);
+
+  // the previous tile's statistics: wave u combines the two column waves' halves of rows 64u .. 64u+63
+  int prev_m0 = 0, prev_tn = 0;
+  auto emit_stats = [&]() {
+    const int r = wave * 64 + lane;
+    const unsigned src = lds_const0 + ((r >> 7) * 2) * V2_CONST_BYTES + (r & 127) * 8;
+    float2 a, b;
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(src), "n"(V2_CONST_BYTES)
+                 : "memory");
+    const float m = fmaxf(a.x, b.x);
+    const float ms = m == -INFINITY ? 0.f : m;
+    const float sum = a.y * __builtin_amdgcn_exp2f(a.x - ms) + b.y * __builtin_amdgcn_exp2f(b.x - ms);
+    const size_t o = (size_t)prev_tn * M + prev_m0 + r;
+    stats.tile_max[o] = m * 0.6931471805599453f;
+    stats.tile_sum[o] = sum;
+  };
+
+  bool more = true, first_tile = true;
+  while (more) {
+    if (first_tile) {
+      v2_step_top<8>();
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8>();
+    } else {
+      v2_step_top<8 + NST>();
+      emit_stats();
+      v2_step_body<0, true>(f, st, rg);
+      v2_step_top<8 + NEMIT + NST>();
+    }
+    first_tile = false;
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<3, false>(f, st, rg);
+    for (int kb = 4; kb < nt - 4; kb += 4) {
+      v2_step_top<8>();
+      v2_step_body<0, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<1, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<2, false>(f, st, rg);
+      v2_step_top<8>();
+      v2_step_body<3, false>(f, st, rg);
+    }
+    v2_step_top<8>();
+    v2_step_body<0, false>(f, st, rg);
+    const int tm_cur = tile_m, tn_cur = tile_n;
+    tile += (int)gridDim.x;
+    more = tile < nout;
+    if (more) {
+      coords(tile);
+      unsigned vo = voff;
+      asm volatile("" : "+v"(vo));
+      st.xp = (const char*)X + (size_t)tile_m * panel + vo;
+      st.wp = (const char*)W + (size_t)tile_n * panel + vo;
+    } else {
+      st.xp -= st.inc;
+      st.wp -= st.inc;
+      st.inc = 0;
+    }
+    v2_step_top<8>();
+    v2_step_body<1, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<2, false>(f, st, rg);
+    v2_step_top<8>();
+    v2_step_body<3, false>(f, st, rg);
+
+    // ---- read-out, one 16-row block at a time: 4 stores + the row's statistics ----
+    char* const obase = (char*)out + ((size_t)tm_cur * (N >> 5) + (size_t)tn_cur * 8 + wc * 4) * (TM_BLOCK * 2) + lane_part;
+    const int n0 = tn_cur * 256;
+    asm volatile(V2_RDOUT_FIRST_STR);
+#define SMI_V2_SROW(MI, FULL)                                                                                            \
+  {                                                                                                                      \
+    uint32_t h[8][2];                                                                                                    \
+    SMI_V2_SBLK(0, 0, MI) SMI_V2_SBLK(0, 1, MI) SMI_V2_SBLK(1, 0, MI) SMI_V2_SBLK(1, 1, MI)                              \
+    SMI_V2_SBLK(2, 0, MI) SMI_V2_SBLK(2, 1, MI) SMI_V2_SBLK(3, 0, MI) SMI_V2_SBLK(3, 1, MI)                              \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+      const auto s0 = __builtin_amdgcn_permlane16_swap(h[2 * j][0], h[2 * j + 1][0], false, false);                      \
+      const auto s1 = __builtin_amdgcn_permlane16_swap(h[2 * j][1], h[2 * j + 1][1], false, false);                      \
+      const u32x4 chunk = {s0[0], s1[0], s0[1], s1[1]};                                                                  \
+      store_nt((u32x4*)(obase + (size_t)j * (TM_BLOCK * 2) + (MI) * 1024), chunk);                                       \
+    }                                                                                                                    \
+    f32x2 t[16]; /* the lane's 32 ROUNDED values of the row (FULL: raw; else scaled to the log2 domain and masked) */     \
+    float mx = -INFINITY;                                                                                                \
+    _Pragma("unroll") for (int ni = 0; ni < 8; ++ni) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                     \
+      const half2v hv = __builtin_bit_cast(half2v, h[ni][q]);                                                            \
+      f32x2 v = {(float)hv[0], (float)hv[1]};                                                                            \
+      if constexpr (!(FULL)) {                                                                                           \
+        const int col = n0 + wc * 128 + ni * 16 + 4 * kg + 2 * q;                                                        \
+        v[0] = col < stats.valid_n ? v[0] * sc2 : -INFINITY;                                                             \
+        v[1] = col + 1 < stats.valid_n ? v[1] * sc2 : -INFINITY;                                                         \
+      }                                                                                                                  \
+      t[ni * 2 + q] = v;                                                                                                 \
+      mx = fmaxf(mx, fmaxf(v[0], v[1]));                                                                                 \
+    }                                                                                                                    \
+    {                                                                                                                    \
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);           \
+      mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));                                                          \
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);           \
+      mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));                                                          \
+    }                                                                                                                    \
+    /* the row maximum in the log2 domain (scale > 0: max and scaling commute, bit for bit) */                           \
+    const float mxs = (FULL) ? mx * sc2 : mx;                                                                            \
+    const float nb = mxs == -INFINITY ? 0.f : -mxs;                                                                      \
+    const f32x2 mul2 = {(FULL) ? sc2 : 1.f, (FULL) ? sc2 : 1.f}, nb2 = {nb, nb};                                         \
+    f32x2 se2 = {0.f, 0.f};                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                     \
+      const f32x2 a = (FULL) ? __builtin_elementwise_fma(t[e], mul2, nb2) : t[e] + nb2;                                  \
+      se2 += f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};                                          \
+    }                                                                                                                    \
+    float se = se2[0] + se2[1];                                                                                          \
+    {                                                                                                                    \
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(se), __float_as_uint(se), false, false);           \
+      se = __uint_as_float(a[0]) + __uint_as_float(a[1]);                                                                \
+      const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(se), __float_as_uint(se), false, false);           \
+      se = __uint_as_float(b[0]) + __uint_as_float(b[1]);                                                                \
+    }                                                                                                                    \
+    if (kg == 0) {                                                                                                       \
+      const float2 pv = {mxs, se};                                                                                       \
+      asm volatile("ds_write_b64 %0, %1" ::"v"(cbase + ((MI) * 16 + l15) * 8), "v"(pv) : "memory");                      \
+    }                                                                                                                    \
+  }
+#define SMI_V2_SBLK(J, NL, MI)                                                          \
+  {                                                                                     \
+    f32x4 v;                                                                            \
+    SMI_V2_RDOUT_IDX(J, NL, MI, v);                                                     \
+    const uint2 hp = __builtin_bit_cast(uint2, epi_act_pack<EPI_BIAS_F16>(v));          \
+    h[2 * (J) + (NL)][0] = hp.x;                                                        \
+    h[2 * (J) + (NL)][1] = hp.y;                                                        \
+  }
+    if (n0 + 256 <= stats.valid_n) {  // every tile but the last column tile
+      SMI_V2_SROW(0, true) SMI_V2_SROW(1, true) SMI_V2_SROW(2, true) SMI_V2_SROW(3, true)
+      SMI_V2_SROW(4, true) SMI_V2_SROW(5, true) SMI_V2_SROW(6, true) SMI_V2_SROW(7, true)
+    } else {
+      SMI_V2_SROW(0, false) SMI_V2_SROW(1, false) SMI_V2_SROW(2, false) SMI_V2_SROW(3, false)
+      SMI_V2_SROW(4, false) SMI_V2_SROW(5, false) SMI_V2_SROW(6, false) SMI_V2_SROW(7, false)
+    }
+#undef SMI_V2_SBLK
+#undef SMI_V2_SROW
+    prev_m0 = tm_cur * 256;
+    prev_tn = tn_cur;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  emit_stats();
+}
+
 template <int EPI, bool FOLD>
 static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* out, int M, int N, int K, hipStream_t stream,
                             const GemmLnFold* fold) {
@@ -572,6 +768,26 @@ static hipError_t launch_v2(const f16* X, const f16* W, const float* c2, f16* ou
   const int raster = (want_raster && grid == 256 && ntn % 4 == 0 && ntn >= 16 && ((ntm + 7) / 8) % 8 == 0) ? want_raster : 0;
   hipLaunchKernelGGL((gemm_v2_kernel<EPI, FOLD>), dim3(grid), dim3(V2_THREADS), V2_LDS_BYTES, stream, X, W, c2, out, M, N, K,
                      raster, fold ? *fold : GemmLnFold{nullptr, nullptr, nullptr, 0, 0.f, 0.f, 0});
+  return hipGetLastError();
+}
+
+bool gemm_v2_stats_fits(int M, int N, int K, const GemmTileStats* stats) {
+  if (tune(TUNE_G2V2, 1) != 1 || !stats || !stats->tile_max || !stats->tile_sum || !(stats->scale > 0.f)) return false;
+  if (M % 256 || N % 256 || K % 128 || K / 32 < V2_MIN_SLICES) return false;
+  return (int64_t)(M / 256) * (N / 256) >= tune(TUNE_G2V2_MIN, 128);
+}
+
+hipError_t launch_gemm_v2_stats(const f16* X, const f16* W, f16* out, int M, int N, int K, hipStream_t stream,
+                                const GemmTileStats* stats, int grid_cap) {
+  static DeviceOnce attr_done;
+  if (!attr_done.done()) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_v2_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done.set();
+  }
+  int grid = std::min((M / 256) * (N / 256), num_cus());
+  if (grid_cap > 0) grid = std::min(grid, grid_cap);
+  hipLaunchKernelGGL(gemm_v2_stats_kernel, dim3(grid), dim3(V2_THREADS), V2_LDS_BYTES, stream, X, W, out, M, N, K, *stats);
   return hipGetLastError();
 }
 

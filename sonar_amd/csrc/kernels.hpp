@@ -108,6 +108,11 @@ bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnF
 hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias, f16* out, int M, int N, int K,
                           hipStream_t stream, const GemmLnFold* fold);
 
+// ... and the decoder's logits projection with the fused softmax statistics (fp16 tile-major logits, no bias, stats->scale > 0)
+bool gemm_v2_stats_fits(int M, int N, int K, const GemmTileStats* stats);
+hipError_t launch_gemm_v2_stats(const f16* X, const f16* W, f16* out, int M, int N, int K, hipStream_t stream,
+                                const GemmTileStats* stats, int grid_cap);
+
 // 160x256 lone units of the 4-wave engine (gemm_v2_lone.hip): M % 1280 == 0 rows, tile-major operands, every unit on its own CU.
 // mode 1 / 2: out = tile-major fp16 relu(X W^T + bias) / X W^T + bias (ksplit 1); mode 0: out = row-major fp16 split-K slabs
 // [ksplit][M][N].  (The 160x256 name is historic: units are 128 / 160 / 192 rows.)

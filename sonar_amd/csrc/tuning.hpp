@@ -27,7 +27,7 @@ namespace smi {
   X(DEC_LOGITS_F16)  /* beam-search logits storage: [-1] the engine setting, 0 fp32, 1 fp16 */                          \
   X(DEC_CHAINS)      /* independent decode chains ([0] the engine's policy) */                                          \
   X(G2_RASTER)       /* 256x256 engine: [2] XCD-owned m-groups, 0 id-order raster */                                    \
-  X(G2V2)            /* [1] 4-wave engine (gemm_v2.hpp) for the tile-major fp16 outputs it covers, 0 the 8-wave engine */ \
+  X(G2V2)            /* [1] 4-wave engine (gemm_v2.hpp) for the tile-major fp16 outputs it covers, 2 but for the logits, 0 off */ \
   X(G2V2_MIN)        /* 256x256 tiles from which a launch takes the 4-wave engine ([128]) */                            \
   X(DEC_M160)        /* [1] 128 / 160 / 192-row lone units for FFN projections whose 256-row tiles leave CUs idle (gemm_v2_lone.hip), 0 off, 2 also short K loops */ \
   X(GT_RING)         /* stages of the lone-tile ring ([4]; anything else: never use it) */                              \

@@ -115,6 +115,57 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
+@pytest.mark.parametrize("m,n,k,valid_n", [(1280, 32768, 1024, 32768 - 50),   # 640 tiles: 2-3 per workgroup, masked last column tile
+                                           (256, 65536, 1024, 65536),          # one row tile, every tile full
+                                           (512, 16384, 256, 16384 - 255),     # shortest K loop (8 slices); one valid column in the last tile
+                                           (1280, 256256, 1024, 256206)])      # the decoder's projection (beam 5 x batch 256)
+def test_gemm_v2_tile_stats(lib, m, n, k, valid_n):
+    """The logits projection with fused softmax statistics on the 4-wave engine (gemm_v2_stats_kernel) against an fp32
+    restatement computed from the kernel's OWN rounded logits (so the check isolates the statistics), the logits against the
+    fp32 product, and both against the 8-wave engine's fused pass (bit-equal logits; statistics equal to fp32 rounding)."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.1).half()
+    xt, wt = to_tile_major(x), to_tile_major(w)
+    scale = 0.7
+    res = {}
+    for v2 in (0, 1):
+        with _lib.tuning(G2V2=v2, G2V2_MIN=1):
+            runs = []
+            for rep in range(2 if v2 else 1):
+                out = torch.full((m * n,), float("nan"), device="cuda", dtype=torch.float16)
+                tmax = torch.full((n // 256, m), float("nan"), device="cuda")
+                tsum = torch.full((n // 256, m), float("nan"), device="cuda")
+                _lib.check(lib.smi_gemm_tn_tile_stats(xt.data_ptr(), wt.data_ptr(), out.data_ptr(), m, n, k, scale, valid_n,
+                                                      tmax.data_ptr(), tsum.data_ptr(), _stream()))
+                torch.cuda.synchronize()
+                runs.append((out, tmax, tsum))
+            for r in runs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+            res[v2] = runs[0]
+    assert torch.equal(res[0][0], res[1][0])          # no bias: the same K sum in both engines
+    logits = from_tile_major(res[1][0], m, n).float()
+    for c0 in range(0, m, 256):                       # fp32 product, a row tile at a time (the full matrix is 1.3 GB)
+        want = x[c0:c0 + 256].float() @ w.float().T
+        assert (logits[c0:c0 + 256] - want).abs().max().item() <= 2e-3 * max(want.abs().max().item(), 1.0)
+    del want
+    v = (logits * scale)
+    v[:, valid_n:] = float("-inf")
+    v = v.view(m, n // 256, 256)
+    wmax = v.max(dim=2).values                        # [m, tiles]
+    wsum = torch.exp(v - wmax.unsqueeze(2)).sum(dim=2)
+    for v2 in (0, 1):
+        tmax, tsum = res[v2][1].T, res[v2][2].T
+        assert torch.isfinite(tmax).all() and torch.isfinite(tsum).all()
+        assert (tmax - wmax).abs().max().item() <= 1e-5 * max(wmax.abs().max().item(), 1.0), v2
+        assert ((tsum - wsum).abs() / wsum).max().item() <= 2e-5, v2
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-5 * max(wmax.abs().max().item(), 1.0)
+    assert lib.smi_gemm_tn_tile_stats(xt.data_ptr(), wt.data_ptr(), out.data_ptr(), m, n, k, -1.0, valid_n, tmax.data_ptr(),
+                                      tsum.data_ptr(), _stream()) != 0
+
+
 @pytest.mark.parametrize("m,n,k", [(6144, 4096, 768),      # 384 tiles on 256 workgroups, the shortest K loop the engine takes (24 slices)
                                    (6144, 4096, 1024),     # the encoder's K; some workgroups walk two tiles, some one
                                    (16384, 4096, 1280),    # 1024 tiles: XCD-owned raster, four tiles per workgroup, 40 slices
