@@ -178,3 +178,51 @@ def test_translation_glue_hands_the_decoder_a_length_one_source_without_mask():
     g = _pooling_fixture()["translation_glue"]
     assert g["encoder_padding_mask_is_none"]
     assert torch.equal(g["encoder_output"], g["embeddings"].unsqueeze(1))
+
+
+def _wiring_fixture():
+    import os
+
+    return torch.load(os.path.join(os.path.dirname(__file__), "golden", "wiring_reference.pt"), weights_only=False)
+
+
+def test_speech_wiring_matches_reference_classes():
+    """oracle.speech_encoder_forward against outputs of the REFERENCE'S OWN `SonarSpeechEncoderModel.forward`
+    (sonar/models/sonar_speech/model.py:59-77) and `AttentionEncoderOutputPooler.__call__` (sonar/nn/encoder_pooler.py:70-89),
+    imported by path and executed by tests/golden/make_golden_wiring.py around layer stacks assembled from the oracle's block
+    functions: the moved LayerNorm sits between the encoder and the pooler and `encoded_seqs` is ITS output, the pooler sends
+    one BOS token per clip through the decoder frontend without a mask and attends over the encoder output with the encoder's
+    mask, `projection_out(...).squeeze(1)`; the returned padding mask is the frontend's (lengths // 2)."""
+    from oracle import speech_encoder as S
+
+    fx = _wiring_fixture()["speech"]
+    cfg = S.OracleSpeechEncoderConfig(**fx["config"])
+    p = S.make_synthetic_params(cfg, seed=fx["seed"])
+    assert len(fx["cases"]) == 2
+    for c in fx["cases"]:
+        enc, emb = S.speech_encoder_forward(p, cfg, c["fbank"], c["fbank_lens"])
+        assert torch.allclose(enc, c["encoded_seqs"], rtol=0, atol=1e-6)
+        assert torch.allclose(emb, c["sentence_embeddings"], rtol=0, atol=1e-6)
+        if c["fbank_lens"] is None:
+            assert c["padding_mask_seq_lens"] is None
+        else:
+            assert torch.equal(c["padding_mask_seq_lens"], c["fbank_lens"] // 2)
+    assert fx["cases"][1]["fbank_lens"] is not None   # the masked path is exercised
+
+
+def test_decoder_wiring_matches_reference_classes():
+    """oracle.decoder_logits against logits produced by the REFERENCE'S OWN `SonarEncoderDecoderModel.encode / decode / project`
+    with `DummyEncoderModel` in front and `ConditionalTransformerDecoderModel` behind (sonar/models/sonar_translation/model.py:48-95,
+    sonar/nn/conditional_decoder_model.py:66-94), executed by path around the oracle's decoder blocks: the sentence vector is a
+    length-1 source without a mask, the frontend sees the previous tokens, the final LayerNorm precedes the tied projection, and
+    the bare decoder model's own encode / decode / project give the same logits (asserted in the generator)."""
+    from oracle import text_decoder as D
+
+    fx = _wiring_fixture()["decoder"]
+    cfg = D.OracleTextDecoderConfig(**fx["config"])
+    p = D.make_synthetic_params(cfg, seed=fx["seed"])
+    logits = D.decoder_logits(p, cfg, fx["embeddings"], fx["prev_tokens"])
+    assert logits.shape == fx["logits"].shape
+    assert torch.allclose(logits, fx["logits"], rtol=0, atol=1e-6)
+    assert fx["encoder_output_shape"] == [3, 1, cfg.cond_dim] and fx["encoder_padding_mask_is_none"]
+    assert fx["pad_idx"] == 0   # SequenceModelOutput carries the vocabulary's pad index (conditional_decoder_model.py:94)
