@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void fbank_kernel(const float* __restrict__ wa
 // per-utterance standardisation over time (two-pass mean / unbiased std, as the reference's
 // converter does).  Three short launches over `nblk` workgroups of 12 x 80 threads (thread (g, b)
 // owns frames g, g+12, ... of its workgroup's frame range for mel bin b, loads independent so they
-// overlap); column partials go through a stream-ordered scratch [2][nblk][80] and every workgroup
+// overlap); column partials go through a stream-ordered scratch [2][nblk][80] (+ [80]: frame 0) and every workgroup
 // folds the partials it needs itself (nblk <= 256).
-//   pass 0: part0[blk][b] = sum_f x            pass 1: part1[blk][b] = sum_f (x - mean)^2
+//   pass 0: part0[blk][b] = sum_f (x - x[0])   pass 1: part1[blk][b] = sum_f (x - mean)^2
 //   pass 2: x = (x - mean) / std
 __global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restrict__ fb, int frames, int per_blk,
                                                                 float* __restrict__ part, int nblk, int pass) {
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restric
   const int b = threadIdx.x % FB_BINS, g = threadIdx.x / FB_BINS;
   float* part0 = part;
   float* part1 = part + (size_t)nblk * FB_BINS;
+  float* x0_saved = part + (size_t)2 * nblk * FB_BINS;  // frame 0 as pass 0 saw it (pass 2 rewrites the frames in place)
   // fold the partials of the earlier passes
   for (int q = 0; q < pass; ++q) {
     const float* src = q == 0 ? part0 : part1;
@@ -103,12 +104,14 @@ __global__ __launch_bounds__(960) void fbank_standardize_kernel(float* __restric
     if (g == 0) {
       float v = 0.f;
       for (int i = 0; i < 12; ++i) v += red[i][b];
-      stat[q][b] = q == 0 ? v / frames : 1.0f / sqrtf(v / (frames - 1));
+      stat[q][b] = q == 0 ? x0_saved[b] + v / frames : 1.0f / sqrtf(v / (frames - 1));
     }
     __syncthreads();
   }
   const int f0 = blockIdx.x * per_blk, f1 = min(frames, f0 + per_blk);
-  const float mean = pass > 0 ? stat[0][b] : 0.f;
+  // pass 0 sums around the column's first value (frame 0): exact mean for a constant column (see the batch kernel)
+  const float mean = pass > 0 ? stat[0][b] : fb[b];
+  if (pass == 0 && blockIdx.x == 0 && g == 0) x0_saved[b] = fb[b];
   if (pass == 2) {
     const float inv = stat[1][b];
     for (int f = f0 + g; f < f1; f += 12) {
@@ -212,8 +215,13 @@ __global__ __launch_bounds__(960) void fbank_batch_standardize_kernel(float* __r
   const int frames = ns < FB_WIN ? 0 : (int)(1 + (ns - FB_WIN) / FB_SHIFT);
   if (frames < 2) return;
   float* x = fb + (size_t)c * tpad * FB_BINS + b;
+  // The mean is accumulated around the column's first value: a CONSTANT column (digital silence: every frame is log(eps)) then
+  // has mean == that value exactly, deviations 0, variance 0 and 0 * inf = NaN features -- what at::std_mean gives the
+  // reference's converter and torch.std_mean the oracle (tests/unit_tests/test_sonar_speech.py:29-32 feeds zeros).  A plain
+  // sum of 1 098 equal values is off by a few ulp, and the clip came out as finite noise of unit variance instead.
+  const float x0 = x[0];
   for (int pass = 0; pass < 2; ++pass) {
-    const float mean = pass ? stat[0][b] : 0.f;
+    const float mean = pass ? stat[0][b] : x0;
     float acc = 0.f;
     for (int f = g; f < frames; f += 12) {
       const float d = x[(size_t)f * FB_BINS] - mean;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(960) void fbank_batch_standardize_kernel(float* __r
     if (g == 0) {
       float v = 0.f;
       for (int i = 0; i < 12; ++i) v += red[i][b];
-      stat[pass][b] = pass ? 1.0f / sqrtf(v / (frames - 1)) : v / frames;
+      stat[pass][b] = pass ? 1.0f / sqrtf(v / (frames - 1)) : x0 + v / frames;
     }
     __syncthreads();
   }
@@ -253,7 +261,7 @@ hipError_t launch_fbank(const float* wave, int64_t nsamples, float scale, int st
     if ((frames + per_blk - 1) / per_blk > 256) per_blk = ((frames + 255) / 256 + 11) / 12 * 12;
     const int nblk = (frames + per_blk - 1) / per_blk;
     float* part = nullptr;
-    hipError_t e = hipMallocAsync((void**)&part, (size_t)2 * nblk * FB_BINS * sizeof(float), stream);
+    hipError_t e = hipMallocAsync((void**)&part, (size_t)(2 * nblk + 1) * FB_BINS * sizeof(float), stream);
     if (e != hipSuccess) return e;
     for (int pass = 0; pass < 3; ++pass)
       hipLaunchKernelGGL(fbank_standardize_kernel, dim3(nblk), dim3(960), 0, stream, out, frames, per_blk, part, nblk,

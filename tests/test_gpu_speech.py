@@ -165,6 +165,77 @@ def test_speech_pipeline_end_to_end(tmp_path):
         assert _cos_err(out[i:i + 1], ref) <= 1e-3
 
 
+def test_reference_unit_tests_zeros_waveform_and_file(tmp_path):
+    """The reference's own pipeline unit tests (tests/unit_tests/test_sonar_speech.py:29-47) on a small model: an all-zero clip,
+    a random clip and a WAV file of 175 920 samples each give one embedding row.  The reference asserts the shape only; here the
+    random clip and the file are also compared with the oracle, and the all-zero clip -- whose standardised filterbank is 0 / 0
+    (std_mean over constant frames, no epsilon: fairseq2's converter and the oracle alike) -- must come out non-finite from the
+    engine exactly as it does from the oracle, not as a plausible-looking vector."""
+    from oracle import speech_encoder as OS
+    from sonar_amd.inference_pipelines import SpeechToEmbeddingModelPipeline
+    from sonar_amd.speech_encoder import SonarSpeechEncoderModel
+
+    import dataclasses
+
+    ocfg, cfg = _cfgs(layers=1, pool=1)
+    cfg = dataclasses.replace(cfg, max_frames=1024)   # 175 920 samples = 1 098 frames = 549 stacked frames
+    params = OS.make_synthetic_params(ocfg, seed=8, std=0.06)
+    model = SonarSpeechEncoderModel(cfg, params, device="cuda:0", dtype=torch.float32)
+    pipe = SpeechToEmbeddingModelPipeline(model, device=torch.device("cuda:0"))
+    n = 175920
+
+    def oracle(w):
+        f = OS.kaldi_fbank(w)
+        t = f.shape[0] + f.shape[0] % 2
+        fb = torch.zeros(1, t, 80)
+        fb[0, : f.shape[0]] = f
+        return OS.speech_encoder_forward(params, ocfg, fb, torch.tensor([f.shape[0]]))[1]
+
+    zeros = pipe.predict([torch.zeros(1, n)])
+    assert zeros.shape == (1, 256)
+    assert not torch.isfinite(oracle(torch.zeros(n))).any()
+    assert not torch.isfinite(zeros).any()
+    g = torch.Generator().manual_seed(11)
+    fake = torch.rand(1, n, generator=g)
+    emb = pipe.predict([fake])
+    assert emb.shape == (1, 256) and torch.isfinite(emb).all()
+    assert _cos_err(emb, oracle(fake[0])) <= 1e-3
+    pcm = (fake[0] * 32767).round().clamp(-32768, 32767).to(torch.int16)
+    path = tmp_path / "audio.wav"
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.numpy().tobytes())
+    emb_f = pipe.predict([str(path.resolve())])
+    assert emb_f.shape == (1, 256)
+    assert _cos_err(emb_f, oracle(pcm.float() / 32768.0)) <= 1e-3
+
+
+def test_fbank_of_digital_silence_is_not_a_number_as_in_the_oracle():
+    """A constant clip has constant log-mel columns: mean == the value, deviations 0, unbiased std 0, 0 / 0.  torch.std_mean (the
+    oracle; at::std_mean in the reference's converter [fs2-recall]) returns NaN features; the kernels sum around the column's
+    first value so that they do too, on the single-clip path (one and several workgroups per pass) and inside a batch, where the
+    neighbouring clip must stay untouched."""
+    from oracle import speech_encoder as OS
+    from sonar_amd.speech_encoder import waveform_to_fbank, waveforms_to_fbank_batch
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    noise = (torch.rand(40000, generator=g) * 2 - 1)
+    for n in (4000, 33333, 175920):
+        want = OS.kaldi_fbank(torch.zeros(n))
+        got = waveform_to_fbank(torch.zeros(n, device=dev))
+        assert got.shape == want.shape and torch.isnan(want).all() and torch.isnan(got).all(), n
+        assert torch.isnan(waveform_to_fbank(torch.full((n,), 0.25, device=dev))).all()   # any constant: DC is removed per frame
+    fb, lens = waveforms_to_fbank_batch([torch.zeros(33333, device=dev), noise.to(dev)])
+    assert torch.isnan(fb[0, : lens[0]]).all() and (fb[0, lens[0]:] == 0).all()
+    single = waveform_to_fbank(noise.to(dev))
+    assert torch.isfinite(fb[1, : lens[1]]).all()
+    assert (fb[1, : lens[1]] - single).abs().max().item() <= 1e-4
+    assert (single.cpu() - OS.kaldi_fbank(noise)).abs().max().item() <= 2e-3
+
+
 def test_batched_fbank_equals_per_clip_and_pads_with_zeros():
     from sonar_amd.speech_encoder import waveform_to_fbank, waveforms_to_fbank_batch
 
