@@ -303,6 +303,7 @@ SYMBOLS = {
     "smi_cast": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _vp]),
     "smi_layernorm": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i32, _i32, _vp]),
     "smi_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "smi_relpos_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -758,4 +758,18 @@ int smi_attention(const void* qkv, const int32_t* cu, void* ctx, int32_t n, int3
   return SMI_OK;
 }
 
+int smi_relpos_attention(const void* qkv, const int32_t* cu, const void* rp, int32_t rp_zero, int32_t rp_rows, const float* u_bias,
+                         const float* v_bias, void* ctx, int32_t n, int32_t max_len, int32_t d, int32_t heads, int32_t tile_major,
+                         void* stream) {
+  if (!qkv || !cu || !rp || !u_bias || !v_bias || !ctx) return fail(SMI_ERR_INVALID_ARG, "null argument");
+  if (heads <= 0 || d != heads * 64) return fail(SMI_ERR_UNSUPPORTED, "head_dim must be 64");
+  if (n <= 0 || max_len <= 0 || rp_rows <= 0 || rp_zero < 0 || rp_zero >= rp_rows)
+    return fail(SMI_ERR_INVALID_ARG, "n=%d max_len=%d rp_zero=%d rp_rows=%d", n, max_len, rp_zero, rp_rows);
+  if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(launch_relpos_attention((const f16*)qkv, cu, (const f16*)rp, rp_zero, rp_rows, u_bias, v_bias, (f16*)ctx, n, max_len, d,
+                                  heads, (hipStream_t)stream, tile_major ? 1 : 0));
+  return SMI_OK;
+}
+
+
 }  // extern "C"

@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   float* Gs = (float*)(lds + 4 * BLK) + wave * 64 * 32;  // [64 rho][32 queries]
+  char* const kvb = lds;
   const size_t ld = (size_t)3 * d;
   const f16* qbase = qkv + (size_t)start * ld + h * 64;
   const f16* kbase = qbase + d;
@@ -598,8 +599,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   const int kchunk = sslot ^ ((skey >> 1) & 7), vchunk = sslot ^ (((skey >> 1) & 1) << 2);
   auto stage = [&](int j0, int buf) {
     const int row = min(j0 + skey, len - 1);
-    glds16(kbase + (size_t)row * ld + kchunk * 8, lds + buf * 2 * BLK + wave * 1024);
-    glds16(vbase + (size_t)row * ld + vchunk * 8, lds + buf * 2 * BLK + BLK + wave * 1024);
+    glds16(kbase + (size_t)row * ld + kchunk * 8, kvb + buf * 2 * BLK + wave * 1024);
+    glds16(vbase + (size_t)row * ld + vchunk * 8, kvb + buf * 2 * BLK + BLK + wave * 1024);
   };
   // position rows of a key block: rp[rel_lo + 32 gb + l31], rel_lo = i0 - j0 - 31
   auto rp_row = [&](int j0, int gb) {
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int chunk = db * 4 + g16 * 2 + ((p16 & 3) >> 1);
-      vaddr[db] = (unsigned)(size_t)(lds + BLK + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
+      vaddr[db] = (unsigned)(size_t)(kvb + BLK + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
     }
   }
   // pad read addresses: query l31 needs G[rho][l31] for rho = l31 - jj + 31, jj = the key of accumulator register r.  Row rho
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   for (int j0 = 0, kb = 0; j0 < len; j0 += RA_KB, ++kb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // block kb has landed for everyone; everyone is done with the other buffer
-    const char* Ks = lds + (kb & 1) * 2 * BLK;
+    const char* Ks = kvb + (kb & 1) * 2 * BLK;
 
     // ---- content term: S^T = K . (Q+u)^T ----
     f32x16 s;
@@ -789,14 +790,317 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   }
 }
 
+// -DSMI_RPL_PAD32 (variant builds): fp32 score pad, 68 KiB of LDS = two workgroups per CU
+#ifdef SMI_RPL_PAD32
+typedef float RplPad;
+#else
+typedef f16 RplPad;
+#endif
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the same kernel with the position rows staged ONCE per workgroup through LDS and the score pad in fp16.
+// What bounded the kernel above (profiles/r06_experiments.txt, experiment 14): not its ~250 VALU instructions per key block and
+// not exposed latency, but the throughput of its global loads -- every wave fetched its own 32 position rows per block as four
+// global_load_dwordx4 that each touch 32 different 128-B lines (the MFMA A-operand layout wants lane = row): 128 line requests
+// for 4 KiB, and every row is fetched by all four waves of the workgroup one block apart (a quarter of the kernel's time).
+//  * The rows a workgroup needs at key block kb are the aligned 32-row blocks b = w - kb of rp[A + 32 b + (0..31)], A = q0 - 31 +
+//    rp_zero, for its waves w = 0..3 (plus b = w + 1 for the first block's second pad half): from one key block to the next ONE
+//    new block enters.  A ring of five 4 KiB slots (slot = b mod 5) holds them; the new block arrives by one coalesced LDS-DMA
+//    instruction per thread (rows clamped to the table as before), in the K layout (row-major, 16-B chunk c of row r at c ^
+//    ((r >> 1) & 7)), and every wave reads its A fragments with four conflict-free ds_read_b128: a quarter of the L2 -> CU bytes,
+//    a sixteenth of the line requests.
+//  * LDS: 16 KiB K / V + 20 KiB ring leave 16 KiB of the 52 KiB that let three workgroups share a CU, so the pad holds the
+//    position scores in fp16 ([64 rho][32 queries] x 2 B per wave).  The reference's fp16 model rounds the position scores (and
+//    the content scores) to fp16 before adding them (fairseq2 RelativePositionSDPA: two fp16 matmuls); here only the position
+//    term takes that rounding, the sum and the softmax stay fp32.
+// SMI_SPEECH_RP_LDS=0: the kernel above (A/B runs).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_WAVES, SMI_RELPOS_WAVES))) void relpos_attention_lds_kernel(
+    const f16* __restrict__ qkv, const int32_t* __restrict__ cu, const f16* __restrict__ rp, int rp_zero, int rp_rows,
+    const float* __restrict__ u_bias, const float* __restrict__ v_bias, f16* __restrict__ ctx, int d, float sl2e, int ctx_tm) {
+  constexpr int BLK = RA_KB * 128;  // 4 KiB
+  __shared__ __attribute__((aligned(16))) char lds[4 * BLK + 4 * BLK * (int)sizeof(RplPad) / 2 + 5 * BLK];  // K / V x 2 | fp16 pads | position-row ring
+  const int n = blockIdx.x, h = blockIdx.y;
+  const int start = cu[n], len = cu[n + 1] - start;
+  const int q0 = blockIdx.z * RA_QB;
+  if (q0 >= len) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  char* const kvb = lds;
+  RplPad* Gs = (RplPad*)(lds + 4 * BLK) + wave * 64 * 32;  // [64 rho][32 queries]
+  char* ring = lds + 4 * BLK + 4 * BLK * (int)sizeof(RplPad) / 2;
+  const size_t ld = (size_t)3 * d;
+  const f16* qbase = qkv + (size_t)start * ld + h * 64;
+  const f16* kbase = qbase + d;
+  const f16* vbase = qbase + 2 * d;
+  const f16* rph = rp + h * 64;
+
+  const int i0 = q0 + wave * 32;
+  const int qi = i0 + l31;
+  const f16* qptr = qbase + (size_t)min(qi, len - 1) * ld;
+  half8 qu[4], qv[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int c0 = (ks * 2 + hi) * 8;
+    const half8 q = *(const half8*)(qptr + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      qu[ks][e] = (f16)((float)q[e] + u_bias[h * 64 + c0 + e]);
+      qv[ks][e] = (f16)((float)q[e] + v_bias[h * 64 + c0 + e]);
+    }
+  }
+
+  // DMA sources of this thread: row tid>>3 of a 32-row block, the chunk that lands in slot tid&7
+  const int skey = tid >> 3, sslot = tid & 7;
+  const int kchunk = sslot ^ ((skey >> 1) & 7), vchunk = sslot ^ (((skey >> 1) & 1) << 2);
+  auto stage = [&](int j0, int buf) {
+    const int row = min(j0 + skey, len - 1);
+    glds16(kbase + (size_t)row * ld + kchunk * 8, kvb + buf * 2 * BLK + wave * 1024);
+    glds16(vbase + (size_t)row * ld + vchunk * 8, kvb + buf * 2 * BLK + BLK + wave * 1024);
+  };
+  // position rows: aligned block b = rows A + 32 b + (0..31), clamped to the table, into ring slot `slot` (K layout)
+  const int rowA = q0 - 31 + rp_zero + skey;
+  auto stage_rp = [&](int b, int slot) {
+    const int row = min(max(rowA + 32 * b, 0), rp_rows - 1);
+    glds16(rph + (size_t)row * d + kchunk * 8, ring + slot * BLK + wave * 1024);
+  };
+  // A fragments of the block in ring slot `slot`: row l31, chunks (2 ks + hi).  asm: a C++ LDS load behind an LDS-DMA issue
+  // gets `s_waitcnt vmcnt(0)` from hipcc while the next block's transfers are in flight
+  const unsigned frag_off = (unsigned)(size_t)ring + l31 * 128;
+  auto rp_frags = [&](int slot, half8 (&rf)[4]) {
+    const unsigned a = frag_off + slot * BLK;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(rf[ks]) : "v"(a + (((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4)) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]), "+v"(rf[2]), "+v"(rf[3]) : : "memory");
+  };
+
+  float m = -1e30f, lsum = 0.f;
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+
+  unsigned vaddr[2];
+  {
+    const int p16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int key = 4 * hi + (p16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int chunk = db * 4 + g16 * 2 + ((p16 & 3) >> 1);
+      vaddr[db] = (unsigned)(size_t)(kvb + BLK + key * 128 + ((chunk ^ (((key >> 1) & 1) << 2)) << 4) + (p16 & 1) * 8);
+    }
+  }
+  // pad reads: byte (gbase + parity * 2048 - c_r * 64) mod 4096 of the wave's pad (rows of 32 fp16), c_r = (r & 3) + 8 (r >> 2)
+  [[maybe_unused]] const int gbase = (l31 + 31 - 4 * hi) * 64 + l31 * 2;
+  // ... of an even block: rd_base + (27 - c_r) * 64, no wrap; of an odd block: the same xor 2048
+  [[maybe_unused]] const unsigned rd_base = (unsigned)(size_t)Gs + (l31 + 31 - 4 * hi - 27) * 64 + l31 * 2;
+  stage(0, 0);
+#pragma unroll
+  for (int b = 0; b < 5; ++b) stage_rp(b, b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    // the first key block needs BOTH pad halves: rho 32..63 = block wave + 1
+    half8 rf_hi[4];
+    rp_frags(wave + 1, rf_hi);
+    f32x16 g;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf_hi[ks], qv[ks], g, 0, 0, 0);
+    RplPad* Gold0 = Gs + 32 * 32;  // block 0 reads rho 32..63 from half 1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Gold0[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = (RplPad)g[r];
+  }
+
+  int rslot = wave;  // ring slot of block (wave - kb)
+  int dslot = 4;     // ring slot of block -(kb + 1), the one that arrives during key block kb
+  // one 32-key block; P = parity of the block index (which K / V buffer, which pad half is the new one): the loop is unrolled by
+  // two so that the pad addresses of an even block are one base + compile-time offsets and those of an odd block one xor away
+  // (+2 KiB modulo the 4 KiB pad), the exponent arguments come from v_pk_fma_f32 and the row sum from a tree of packed adds
+  // (experiment 14: 16 adds + 16 ands + 16 adds per block for the wrapped reads, 16 + 16 scalar VALU operations for the rest)
+  auto block = [&](auto ptag, int j0) {
+    constexpr int kb = decltype(ptag)::value;  // only its parity is used below
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // block kb (K, V, its position rows) has landed for everyone; everyone is done with the other buffers
+    const char* Ks = kvb + (kb & 1) * 2 * BLK;
+
+    // ---- content term: S^T = K . (Q+u)^T ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      half8 kf[4];
+      const unsigned ka = (unsigned)(size_t)Ks + l31 * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(kf[ks]) : "v"(ka + (((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4)) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]) : : "memory");
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qu[ks], s, 0, 0, 0);
+    }
+    // ---- position term: G[rho][i] = rp[rel_lo + rho] . (q_i + v), rho = 0..31 new, 32..63 = the previous block's ----
+    RplPad* Gnew = Gs + (kb & 1) * 32 * 32;
+    {
+      half8 rf[4];
+      rp_frags(rslot, rf);
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) g = __builtin_amdgcn_mfma_f32_32x32x16_f16(rf[ks], qv[ks], g, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Gnew[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = (RplPad)g[r];
+    }
+    // next block: K / V into the other buffer, the one new block of position rows into the slot that just fell out of use
+    if (j0 + RA_KB < len) {
+      stage(j0 + RA_KB, (kb + 1) & 1);
+      stage_rp(-(j0 / RA_KB + 1), dslot);
+    }
+    rslot = rslot ? rslot - 1 : 4;
+    dslot = dslot ? dslot - 1 : 4;
+    float bd[16];
+#ifdef SMI_RPL_PAD32
+    {
+      int gb = 2 * gbase + ((kb & 1) << 12);
+      asm volatile("" : "+v"(gb));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bd[r] = *(const float*)((const char*)Gs + ((gb - ((r & 3) + 8 * (r >> 2)) * 128) & 8191));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(bd[r]));
+    }
+#else
+    {
+      // 32-bit destinations: ds_read_u16 zero-extends itself.  With 16-bit asm outputs hipcc masks every result with 0xffff right
+      // behind its load -- in front of the wait below, i.e. on a register the data has not reached yet (stale values whenever a
+      // second workgroup on the CU delays the LDS: the run-to-run differences this kernel had at first).
+      unsigned raw[16];
+      unsigned rb = rd_base;
+      asm volatile("" : "+v"(rb));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr ((kb & 1) == 0) {
+          asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(raw[r]) : "v"(rb), "n"((27 - ((r & 3) + 8 * (r >> 2))) * 64) : "memory");
+        } else {
+          const unsigned a = (rb + (27 - ((r & 3) + 8 * (r >> 2))) * 64) ^ 2048u;
+          asm volatile("ds_read_u16 %0, %1" : "=v"(raw[r]) : "v"(a) : "memory");
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]), "+v"(raw[6]), "+v"(raw[7]),
+                     "+v"(raw[8]), "+v"(raw[9]), "+v"(raw[10]), "+v"(raw[11]), "+v"(raw[12]), "+v"(raw[13]), "+v"(raw[14]),
+                     "+v"(raw[15])
+                   :
+                   : "memory");
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bd[r] = (float)__builtin_bit_cast(f16, (unsigned short)raw[r]);
+    }
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] += bd[r];
+    if (j0 + RA_KB > len) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (j0 + (r & 3) + 8 * (r >> 2) + 4 * hi >= len) s[r] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * sl2e;
+    }
+    if (__any(mx > m + 8.0f)) {  // lazy rescale (see the kernel above)
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+      m = m_new;
+      lsum *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    f32x2 ps2[8];
+    half8 pf[2];
+    const f32x2 sc2 = {sl2e, sl2e}, nm2 = {-m, -m};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 a = __builtin_elementwise_fma(f32x2{s[r], s[r + 1]}, sc2, nm2);
+      const f32x2 pp = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+      ps2[r >> 1] = pp;
+      pf[r >> 3][r & 7] = (f16)pp[0];
+      pf[r >> 3][(r & 7) + 1] = (f16)pp[1];
+    }
+    {
+      const f32x2 t0 = (ps2[0] + ps2[1]) + (ps2[2] + ps2[3]), t1 = (ps2[4] + ps2[5]) + (ps2[6] + ps2[7]);
+      const f32x2 t = t0 + t1;
+      lsum += t[0] + t[1];
+    }
+    half4 va[2][2][2];  // [db][u][part]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const unsigned a = vaddr[db] + (kb & 1) * 2 * BLK;
+      va[db][0][0] = ra_tr_read<0>(a);
+      va[db][0][1] = ra_tr_read<1024>(a);
+      va[db][1][0] = ra_tr_read<2048>(a);
+      va[db][1][1] = ra_tr_read<3072>(a);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(va[0][0][0]), "+v"(va[0][0][1]), "+v"(va[0][1][0]), "+v"(va[0][1][1]), "+v"(va[1][0][0]),
+                   "+v"(va[1][0][1]), "+v"(va[1][1][0]), "+v"(va[1][1][1])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        half8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[e] = va[db][u][0][e];
+          vf[4 + e] = va[db][u][1][e];
+        }
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
+      }
+  };
+  for (int j0 = 0;;) {
+    block(std::integral_constant<int, 0>{}, j0);
+    j0 += RA_KB;
+    if (j0 >= len) break;
+    block(std::integral_constant<int, 1>{}, j0);
+    j0 += RA_KB;
+    if (j0 >= len) break;
+  }
+  const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / ltot;
+  if (qi < len) {
+    f16* op = ctx + (size_t)(start + qi) * d + h * 64;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        half4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][q * 4 + e] * inv);
+        const int col = db * 32 + 8 * q + 4 * hi;
+        if (ctx_tm) *(half4*)(ctx + tm_offset(start + qi, h * 64 + col, d)) = v;
+        else *(half4*)(op + col) = v;
+      }
+  }
+}
+
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
                                    int heads, hipStream_t stream, int ctx_tm) {
   if (heads <= 0 || d != heads * 64 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
   const float sl2e = 0.125f * 1.4426950408889634f;
   dim3 grid(n, heads, (max_len + RA_QB - 1) / RA_QB);
-  hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias,
-                     v_bias, ctx, d, sl2e, ctx_tm);
+  if (tune(TUNE_SPEECH_RP_LDS, 1) != 0)
+    hipLaunchKernelGGL(relpos_attention_lds_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias, v_bias,
+                       ctx, d, sl2e, ctx_tm);
+  else
+    hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias,
+                       v_bias, ctx, d, sl2e, ctx_tm);
   return hipGetLastError();
 }
 

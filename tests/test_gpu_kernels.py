@@ -511,3 +511,60 @@ def test_attention(lib, lens, heads, tm):
     got = (from_tile_major(ctx.view(-1), pad, d) if tm & 1 else ctx)[:t].float()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() <= 6e-3, (got - ref).abs().max().item()
+
+
+def _relpos_attention_ref(qkv, lens, d, heads, rp, rp_zero, u, v):
+    """scores[i][j] = ((q_i + u) . k_j + (q_i + v) . rp[rp_zero + i - j]) / 8, per clip and head, fp32.  The engine forms q + u and
+    q + v in fp16 (as an fp16 model would), so the reference rounds them the same way."""
+    out = torch.zeros(sum(lens), d, device=qkv.device)
+    o = 0
+    for n in lens:
+        q, k, vv = (qkv[o:o + n, i * d:(i + 1) * d].float().view(n, heads, 64).transpose(0, 1) for i in range(3))
+        qu = (q + u.view(heads, 1, 64)).half().float()
+        qv = (q + v.view(heads, 1, 64)).half().float()
+        idx = (rp_zero + torch.arange(n, device=qkv.device)[:, None] - torch.arange(n, device=qkv.device)[None, :]).clamp(0, rp.shape[0] - 1)
+        r = rp.float().view(rp.shape[0], heads, 64)                     # [rows, H, 64]
+        pos = torch.einsum("hid,ijhd->hij", qv, r[idx])                  # [H, n, n]
+        att = torch.softmax((qu @ k.transpose(1, 2) + pos) * 0.125, dim=-1)
+        out[o:o + n] = (att @ vv).transpose(0, 1).reshape(n, d)
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("lens,heads", [([40], 2), ([129, 7, 300], 4), ([499] * 6, 2), ([64] * 40, 2), ([1, 33, 128, 257], 16),
+                                        ([300] * 30, 4), ([97] * 100, 8)])   # 360 / 800 workgroups: more than one per CU
+def test_relpos_attention(lib, lens, heads):
+    """The conformer's relative-position attention through `smi_relpos_attention` against an fp32 restatement: both kernels (per-wave
+    global loads of the position rows + fp32 score pad; LDS ring + fp16 pad), row-major and tile-major output, clips shorter than
+    a key block, more workgroups than the chip holds at once (the LDS-ring kernel shares a CU three ways), and twice in a row
+    bit-identical."""
+    from sonar_amd import _lib
+
+    d = heads * 64
+    t = sum(lens)
+    pad = (t + 255) // 256 * 256
+    tmax = max(lens)
+    g = torch.Generator(device="cuda").manual_seed(t + heads)
+    qkv = (torch.randn(t, 3 * d, device="cuda", generator=g) * 1.2).half()
+    rp_rows = (2 * tmax - 1 + 127) // 128 * 128
+    rp = (torch.randn(rp_rows, d, device="cuda", generator=g) * 0.8).half()
+    u = torch.randn(d, device="cuda", generator=g) * 0.3
+    v = torch.randn(d, device="cuda", generator=g) * 0.3
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    ref = _relpos_attention_ref(qkv, lens, d, heads, rp, tmax - 1, u, v)
+    for ring in (0, 1):
+        for tm in (0, 1):
+            outs = []
+            for rep in range(2):
+                ctx = torch.full((pad, d), float("nan"), device="cuda", dtype=torch.float16)
+                with _lib.tuning(SPEECH_RP_LDS=ring):
+                    _lib.check(lib.smi_relpos_attention(qkv.data_ptr(), cu.data_ptr(), rp.data_ptr(), tmax - 1, rp_rows, u.data_ptr(),
+                                                        v.data_ptr(), ctx.data_ptr(), len(lens), tmax, d, heads, tm, _stream()))
+                torch.cuda.synchronize()
+                outs.append((from_tile_major(ctx.view(-1), pad, d) if tm else ctx)[:t])
+            assert torch.equal(outs[0], outs[1]), (ring, tm)
+            got = outs[0].float()
+            assert torch.isfinite(got).all(), (ring, tm)
+            err = (got - ref).abs().max().item()
+            assert err <= (8e-3 if ring else 6e-3), (ring, tm, err)
+
