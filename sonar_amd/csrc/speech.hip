@@ -1132,19 +1132,38 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
     *(half8*)&xin[r][ch] = v;
   }
   const int c = c0 + tid;
-  float wk[KT];
+  // Two taps per instruction (round 6: the kernel is VALU-bound -- 32 x 31 fp32 FMAs per thread were ~80 % of its time): the
+  // window is held as fp16 PAIRS of consecutive frames, once starting at even and once at odd offsets (62 registers, as many as
+  // the fp32 window took), the taps as fp16 pairs (the fp16 model's conv weights ARE fp16; an fp32 model's are rounded like every
+  // GEMM weight of the engine), and v_dot2_f32_f16 forms a0 b0 + a1 b1 + c with exact products and fp32 accumulation.
+  constexpr int NP = (KT + 1) / 2;
+  half2v wk2[NP];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) wk[k] = w[(size_t)c * KT + k];
+  for (int j = 0; j < NP; ++j) {
+    const float w0 = w[(size_t)c * KT + 2 * j], w1 = 2 * j + 1 < KT ? w[(size_t)c * KT + 2 * j + 1] : 0.f;
+    wk2[j] = half2v{(f16)w0, (f16)w1};
+  }
   const float sc = scale[c], sh = shift[c];
   __syncthreads();
-  float win[NIN];
+  constexpr int NW = NIN + 1;  // one padding frame so that the last odd pair exists (its tap is the zero pad of an odd KT)
+  half2v pe[NW / 2], po[NW / 2];  // pe[i] = (x[2i], x[2i+1]), po[i] = (x[2i+1], x[2i+2])
+  {
+    f16 prev = xin[0][tid];
 #pragma unroll
-  for (int r = 0; r < NIN; ++r) win[r] = (float)xin[r][tid];
+    for (int i = 0; i < NW / 2; ++i) {
+      const f16 a = xin[2 * i + 1][tid];
+      const f16 b = 2 * i + 2 < NIN ? xin[2 * i + 2][tid] : (f16)0.f;
+      pe[i] = half2v{prev, a};
+      po[i] = half2v{a, b};
+      prev = b;
+    }
+  }
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < KT; ++k) acc += wk[k] * win[tt + k];
+    for (int j = 0; j < NP; ++j)  // frames tt + 2j, tt + 2j + 1
+      acc = __builtin_amdgcn_fdot2((tt & 1) ? po[(tt + 2 * j) / 2] : pe[(tt + 2 * j) / 2], wk2[j], acc, false);
     const float v = acc * sc + sh;
     yout[tt][tid] = (f16)(v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)));  // SiLU
   }
