@@ -331,20 +331,29 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
   constexpr int D = NV * 256;
   constexpr float inv_d = 1.0f / D;
   const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  XT* xr = x + (size_t)r * D;
   if constexpr (sizeof(XT) == 2 && NV % 2 == 0) {
-    // x_tm: the fp16 stream itself is tile-major (common.hpp; round 4, with the LayerNorm fold of the conformer's GEMMs):
-    // a lane's 16-B chunk of row r is a 16-B chunk there too
-    auto xp = [&](int k) { return x_tm ? x + tm_offset(r, k * 512 + lane * 8, D) : xr + k * 512 + lane * 8; };
-    // fp16 stream: a lane owns 8 consecutive columns per 512-column block -> every access is 16 B
-    // (the stream read and write-back, and one whole 16-B chunk of the tile-major h)
-    constexpr int NH = NV / 2;
-    float u[NH][8];
+    // fp16 stream: TWO rows per wave (round 6), lanes 0..31 the even row, 32..63 the odd one, a lane owns the 16-B chunks l, l + 32,
+    // ... of its row.  In the tile-major layout (common.hpp) a row's share of a 32-column block is 64 B and the next row's follows
+    // it: with one row per wave every access was a 64-B piece of a 128-B line (the stream read, its write-back and the tile-major
+    // h); a row pair covers whole lines.  x_tm: the stream itself is tile-major; TM: h is.  8 rows per workgroup.
+    const int half = lane >> 5, l = lane & 31;
+    const int rr = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + half;
+    const bool live = rr < rows;
+    const int r2 = live ? rr : rows - 1;
+    XT* xr2 = x + (size_t)r2 * D;
+    auto xp = [&](int k) { return x_tm ? x + tm_offset(r2, (l + 32 * k) * 8, D) : xr2 + (l + 32 * k) * 8; };
+    auto half_sum = [](float v) {  // over the 32 lanes of a row: wave_sum without its last step
+      v += dpp_f<0xB1>(v);
+      v += dpp_f<0x4E>(v);
+      v += dpp_f<0x141>(v);
+      v += dpp_f<0x140>(v);
+      const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    };
+    float u[NV][8];
     float s8 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
+    for (int k = 0; k < NV; ++k) {
       const half8 raw = *(const half8*)xp(k);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -352,20 +361,20 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
         s8 += u[k][i];
       }
     }
-    float mean8 = wave_sum(s8) * inv_d, q8 = 0.f;
+    float mean8 = half_sum(s8) * inv_d, q8 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NH; ++k)
+    for (int k = 0; k < NV; ++k)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         u[k][i] -= mean8;
         q8 += u[k][i] * u[k][i];
       }
-    float rstd8 = 1.0f / sqrtf(wave_sum(q8) * inv_d + eps);
+    float rstd8 = 1.0f / sqrtf(half_sum(q8) * inv_d + eps);
     s8 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
-      const float* wp = w1 + k * 512 + lane * 8;
-      const float* bp = b1 + k * 512 + lane * 8;
+    for (int k = 0; k < NV; ++k) {
+      const float* wp = w1 + (l + 32 * k) * 8;
+      const float* bp = b1 + (l + 32 * k) * 8;
       const f32x4 wa = *(const f32x4*)wp, wb = *(const f32x4*)(wp + 4), ba = *(const f32x4*)bp, bb = *(const f32x4*)(bp + 4);
       half8 hv;
 #pragma unroll
@@ -375,41 +384,45 @@ __global__ __launch_bounds__(256) void ln2_kernel(XT* __restrict__ x, const floa
         u[k][i] = (float)hv[i];  // the second LayerNorm sees what the stream holds
         s8 += u[k][i];
       }
-      *(half8*)xp(k) = hv;
+      if (live) *(half8*)xp(k) = hv;
     }
     if (!h) return;
     if (w2) {
-      mean8 = wave_sum(s8) * inv_d;
+      mean8 = half_sum(s8) * inv_d;
       q8 = 0.f;
 #pragma unroll
-      for (int k = 0; k < NH; ++k)
+      for (int k = 0; k < NV; ++k)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           u[k][i] -= mean8;
           q8 += u[k][i] * u[k][i];
         }
-      rstd8 = 1.0f / sqrtf(wave_sum(q8) * inv_d + eps);
+      rstd8 = 1.0f / sqrtf(half_sum(q8) * inv_d + eps);
 #pragma unroll
-      for (int k = 0; k < NH; ++k) {
-        const float* wp = w2 + k * 512 + lane * 8;
-        const float* bp = b2 + k * 512 + lane * 8;
+      for (int k = 0; k < NV; ++k) {
+        const float* wp = w2 + (l + 32 * k) * 8;
+        const float* bp = b2 + (l + 32 * k) * 8;
         const f32x4 wa = *(const f32x4*)wp, wb = *(const f32x4*)(wp + 4), ba = *(const f32x4*)bp, bb = *(const f32x4*)(bp + 4);
 #pragma unroll
         for (int i = 0; i < 8; ++i) u[k][i] = u[k][i] * rstd8 * (i < 4 ? wa[i] : wb[i - 4]) + (i < 4 ? ba[i] : bb[i - 4]);
       }
     }
+    if (!live) return;
 #pragma unroll
-    for (int k = 0; k < NH; ++k) {
+    for (int k = 0; k < NV; ++k) {
       half8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = (f16)u[k][i];
       if constexpr (TM)
-        *(half8*)(h + tm_offset(r, k * 512 + lane * 8, D)) = o;  // one 16-B chunk of the tile-major operand
+        *(half8*)(h + tm_offset(rr, (l + 32 * k) * 8, D)) = o;  // one 16-B chunk of the tile-major operand
       else
-        *(half8*)(h + (size_t)r * D + k * 512 + lane * 8) = o;
+        *(half8*)(h + (size_t)rr * D + (l + 32 * k) * 8) = o;
     }
     return;
   }
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  XT* xr = x + (size_t)r * D;
   f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
@@ -488,9 +501,10 @@ hipError_t launch_ln2(void* x, const float* w1, const float* b1, const float* w2
                       f16* h, int rows, int d, hipStream_t stream, int out_tm, int x_f16, int x_tm) {
   if (rows <= 0) return hipErrorInvalidValue;
   if (x_tm && (!x_f16 || d % 512)) return hipErrorInvalidValue;  // the tile-major stream is fp16, 16-B chunks per lane
-  const int blocks = (rows + 3) / 4;
-#define SMI_LN2_LAUNCH(NV, TMF, XT) \
-  hipLaunchKernelGGL((ln2_kernel<NV, TMF, XT>), dim3(blocks), dim3(256), 0, stream, (XT*)x, w1, b1, w2, b2, eps, h, rows, x_tm);
+  // 4 rows per workgroup (one wave per row); the fp16 stream with an even NV: 8 (a row pair per wave)
+#define SMI_LN2_LAUNCH(NV, TMF, XT)                                                                                      \
+  hipLaunchKernelGGL((ln2_kernel<NV, TMF, XT>), dim3(sizeof(XT) == 2 && NV % 2 == 0 ? (rows + 7) / 8 : (rows + 3) / 4), dim3(256), 0, \
+                     stream, (XT*)x, w1, b1, w2, b2, eps, h, rows, x_tm);
 #define SMI_LN2_CASE(NV)                 \
   case NV * 256:                         \
     if (out_tm) {                        \
