@@ -590,8 +590,9 @@ int smi_attention(const void* qkv_f16, const int32_t* cu_seqlens, void* ctx_f16,
  * sonar/models/sonar_speech/factory.py via the w2v-BERT encoder: Shaw-style scores with the learned u / v biases):
  * scores[i][j] = ((q_i + u) . k_j + (q_i + v) . rp[rp_zero + i - j]) / 8 over the frames j of the clip, softmax, times V.
  * qkv: f16 [t, 3*d] packed rows (q | k | v); cu_seqlens: device int32 [n+1]; rp: f16 [rp_rows, d], the projected relative-position
- * table, row rp_zero = distance 0 (rows outside the table are clamped); u_bias / v_bias: fp32 [d]; ctx: f16 [t, d] (tile_major != 0:
- * tile-major, (t+255)/256*256 rows allocated).  head_dim = 64. */
+ * table, row rp_zero = distance 0 (rows outside the table are clamped); u_bias / v_bias: fp32 [d]; ctx: f16 [t, d].
+ * tile_major bit 0: ctx written tile-major, bit 1: qkv read tile-major (k = 3*d) ((t+255)/256*256 rows allocated for a
+ * tile-major buffer).  head_dim = 64. */
 int smi_relpos_attention(const void* qkv_f16, const int32_t* cu_seqlens, const void* rp_f16, int32_t rp_zero, int32_t rp_rows,
                          const float* u_bias, const float* v_bias, void* ctx_f16, int32_t n, int32_t max_len, int32_t d,
                          int32_t heads, int32_t tile_major, void* stream);

@@ -763,11 +763,13 @@ int smi_relpos_attention(const void* qkv, const int32_t* cu, const void* rp, int
                          void* stream) {
   if (!qkv || !cu || !rp || !u_bias || !v_bias || !ctx) return fail(SMI_ERR_INVALID_ARG, "null argument");
   if (heads <= 0 || d != heads * 64) return fail(SMI_ERR_UNSUPPORTED, "head_dim must be 64");
-  if (n <= 0 || max_len <= 0 || rp_rows <= 0 || rp_zero < 0 || rp_zero >= rp_rows)
-    return fail(SMI_ERR_INVALID_ARG, "n=%d max_len=%d rp_zero=%d rp_rows=%d", n, max_len, rp_zero, rp_rows);
+  if (n <= 0 || max_len <= 0 || rp_rows <= 0 || rp_zero < 0 || rp_zero >= rp_rows || tile_major < 0 || tile_major > 3)
+    return fail(SMI_ERR_INVALID_ARG, "n=%d max_len=%d rp_zero=%d rp_rows=%d tile_major=%d", n, max_len, rp_zero, rp_rows, tile_major);
+  if ((tile_major & 2) && !relpos_attention_reads_tile_major())
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major q | k | v needs the LDS-ring kernel (SPEECH_RP_LDS, SPEECH_QKV_TM)");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(launch_relpos_attention((const f16*)qkv, cu, (const f16*)rp, rp_zero, rp_rows, u_bias, v_bias, (f16*)ctx, n, max_len, d,
-                                  heads, (hipStream_t)stream, tile_major ? 1 : 0));
+                                  heads, (hipStream_t)stream, tile_major & 1, (tile_major >> 1) & 1));
   return SMI_OK;
 }
 

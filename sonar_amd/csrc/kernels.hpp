@@ -255,7 +255,8 @@ hipError_t launch_fbank_batch(const float* waves, const int64_t* off_dev, int n,
                               float* out, hipStream_t stream);
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
-                                   int heads, hipStream_t stream, int ctx_tm = 0);
+                                   int heads, hipStream_t stream, int ctx_tm = 0, int qkv_tm = 0);
+bool relpos_attention_reads_tile_major();  // tuning: the LDS-ring kernel is on and SPEECH_QKV_TM is not 0
 hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
                                  const float* shift, f16* y, int n, int max_len, int d, int ktaps,
                                  hipStream_t stream, int y_tm = 0);

@@ -829,7 +829,8 @@ typedef f16 RplPad;
 // SMI_SPEECH_RP_LDS=0: the kernel above (A/B runs).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_WAVES, SMI_RELPOS_WAVES))) void relpos_attention_lds_kernel(
     const f16* __restrict__ qkv, const int32_t* __restrict__ cu, const f16* __restrict__ rp, int rp_zero, int rp_rows,
-    const float* __restrict__ u_bias, const float* __restrict__ v_bias, f16* __restrict__ ctx, int d, float sl2e, int ctx_tm) {
+    const float* __restrict__ u_bias, const float* __restrict__ v_bias, f16* __restrict__ ctx, int d, float sl2e, int ctx_tm,
+    int qkv_tm) {
   constexpr int BLK = RA_KB * 128;  // 4 KiB
   __shared__ __attribute__((aligned(16))) char lds[4 * BLK + 4 * BLK * (int)sizeof(RplPad) / 2 + 5 * BLK];  // K / V x 2 | fp16 pads | position-row ring
   const int n = blockIdx.x, h = blockIdx.y;
@@ -842,19 +843,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   RplPad* Gs = (RplPad*)(lds + 4 * BLK) + wave * 64 * 32;  // [64 rho][32 queries]
   char* ring = lds + 4 * BLK + 4 * BLK * (int)sizeof(RplPad) / 2;
   const size_t ld = (size_t)3 * d;
-  const f16* qbase = qkv + (size_t)start * ld + h * 64;
-  const f16* kbase = qbase + d;
-  const f16* vbase = qbase + 2 * d;
+  // qkv_tm: the fused QKV projection leaves q | k | v in the tile-major layout (common.hpp; K = 3 d), which lets that GEMM run on the
+  // 4-wave engine: a 16-B chunk of a row is a 16-B chunk there too, the chunks of 8 consecutive rows of a 32-column block are 512
+  // contiguous bytes, so the per-thread DMA sources below only change their address arithmetic
+  auto src = [&](int row, int col) -> const f16* {  // 16-B chunk (start + row, col .. col + 7) of qkv
+    return qkv_tm ? qkv + tm_offset(start + row, col, 3 * d) : qkv + (size_t)(start + row) * ld + col;
+  };
   const f16* rph = rp + h * 64;
 
   const int i0 = q0 + wave * 32;
   const int qi = i0 + l31;
-  const f16* qptr = qbase + (size_t)min(qi, len - 1) * ld;
   half8 qu[4], qv[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int c0 = (ks * 2 + hi) * 8;
-    const half8 q = *(const half8*)(qptr + c0);
+    const half8 q = *(const half8*)src(min(qi, len - 1), h * 64 + c0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       qu[ks][e] = (f16)((float)q[e] + u_bias[h * 64 + c0 + e]);
@@ -867,8 +870,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   const int kchunk = sslot ^ ((skey >> 1) & 7), vchunk = sslot ^ (((skey >> 1) & 1) << 2);
   auto stage = [&](int j0, int buf) {
     const int row = min(j0 + skey, len - 1);
-    glds16(kbase + (size_t)row * ld + kchunk * 8, kvb + buf * 2 * BLK + wave * 1024);
-    glds16(vbase + (size_t)row * ld + vchunk * 8, kvb + buf * 2 * BLK + BLK + wave * 1024);
+    glds16(src(row, d + h * 64 + kchunk * 8), kvb + buf * 2 * BLK + wave * 1024);
+    glds16(src(row, 2 * d + h * 64 + vchunk * 8), kvb + buf * 2 * BLK + BLK + wave * 1024);
   };
   // position rows: aligned block b = rows A + 32 b + (0..31), clamped to the table, into ring slot `slot` (K layout)
   const int rowA = q0 - 31 + rp_zero + skey;
@@ -1103,15 +1106,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMI_RELPOS_
   }
 }
 
+bool relpos_attention_reads_tile_major() { return tune(TUNE_SPEECH_RP_LDS, 1) != 0 && tune(TUNE_SPEECH_QKV_TM, 1) != 0; }
+
 hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16* rp, int rp_zero, int rp_rows,
                                    const float* u_bias, const float* v_bias, f16* ctx, int n, int max_len, int d,
-                                   int heads, hipStream_t stream, int ctx_tm) {
+                                   int heads, hipStream_t stream, int ctx_tm, int qkv_tm) {
   if (heads <= 0 || d != heads * 64 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
+  if (qkv_tm && tune(TUNE_SPEECH_RP_LDS, 1) == 0) return hipErrorInvalidValue;  // only the LDS-ring kernel reads tile-major q | k | v
   const float sl2e = 0.125f * 1.4426950408889634f;
   dim3 grid(n, heads, (max_len + RA_QB - 1) / RA_QB);
   if (tune(TUNE_SPEECH_RP_LDS, 1) != 0)
     hipLaunchKernelGGL(relpos_attention_lds_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias, v_bias,
-                       ctx, d, sl2e, ctx_tm);
+                       ctx, d, sl2e, ctx_tm, qkv_tm);
   else
     hipLaunchKernelGGL(relpos_attention_kernel, grid, dim3(256), 0, stream, qkv, cu, rp, rp_zero, rp_rows, u_bias,
                        v_bias, ctx, d, sl2e, ctx_tm);

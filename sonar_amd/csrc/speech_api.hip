@@ -508,6 +508,9 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   const int mid_in = E->mid_tm ? GEMM_IN_TM : 0;
   HIP_TRY(launch_layernorm(x, E->layers[0].ffn1_ln_w.as<float>(), E->layers[0].ffn1_ln_b.as<float>(), c.ln_eps, h, R, d, stream,
                            tmf, x16, xtm));
+  // q | k | v tile-major between the fused QKV GEMM and the attention: with the LayerNorm fold on the tile-major stream only (the
+  // GEMM then runs on the 4-wave engine, which has no row-major epilogue) and when the attention kernel that reads it is on
+  const int qkv_tm = xtm && d % 256 == 0 && relpos_attention_reads_tile_major();
   for (int l = 0; l < c.num_layers; ++l) {
     ConfLayer& L = E->layers[l];
     // x += 0.5 * FFN1(LN(x))
@@ -517,8 +520,8 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
                              nullptr, &produce));
       // x += RelPosMHA(LN(x)): the LayerNorm rides in the fused QKV GEMM, which multiplies the stream itself
       const GemmLnFold cq = consume(L.c1_qkv);
-      HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | GEMM_IN_TM, (const f16*)x, L.wf_qkv.as<f16>(), L.c2_qkv.as<float>(), qkv, R, 3 * d, d,
-                             3 * d, stream, nullptr, &cq));
+      HIP_TRY(launch_gemm_tn(EPI_BIAS_F16 | GEMM_IN_TM | (qkv_tm ? GEMM_OUT_TM : 0), (const f16*)x, L.wf_qkv.as<f16>(),
+                             L.c2_qkv.as<float>(), qkv, R, 3 * d, d, 3 * d, stream, nullptr, &cq));
     } else {
       HIP_TRY(launch_gemm_tn(epi_half | ffn_in, big, L.ffn1_w2.as<f16>(), L.ffn1_b2.as<float>(), x, R, d, f, d,
                              stream));
@@ -528,7 +531,7 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
     }
     HIP_TRY(launch_gemm_tn(EPI_BIAS_F16, pe_slice, L.w_r.as<f16>(), nullptr, E->rp.p, rp_m, d, d, d, stream));
     HIP_TRY(launch_relpos_attention(qkv, dcu, E->rp.as<f16>(), tm - 1, rp_m, L.u_bias.as<float>(), L.v_bias.as<float>(), ctx,
-                                    n, tm, d, c.num_heads, stream, E->mid_tm));
+                                    n, tm, d, c.num_heads, stream, E->mid_tm, qkv_tm));
     // x += Conv(LN(x)): pointwise(d->2d)+GLU, depthwise+BN+SiLU, pointwise(d->d)
     if (xtm) {
       HIP_TRY(launch_gemm_tn(EPI_RESID_F16 | io_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream, nullptr,

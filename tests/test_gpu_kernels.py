@@ -552,19 +552,24 @@ def test_relpos_attention(lib, lens, heads):
     v = torch.randn(d, device="cuda", generator=g) * 0.3
     cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
     ref = _relpos_attention_ref(qkv, lens, d, heads, rp, tmax - 1, u, v)
+    qkv_tm = to_tile_major(torch.cat([qkv, torch.zeros(pad - t, 3 * d, device="cuda", dtype=torch.float16)]))
     for ring in (0, 1):
-        for tm in (0, 1):
+        for tm in ((0, 1, 2, 3) if ring else (0, 1)):   # bit 1: q | k | v handed over tile-major (the LDS-ring kernel only)
             outs = []
             for rep in range(2):
                 ctx = torch.full((pad, d), float("nan"), device="cuda", dtype=torch.float16)
                 with _lib.tuning(SPEECH_RP_LDS=ring):
-                    _lib.check(lib.smi_relpos_attention(qkv.data_ptr(), cu.data_ptr(), rp.data_ptr(), tmax - 1, rp_rows, u.data_ptr(),
-                                                        v.data_ptr(), ctx.data_ptr(), len(lens), tmax, d, heads, tm, _stream()))
+                    _lib.check(lib.smi_relpos_attention((qkv_tm if tm & 2 else qkv).data_ptr(), cu.data_ptr(), rp.data_ptr(), tmax - 1,
+                                                        rp_rows, u.data_ptr(), v.data_ptr(), ctx.data_ptr(), len(lens), tmax, d, heads, tm,
+                                                        _stream()))
                 torch.cuda.synchronize()
-                outs.append((from_tile_major(ctx.view(-1), pad, d) if tm else ctx)[:t])
+                outs.append((from_tile_major(ctx.view(-1), pad, d) if tm & 1 else ctx)[:t])
             assert torch.equal(outs[0], outs[1]), (ring, tm)
             got = outs[0].float()
             assert torch.isfinite(got).all(), (ring, tm)
             err = (got - ref).abs().max().item()
             assert err <= (8e-3 if ring else 6e-3), (ring, tm, err)
+    with _lib.tuning(SPEECH_RP_LDS=0):   # the round-5 kernel has no tile-major q | k | v path: refused, not mis-read
+        assert lib.smi_relpos_attention(qkv_tm.data_ptr(), cu.data_ptr(), rp.data_ptr(), tmax - 1, rp_rows, u.data_ptr(), v.data_ptr(),
+                                        ctx.data_ptr(), len(lens), tmax, d, heads, 2, _stream()) != 0
 
