@@ -100,6 +100,35 @@ def main():
     torch.cuda.synchronize()
     print(f"{'v2 tile stats':16s} M={m} N={n} K={k}: {diff} of {iters - 1} launches differ", flush=True)
     bad += diff
+    # the conformer's relative-position attention (LDS ring + fp16 pad, inline-asm LDS reads): the benchmark shape (64 clips of 499
+    # frames, 16 heads = 4096 workgroups, three per CU) and a ragged batch, row-major and tile-major q | k | v
+    for lens, heads in (([499] * 64, 16), ([37, 499, 128, 300, 1, 260] * 8, 16)):
+        d = heads * 64
+        t = sum(lens)
+        pad = (t + 255) // 256 * 256
+        tmx = max(lens)
+        qkv = (torch.randn(pad, 3 * d, device="cuda", generator=g) * 1.2).half()
+        qkv_t = to_tile_major(qkv)
+        rp_rows = (2 * tmx - 1 + 127) // 128 * 128
+        rp = (torch.randn(rp_rows, d, device="cuda", generator=g) * 0.8).half()
+        ub = torch.randn(d, device="cuda", generator=g) * 0.3
+        vb = torch.randn(d, device="cuda", generator=g) * 0.3
+        cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+        for tmode in (1, 3):
+            first, diff = None, 0
+            for it in range(iters):
+                disturb()
+                ctx = torch.zeros((pad, d), device="cuda", dtype=torch.float16)
+                _lib.check(lib.smi_relpos_attention((qkv_t if tmode & 2 else qkv).data_ptr(), cu.data_ptr(), rp.data_ptr(), tmx - 1, rp_rows,
+                                                    ub.data_ptr(), vb.data_ptr(), ctx.data_ptr(), len(lens), tmx, d, heads, tmode, st()))
+                if first is None:
+                    first = ctx
+                elif not torch.equal(ctx, first):
+                    diff += 1
+            torch.cuda.synchronize()
+            ok = bool(torch.isfinite(first.float()).all())
+            print(f"{'relpos attention':16s} {len(lens)} clips, {t} frames, tile_major={tmode}: {diff} of {iters - 1} launches differ, finite={ok}", flush=True)
+            bad += diff + (0 if ok else 1)
     del x, w, out, tmax, tsum, first, cur, dx, dw, dout
     torch.cuda.empty_cache()
     # the full text encoder (LayerNorm-fold consumer / producer kernels, residual stream, row sums): repeated forwards of
