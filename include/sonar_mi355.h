@@ -558,7 +558,8 @@ int smi_pack_tile_major(const void* src_f16, void* dst_f16, int32_t rows, int32_
  * 5 f16 SiLU out, 6 f16 GLU out (n/2 wide), 7 f16 tanh out, 8 f16 residual accumulate
  * (out_f16 = f16(float(out_f16) + ...), one rounding), 9 the same with 0.5 * (...) (bias may be NULL);
  * (epi >> 8) & 0xf selects the tile engine: 0 auto, 1 128x128, 2 256x256 (needs m,n % 256 == 0);
- * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 6, 8, 9) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5, 8, 9).
+ * layout flags SMI_GEMM_IN_TM (epilogues 0, 2, 3, 4, 6, 8, 9) and SMI_GEMM_IN_TM|SMI_GEMM_OUT_TM (0, 1, 5, 8, 9; 6 with ldo == n/2, a bias
+ * and enough 256x256 tiles for the 4-wave engine -- SMI_ERR_UNSUPPORTED otherwise).
  * m%128==0, n%128==0, k%64==0. */
 int smi_gemm_tn(int32_t epi, const void* x_f16, const void* w_f16, const float* bias, void* out,
                 int32_t m, int32_t n, int32_t k, int32_t ldo, void* stream);

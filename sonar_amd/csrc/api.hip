@@ -693,12 +693,19 @@ int smi_gemm_tn(int32_t epi, const void* x, const void* w, const float* bias, vo
   if (epi < 0 || (epi & ~(0xfff | GEMM_IN_TM | GEMM_OUT_TM)) || e > 9 || sel > 2 || m <= 0 || m % 128 ||
       n <= 0 || n % 128 || k <= 0 || k % 64 || ldo < (e == 6 ? n / 2 : n) || (sel == 2 && (m % 256 || n % 256)))
     return fail(SMI_ERR_UNSUPPORTED, "gemm shape m=%d n=%d k=%d epi=%d ldo=%d", m, n, k, epi, ldo);
-  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5 && e != 8 && e != 9) : (e != 0 && e != 2 && e != 3 && e != 4 && e != 6 && e != 8 && e != 9))))
+  if (in_tm && (m % 256 || n % 256 || (out_tm ? (e != 0 && e != 1 && e != 5 && e != 6 && e != 8 && e != 9) : (e != 0 && e != 2 && e != 3 && e != 4 && e != 6 && e != 8 && e != 9))))
     return fail(SMI_ERR_UNSUPPORTED, "tile-major gemm: m=%d n=%d epi=%d", m, n, epi);
-  if (out_tm && (!in_tm || ldo != n))
-    return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n");
+  if (out_tm && (!in_tm || ldo != (e == 6 ? n / 2 : n)))
+    return fail(SMI_ERR_UNSUPPORTED, "tile-major output needs tile-major inputs and ldo == n (n / 2 for the GLU epilogue)");
   if (!have_device()) return fail(SMI_ERR_NO_DEVICE, "no HIP device visible");
-  HIP_TRY(launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream));
+  {
+    const hipError_t he = launch_gemm_tn(epi, (const f16*)x, (const f16*)w, bias, out, m, n, k, ldo, (hipStream_t)stream);
+    // combinations only one engine implements (the GLU epilogue with a tile-major output: the 4-wave engine, from its tile
+    // threshold up, with a bias) are refused, not mis-computed
+    if (he == hipErrorInvalidValue)
+      return fail(SMI_ERR_UNSUPPORTED, "gemm m=%d n=%d k=%d epi=%d: no engine takes this combination", m, n, k, epi);
+    HIP_TRY(he);
+  }
   return SMI_OK;
 }
 

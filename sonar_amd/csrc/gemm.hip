@@ -1307,7 +1307,7 @@ hipError_t launch_gemm_tn(int epi_sel, const f16* X, const f16* W, const float* 
   const bool in_tm = epi_sel & GEMM_IN_TM, out_tm = epi_sel & GEMM_OUT_TM;
   if (M % GT_BM || N % GT_BN || K % GT_BK || M <= 0) return hipErrorInvalidValue;
   if (in_tm && (M % TM_ROWS || N % TM_ROWS)) return hipErrorInvalidValue;
-  if (out_tm && (!in_tm || ldo != N)) return hipErrorInvalidValue;
+  if (out_tm && (!in_tm || ldo != (epi == EPI_GLU_F16 ? N / 2 : N))) return hipErrorInvalidValue;
   const bool can256 = M % G2_BM == 0 && N % G2_BN == 0;
   if (sel == 2 && !can256) return hipErrorInvalidValue;
   // the 256x256 ping-pong engine is ~1.5x more efficient per CU than the 128x128 one but has a 21 us

@@ -113,10 +113,15 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_kernel(const f16* __restri
   // j * 16 KiB + mi * 1 KiB
   const int cidx = (kg & 1) * 2 + (kg >> 1);
   const unsigned lane_part = (unsigned)(((wr * 128 + l15) * 32 + ((cidx ^ tm_swz(l15)) << 3)) * 2);
+  // EPI_GLU_F16 (the conformer's pointwise_conv1 + GLU; out_h[m][g * 32 + c] = f16(a * sigmoid(b)), a / b = columns g * 64 + c /
+  // g * 64 + 32 + c, gemm.hip): the output has N / 2 columns, a wave's 128 columns are two [32 values | 32 gates] groups = two
+  // 32-column blocks of the tile-major output, 16 chunks per lane and tile
+  constexpr bool GLU = EPI == EPI_GLU_F16;
   auto tile_out = [&](int tm_, int tn_) {
+    if constexpr (GLU) return (char*)out + ((size_t)tm_ * (N >> 6) + (size_t)tn_ * 4 + wc * 2) * (TM_BLOCK * 2);
     return (char*)out + ((size_t)tm_ * (N >> 5) + (size_t)tn_ * 8 + wc * 4) * (TM_BLOCK * 2);
   };
-  constexpr int NST = (V2_PROBE & 3) ? 0 : 32;  // stores per wave and tile
+  constexpr int NST = (V2_PROBE & 3) ? 0 : (GLU ? 16 : 32);  // stores per wave and tile
 
   bool more = true, first_tile = true;
   while (more) {
@@ -234,6 +239,66 @@ __global__ __launch_bounds__(V2_THREADS) void gemm_v2_kernel(const f16* __restri
           rsall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_rs[mi >> 2])));
           if constexpr (MODE == 1) nmall[mi] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(row_nm[mi >> 2])));
         }
+      }
+      if constexpr (GLU) {
+        // the fold / bias affine of one accumulator block (the LayerNorm in front of this GEMM), no activation
+        auto affine = [&](f32x4 v, const f32x4& c2q, const f32x4& c1q, float rs, float nm) {
+          const f32x2 rs2 = {rs, rs}, nm2 = {nm, nm};
+#pragma unroll
+          for (int hp2 = 0; hp2 < 2; ++hp2) {
+            const f32x2 c2p = {c2q[2 * hp2], c2q[2 * hp2 + 1]};
+            f32x2 vp = {v[2 * hp2], v[2 * hp2 + 1]};
+            if constexpr (MODE == 1) {
+              const f32x2 c1p = {c1q[2 * hp2], c1q[2 * hp2 + 1]};
+              vp = __builtin_elementwise_fma(rs2, vp, __builtin_elementwise_fma(nm2, c1p, c2p));
+            } else if constexpr (MODE == 2) {
+              vp = __builtin_elementwise_fma(rs2, vp, c2p);
+            } else {
+              vp = vp + c2p;
+            }
+            v[2 * hp2] = vp[0];
+            v[2 * hp2 + 1] = vp[1];
+          }
+          return v;
+        };
+#define SMI_V2_GLU(G, JA, JG, MI)                                                                                       \
+  {                                                                                                                    \
+    f32x4 a0, a1, g0, g1;                                                                                              \
+    SMI_V2_RDOUT_IDX(JA, 0, MI, a0);                                                                                   \
+    SMI_V2_RDOUT_IDX(JA, 1, MI, a1);                                                                                   \
+    SMI_V2_RDOUT_IDX(JG, 0, MI, g0);                                                                                   \
+    SMI_V2_RDOUT_IDX(JG, 1, MI, g1);                                                                                   \
+    a0 = affine(a0, c2q[0], c1q[0], rsall[MI], nmall[MI]);                                                             \
+    a1 = affine(a1, c2q[1], c1q[1], rsall[MI], nmall[MI]);                                                             \
+    g0 = affine(g0, c2q[2], c1q[2], rsall[MI], nmall[MI]);                                                             \
+    g1 = affine(g1, c2q[3], c1q[3], rsall[MI], nmall[MI]);                                                             \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                    \
+      a0[e] *= sigmoid_f(g0[e]);                                                                                       \
+      a1[e] *= sigmoid_f(g1[e]);                                                                                       \
+    }                                                                                                                  \
+    const uint2 h0 = __builtin_bit_cast(uint2, epi_act_pack<EPI_BIAS_F16>(a0));                                        \
+    const uint2 h1 = __builtin_bit_cast(uint2, epi_act_pack<EPI_BIAS_F16>(a1));                                        \
+    const auto s0 = __builtin_amdgcn_permlane16_swap(h0.x, h1.x, false, false);                                        \
+    const auto s1 = __builtin_amdgcn_permlane16_swap(h0.y, h1.y, false, false);                                        \
+    put((G) * 8 + (MI), u32x4{s0[0], s1[0], s0[1], s1[1]});                                                            \
+  }
+#define SMI_V2_GLU_GROUP(G, JA, JG)                                                                                    \
+  {                                                                                                                    \
+    f32x4 c2q[4], c1q[4]; /* blocks ni = 4 G + q: values q = 0, 1, gates q = 2, 3 */                                   \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int r = 0; r < 4; ++r) {                      \
+      const int col = (4 * (G) + q) * 16 + 4 * kg + r; /* of the wave's 128: lane col & 63, register col >> 6 */        \
+      c2q[q][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((col & 63) * 4, __float_as_int(c2r[(4 * (G) + q) >> 2]))); \
+      c1q[q][r] = 0.f;                                                                                                 \
+      if constexpr (MODE == 1)                                                                                         \
+        c1q[q][r] = __int_as_float(__builtin_amdgcn_ds_bpermute((col & 63) * 4, __float_as_int(c1r[(4 * (G) + q) >> 2]))); \
+    }                                                                                                                  \
+    SMI_V2_GLU(G, JA, JG, 0) SMI_V2_GLU(G, JA, JG, 1) SMI_V2_GLU(G, JA, JG, 2) SMI_V2_GLU(G, JA, JG, 3)                \
+    SMI_V2_GLU(G, JA, JG, 4) SMI_V2_GLU(G, JA, JG, 5) SMI_V2_GLU(G, JA, JG, 6) SMI_V2_GLU(G, JA, JG, 7)                \
+  }
+        SMI_V2_GLU_GROUP(0, 0, 1) SMI_V2_GLU_GROUP(1, 2, 3)
+#undef SMI_V2_GLU_GROUP
+#undef SMI_V2_GLU
+        return;
       }
 #define SMI_V2_PAIR(J, MI)                                                                                              \
   {                                                                                                                    \
@@ -799,10 +864,10 @@ bool gemm_v2_fits(int epi, int M, int N, int K, const float* bias, const GemmLnF
   if ((int64_t)(M / 256) * (N / 256) < tune(TUNE_G2V2_MIN, 128)) return false;
   if (epi == EPI_RESID_F16 || epi == EPI_RESID_HALF_F16)  // tile-major residual stream; fold: producer side only
     return !fold || !fold->part_in;
-  if (epi != EPI_BIAS_F16 && epi != EPI_RELU_F16 && epi != EPI_SILU_F16) return false;
+  if (epi != EPI_BIAS_F16 && epi != EPI_RELU_F16 && epi != EPI_SILU_F16 && epi != EPI_GLU_F16) return false;
   if (!bias) return false;
   if (fold && (!fold->part_in || !fold->c1 || fold->nparts < 1 || fold->nparts > 4)) return false;
-  if (fold && epi == EPI_SILU_F16 && !fold->centered) return false;
+  if (fold && (epi == EPI_SILU_F16 || epi == EPI_GLU_F16) && !fold->centered) return false;
   return true;
 }
 
@@ -843,6 +908,7 @@ hipError_t launch_gemm_v2(int epi, const f16* X, const f16* W, const float* bias
     SMI_V2_CASE(EPI_BIAS_F16)
     SMI_V2_CASE(EPI_RELU_F16)
     SMI_V2_CASE(EPI_SILU_F16)
+    SMI_V2_CASE(EPI_GLU_F16)
   }
 #undef SMI_V2_CASE
   return hipErrorInvalidValue;

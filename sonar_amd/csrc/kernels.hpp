@@ -259,7 +259,7 @@ hipError_t launch_relpos_attention(const f16* qkv, const int32_t* cu, const f16*
 bool relpos_attention_reads_tile_major();  // tuning: the LDS-ring kernel is on and SPEECH_QKV_TM is not 0
 hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
                                  const float* shift, f16* y, int n, int max_len, int d, int ktaps,
-                                 hipStream_t stream, int y_tm = 0);
+                                 hipStream_t stream, int y_tm = 0, int x_tm = 0);
 hipError_t launch_pool_attention(const f16* q, const f16* kv, const int32_t* cu, f16* ctx, int n, int d, int heads,
                                  hipStream_t stream);
 hipError_t launch_broadcast_row(const float* row, float* x, int rows, int d, hipStream_t stream);

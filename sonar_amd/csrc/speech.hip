@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift,
-                                                             f16* __restrict__ y, int d, int y_tm) {
+                                                             f16* __restrict__ y, int d, int y_tm, int x_tm) {
   constexpr int TT = 32, HALF = (KT - 1) / 2, NIN = TT + KT - 1;
   __shared__ __attribute__((aligned(16))) f16 xin[NIN][256];
   __shared__ __attribute__((aligned(16))) f16 yout[TT][256];
@@ -1148,7 +1148,8 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
     const int r = i >> 5, ch = (i & 31) * 8;
     const int t = t0 - HALF + r;
     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};  // zero outside the clip
-    if (t >= 0 && t < len) v = *(const half8*)(x + (size_t)(start + t) * d + c0 + ch);
+    if (t >= 0 && t < len)  // x_tm: the GLU output arrives tile-major (a 16-B chunk of a row is a 16-B chunk there too)
+      v = *(const half8*)(x_tm ? x + tm_offset(start + t, c0 + ch, d) : x + (size_t)(start + t) * d + c0 + ch);
     *(half8*)&xin[r][ch] = v;
   }
   const int c = c0 + tid;
@@ -1199,15 +1200,15 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(const f16* __restri
 
 hipError_t launch_dwconv_bn_silu(const f16* x, const int32_t* cu, const float* w, const float* scale,
                                  const float* shift, f16* y, int n, int max_len, int d, int ktaps,
-                                 hipStream_t stream, int y_tm) {
+                                 hipStream_t stream, int y_tm, int x_tm) {
   if (d % 256 || n <= 0 || max_len <= 0) return hipErrorInvalidValue;
   dim3 grid(n, (max_len + 31) / 32, d / 256);
   switch (ktaps) {
     case 31:
-      hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm);
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<31>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm, x_tm);
       break;
     case 7:
-      hipLaunchKernelGGL(dwconv_bn_silu_kernel<7>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm);
+      hipLaunchKernelGGL(dwconv_bn_silu_kernel<7>, grid, dim3(256), 0, stream, x, cu, w, scale, shift, y, d, y_tm, x_tm);
       break;
     default: return hipErrorInvalidValue;
   }

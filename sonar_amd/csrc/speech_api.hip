@@ -511,6 +511,7 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
   // q | k | v tile-major between the fused QKV GEMM and the attention: with the LayerNorm fold on the tile-major stream only (the
   // GEMM then runs on the 4-wave engine, which has no row-major epilogue) and when the attention kernel that reads it is on
   const int qkv_tm = xtm && d % 256 == 0 && relpos_attention_reads_tile_major();
+  int glu_tm = 0;  // set per layer where the fold-consumer GLU GEMM is launched
   for (int l = 0; l < c.num_layers; ++l) {
     ConfLayer& L = E->layers[l];
     // x += 0.5 * FFN1(LN(x))
@@ -537,15 +538,17 @@ int smi_speech_encoder_forward(smi_speech_encoder* E, const float* fbank, const 
       HIP_TRY(launch_gemm_tn(EPI_RESID_F16 | io_tm, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream, nullptr,
                              &produce));
       const GemmLnFold cg = consume(L.c1_pw1);
-      HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | GEMM_IN_TM, (const f16*)x, L.wf_pw1.as<f16>(), L.c2_pw1.as<float>(), E->glu.p,
-                             R, 2 * d, d, d, stream, nullptr, &cg));
+      // tile-major GLU output where the 4-wave engine takes the launch (its GLU read-out; SPEECH_GLU_TM=0: row-major, 8-wave engine)
+      glu_tm = tune(TUNE_SPEECH_GLU_TM, 1) != 0 && gemm_v2_fits(EPI_GLU_F16, R, 2 * d, d, L.c2_pw1.as<float>(), &cg);
+      HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | GEMM_IN_TM | (glu_tm ? GEMM_OUT_TM : 0), (const f16*)x, L.wf_pw1.as<f16>(),
+                             L.c2_pw1.as<float>(), E->glu.p, R, 2 * d, d, d, stream, nullptr, &cg));
     } else {
       HIP_TRY(launch_gemm_tn(epi_res | mid_in, ctx, L.w_o.as<f16>(), L.b_o.as<float>(), x, R, d, d, d, stream));
       HIP_TRY(launch_layernorm(x, L.conv_ln_w.as<float>(), L.conv_ln_b.as<float>(), c.ln_eps, h, R, d, stream, tmf, x16));
       HIP_TRY(launch_gemm_tn(EPI_GLU_F16 | (2 << 8) | ffn_in, h, L.w_pw1.as<f16>(), nullptr, E->glu.p, R, 2 * d, d, d, stream));
     }
     HIP_TRY(launch_dwconv_bn_silu(E->glu.as<f16>(), dcu, L.w_dw.as<float>(), L.bn_scale.as<float>(), L.bn_shift.as<float>(),
-                                  E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream, E->mid_tm));
+                                  E->dw.as<f16>(), n, tm, d, c.conv_kernel, stream, E->mid_tm, glu_tm));
     // x += 0.5 * FFN2(LN(x))
     if (xtm) {
       HIP_TRY(launch_gemm_tn(EPI_RESID_F16 | io_tm, E->dw.as<f16>(), L.w_pw2.as<f16>(), nullptr, x, R, d, d, d, stream, nullptr,

@@ -38,6 +38,7 @@ namespace smi {
   X(G2_SPLITK_MIN)   /* 256x256 units from which a split-K launch takes the 256x256 engine ([96]) */                    \
   X(SPEECH_MID_TM)   /* speech encoder: [1] tile-major outputs of the per-clip kernels (at create) */                   \
   X(SPEECH_RP_LDS)   /* speech attention: [1] position rows staged once per workgroup through an LDS ring + fp16 score pad, 0 per-wave global loads + fp32 pad */ \
+  X(SPEECH_GLU_TM)   /* speech encoder: [1] tile-major GLU output (pointwise_conv1 on the 4-wave engine; needs SPEECH_X_TM), 0 row-major, 8-wave engine */ \
   X(SPEECH_QKV_TM)   /* speech encoder: [1] tile-major q | k | v between the fused QKV GEMM (4-wave engine) and the attention (needs SPEECH_RP_LDS, SPEECH_X_TM), 0 row-major */ \
   X(SPEECH_X_TM)     /* speech encoder: [1] tile-major residual stream + LayerNorm fold (at create) */                  \
   X(XSIM_TM)         /* xsim: [1] tile-major normalised operands, 0 row-major */                                        \

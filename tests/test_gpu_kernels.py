@@ -115,6 +115,46 @@ def test_gemm_tn_tile_major(lib, m, n, k, epi, out_tm):
                            _stream()) != 0
 
 
+@pytest.mark.parametrize("m,n,k", [(6144, 2048, 1024), (4096, 4096, 256), (32000, 2048, 1024)])
+def test_gemm_v2_glu_tile_major(lib, m, n, k):
+    """The GLU epilogue of the 4-wave engine (the conformer's pointwise_conv1: out[m][g*32+c] = a * sigmoid(b), a / b = columns
+    g*64+c / g*64+32+c), tile-major [m][n/2] output, against the fp32 reference and the 8-wave engine's row-major GLU on the same
+    operands; below the engine's tile threshold the combination is refused."""
+    from sonar_amd import _lib
+
+    g = torch.Generator(device="cuda").manual_seed(m + n + k)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).half()
+    bias = torch.randn(n, device="cuda", generator=g)
+    xt, wt = to_tile_major(x), to_tile_major(w)
+    ref = x.float() @ w.float().T + bias
+    r4 = ref.view(m, n // 64, 2, 32)
+    want = (r4[:, :, 0] * torch.sigmoid(r4[:, :, 1])).reshape(m, n // 2)
+    flags = 6 | _lib.SMI_GEMM_IN_TM
+    row = torch.full((m, n // 2), float("nan"), device="cuda", dtype=torch.float16)
+    _lib.check(lib.smi_gemm_tn(flags | (2 << 8), xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), row.data_ptr(), m, n, k, n // 2, _stream()))
+    outs = []
+    with _lib.tuning(G2V2=1, G2V2_MIN=1):
+        for rep in range(3):
+            out = torch.full((m * n // 2,), float("nan"), device="cuda", dtype=torch.float16)
+            _lib.check(lib.smi_gemm_tn(flags | _lib.SMI_GEMM_OUT_TM | (2 << 8), xt.data_ptr(), wt.data_ptr(), bias.data_ptr(),
+                                       out.data_ptr(), m, n, k, n // 2, _stream()))
+            torch.cuda.synchronize()
+            outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    got = from_tile_major(outs[0], m, n // 2).float()
+    scale = max(want.abs().max().item(), 1.0)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 2e-3 * scale
+    assert (row.float() - want).abs().max().item() <= 2e-3 * scale
+    assert (got - row.float()).abs().max().item() <= 2e-3 * scale
+    with _lib.tuning(G2V2=0):   # no other engine writes the GLU output tile-major: refused
+        assert lib.smi_gemm_tn(flags | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, n // 2,
+                               _stream()) != 0
+    assert lib.smi_gemm_tn(flags | _lib.SMI_GEMM_OUT_TM, xt.data_ptr(), wt.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, n,
+                           _stream()) != 0   # ldo must be n / 2
+
+
 @pytest.mark.parametrize("m,n,k,valid_n", [(1280, 32768, 1024, 32768 - 50),   # 640 tiles: 2-3 per workgroup, masked last column tile
                                            (256, 65536, 1024, 65536),          # one row tile, every tile full
                                            (512, 16384, 256, 16384 - 255),     # shortest K loop (8 slices); one valid column in the last tile
