@@ -572,7 +572,8 @@ def _relpos_attention_ref(qkv, lens, d, heads, rp, rp_zero, u, v):
 
 
 @pytest.mark.parametrize("lens,heads", [([40], 2), ([129, 7, 300], 4), ([499] * 6, 2), ([64] * 40, 2), ([1, 33, 128, 257], 16),
-                                        ([300] * 30, 4), ([97] * 100, 8)])   # 360 / 800 workgroups: more than one per CU
+                                        ([300] * 30, 4), ([97] * 100, 8),   # 360 / 800 workgroups: more than one per CU
+                                        ([1999, 700], 2)])                 # 63 key blocks: the position-row ring wraps 12 times
 def test_relpos_attention(lib, lens, heads):
     """The conformer's relative-position attention through `smi_relpos_attention` against an fp32 restatement: both kernels (per-wave
     global loads of the position rows + fp32 score pad; LDS ring + fp16 pad), row-major and tile-major output, clips shorter than
